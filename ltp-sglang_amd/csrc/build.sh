@@ -1,0 +1,22 @@
+#!/bin/bash
+# Build the C-ABI shared library for gfx950 (hipcc cross-compiles without a GPU).
+# Output: ltp-sglang_amd/lib/libsgl_mi355.so (git-ignored, travels with gpurun).
+set -euo pipefail
+HERE="$(cd "$(dirname "$0")" && pwd)"
+OUT="$HERE/../lib"
+mkdir -p "$OUT" "$HERE/.obj"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffast-math -fno-finite-math-only -Wno-unused-result -I$HERE"
+pids=()
+objs=()
+for src in "$HERE"/*.hip; do
+  obj="$HERE/.obj/$(basename "${src%.hip}").o"
+  objs+=("$obj")
+  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/common.h" -nt "$obj" ]; then
+    $HIPCC $FLAGS -c "$src" -o "$obj" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libsgl_mi355.so" "${objs[@]}"
+echo "built $OUT/libsgl_mi355.so"

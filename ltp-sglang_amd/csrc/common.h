@@ -1,0 +1,96 @@
+// Shared device/host helpers for the MI355X (gfx950) hot-path kernels.
+// Everything here is written for CDNA4 only: 64-lane wavefronts, MFMA 16x16x32,
+// OCP e4m3fn fp8.  There is no other target.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+// ---- C-ABI status / error convention (include/sgl_mi355.h) -------------------
+// The reference reports errors with TORCH_CHECK -> RuntimeError (message only,
+// sgl-kernel/csrc/gemm/fp8_gemm_kernel.cu:1078-1108).  The C-ABI returns an int
+// status and keeps the message in a thread-local buffer; the Python shim raises
+// RuntimeError(sgl_mi355_last_error()).
+#define SGL_MI355_OK 0
+#define SGL_MI355_EINVAL 1
+#define SGL_MI355_EHIP 2
+
+extern thread_local char g_sgl_mi355_err[512];
+
+#define SGL_CHECK(cond, ...)                                           \
+  do {                                                                 \
+    if (!(cond)) {                                                     \
+      snprintf(g_sgl_mi355_err, sizeof(g_sgl_mi355_err), __VA_ARGS__); \
+      return SGL_MI355_EINVAL;                                         \
+    }                                                                  \
+  } while (0)
+
+#define SGL_HIP_LAUNCH_CHECK()                                                         \
+  do {                                                                                 \
+    hipError_t e__ = hipGetLastError();                                                \
+    if (e__ != hipSuccess) {                                                           \
+      snprintf(g_sgl_mi355_err, sizeof(g_sgl_mi355_err), "HIP launch failed: %s (%s:%d)", \
+               hipGetErrorString(e__), __FILE__, __LINE__);                            \
+      return SGL_MI355_EHIP;                                                           \
+    }                                                                                  \
+  } while (0)
+
+// dtype codes shared with the Python shim
+enum SglDtype : int { SGL_BF16 = 0, SGL_F16 = 1, SGL_F32 = 2, SGL_FP8_E4M3 = 3 };
+
+// ---- vector types -------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+
+#define WAVE 64
+
+template <typename T>
+struct ElemTraits;
+
+template <>
+struct ElemTraits<__bf16> {
+  typedef bf16x8_t vec8;
+  typedef bf16x4_t vec4;
+  static __device__ __forceinline__ f32x4_t mfma16(vec8 a, vec8 b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ float to_f32(__bf16 x) { return (float)x; }
+  static __device__ __forceinline__ __bf16 from_f32(float x) { return (__bf16)x; }
+};
+
+template <>
+struct ElemTraits<_Float16> {
+  typedef f16x8_t vec8;
+  typedef f16x4_t vec4;
+  static __device__ __forceinline__ f32x4_t mfma16(vec8 a, vec8 b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ float to_f32(_Float16 x) { return (float)x; }
+  static __device__ __forceinline__ _Float16 from_f32(float x) { return (_Float16)x; }
+};
+
+// wave-wide xor shuffle (ds_bpermute / DPP chosen by the compiler)
+__device__ __forceinline__ float wave_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, WAVE); }
+
+__device__ __forceinline__ float wave_reduce_max(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, WAVE));
+  return v;
+}
+__device__ __forceinline__ float wave_reduce_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, WAVE);
+  return v;
+}
+
+static inline int cdiv_i(int a, int b) { return (a + b - 1) / b; }

@@ -1,0 +1,471 @@
+// Split-KV (flash-decoding) GQA decode attention over the paged token_to_kv_pool, gfx950.
+//
+// Replaces, for the hot path, the reference's decode kernels:
+//   python/sglang/srt/layers/attention/triton_ops/decode_attention.py:38-728
+//     (_fwd_grouped_kernel_stage1 / _fwd_kernel_stage1 / _fwd_kernel_stage2)
+//   sgl-kernel/csrc/cpu/decode.cpp:1375-1575 (decode_attention_cpu: same math, takes
+//     req_to_token/req_pool_indices/seq_lens instead of kv_indices)
+// and matches the semantics of the oracle torch_native_backend.py:112-180.
+//
+// Design (MI355X-first, see DESIGN.md "decode attention"):
+//  * one workgroup = NW independent wavefronts working on one (request, kv-head, kv-split);
+//    every wave owns whole 32-token tiles, a private 2 x 32 x D LDS image and its own
+//    online-softmax state, so the main loop has no workgroup barrier at all;
+//  * K/V rows are gathered through kv_indices with 16-byte loads in which 16 (D=128)
+//    consecutive lanes cover one contiguous 256-byte row: every HBM request is a whole row;
+//    the gather is register-staged and issued one tile ahead of the compute (loads of
+//    tile i+1 are in flight while tile i is consumed from LDS);
+//  * LDS images are XOR-swizzled so both the ds_read_b128 K-fragment reads and the
+//    ds_read_b64_tr_b16 transposed V reads are bank-conflict free;
+//  * QK^T is computed transposed (S^T = K Q^T) with v_mfma_f32_16x16x32, so that the
+//    accumulator (head on lane&15, 4 consecutive tokens in registers) is, after the
+//    in-register softmax (two DPP/bpermute xor-shuffles per row reduction), already the
+//    B operand of O^T = V^T P^T; all q heads of the GQA group share every K/V byte;
+//  * partial results use the reference's own scratch layout (attn_logits f32
+//    [bs, Hq, max_splits, Dv] holding acc/l, attn_lse f32 [bs, Hq, max_splits] holding
+//    m + log(l)) and stage 2 merges the splits by LSE exactly like _fwd_kernel_stage2.
+#include "common.h"
+
+namespace {
+
+struct DecodeParams {
+  const void* q;
+  int64_t q_stride_t;  // elements between tokens of q; heads are contiguous [Hq, D]
+  const void* k_buf;
+  const void* v_buf;
+  int64_t k_stride_t, k_stride_h, v_stride_t, v_stride_h;  // elements
+  void* o;
+  int64_t o_stride_t;
+  // index mode A (Triton backend metadata): kv_indptr/kv_indices
+  const int32_t* kv_indptr;
+  const int32_t* kv_indices;
+  // index mode B (CPU op schema): req_to_token[req_pool_indices[b], :seq_lens[b]]
+  const int32_t* req_to_token;
+  int64_t req_to_token_stride;
+  const int64_t* req_pool_indices;
+  const int64_t* seq_lens;
+  float* attn_logits;
+  float* attn_lse;
+  const int32_t* num_kv_splits;
+  int max_kv_splits;
+  int bs, hq, hkv, group, dv;
+  float sm_scale, logit_cap;
+};
+
+constexpr int kTile = 32;  // tokens per wave tile == reference _MIN_BLOCK_KV (decode_attention.py:35)
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+
+__device__ __forceinline__ void request_range(const DecodeParams& p, int b, const int32_t*& idx_row, int& seq_len) {
+  if (p.kv_indices != nullptr) {
+    const int s0 = p.kv_indptr[b];
+    seq_len = p.kv_indptr[b + 1] - s0;
+    idx_row = p.kv_indices + s0;
+  } else {
+    seq_len = (int)p.seq_lens[b];
+    idx_row = p.req_to_token + p.req_pool_indices[b] * p.req_to_token_stride;
+  }
+}
+
+__device__ __forceinline__ int split_len(int seq_len, int nsplit) {
+  // decode_attention.py:90-94: ceil(ceil(seq/splits)/MIN_BLOCK_KV)*MIN_BLOCK_KV
+  const int per = (seq_len + nsplit - 1) / nsplit;
+  return (per + kTile - 1) / kTile * kTile;
+}
+
+__device__ __forceinline__ float softcap_log2(float s_scaled, float cap) {
+  // cap * tanh(x / cap), tanh(y) = 2*sigmoid(2y) - 1 (decode_attention.py:38-41)
+  const float y = s_scaled / cap;
+  const float t = 2.0f / (1.0f + __expf(-2.0f * y)) - 1.0f;
+  return cap * t * kLog2e;
+}
+
+template <typename T, int D, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void decode_attn_stage1(const DecodeParams p) {
+  using Tr = ElemTraits<T>;
+  using vec8 = typename Tr::vec8;
+  constexpr int ROWB = D * 2;
+  constexpr int LPR = ROWB / 16;   // lanes covering one K/V row with 16-byte loads
+  constexpr int RPI = 64 / LPR;    // rows per wave-wide load instruction
+  constexpr int NI = kTile / RPI;  // load instructions per tile
+  constexpr int KS = D / 32;       // QK^T k-steps
+  constexpr int NT = D / 16;       // PV output column tiles
+  constexpr int TILE_B = kTile * ROWB;
+  constexpr int RPB = (ROWB >= 256) ? 1 : 256 / ROWB;  // rows per 256-B LDS bank row
+  constexpr int KMASK = (LPR < 16 ? LPR : 16) - 1;
+  constexpr int VCH = ROWB / 32;
+  constexpr int VMASK = (VCH < 8 ? VCH : 8) - 1;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int hchunks = (p.group + 15) >> 4;
+  const int kh = blockIdx.x / hchunks;
+  const int hc = blockIdx.x - kh * hchunks;
+  const int split = blockIdx.y;
+  const int b = blockIdx.z;
+  const int h0 = kh * p.group + hc * 16;
+  const int nh = min(16, p.group - hc * 16);
+
+  const int32_t* idx_row;
+  int seq_len;
+  request_range(p, b, idx_row, seq_len);
+  int nsplit = p.num_kv_splits[b];
+  nsplit = max(1, min(nsplit, p.max_kv_splits));
+  if (split >= nsplit) return;
+  const int per = split_len(seq_len, nsplit);
+  const int start = split * per;
+  const int end = min(start + per, seq_len);
+  if (start >= end) return;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int a = lane & 15;  // MFMA n index: q head within the chunk
+  const int g = lane >> 4;  // MFMA k/m group
+  const int c16 = lane % LPR;
+  const int rsub = lane / LPR;
+
+  char* kl = smem + w * (2 * TILE_B);
+  char* vl = kl + TILE_B;
+
+  // Q fragments: B operand of S^T = K Q^T, lane (a,g) holds Q[h0+a][32*ks + 8*g .. +8]
+  vec8 qf[KS];
+  {
+    const T* qrow = (const T*)p.q + (int64_t)b * p.q_stride_t + (int64_t)(h0 + a) * D;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (a < nh) {
+        qf[ks] = *(const vec8*)(qrow + 32 * ks + 8 * g);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[ks][j] = (T)0.0f;
+      }
+    }
+  }
+
+  const char* kbase = (const char*)p.k_buf + ((int64_t)kh * p.k_stride_h) * 2 + c16 * 16;
+  const char* vbase = (const char*)p.v_buf + ((int64_t)kh * p.v_stride_h) * 2 + c16 * 16;
+  const int64_t kst = p.k_stride_t * 2, vst = p.v_stride_t * 2;
+
+  const int ntiles = (end - start + kTile - 1) / kTile;
+  const float scale_log2 = p.sm_scale * kLog2e;
+  const bool use_cap = p.logit_cap > 0.0f;
+
+  float m_i = -INFINITY, l_i = 0.0f;
+  f32x4_t acc[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) acc[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  u32x4_t kreg[NI], vreg[NI];
+
+  auto load_idx = [&](int t) -> int {
+    const int tok = start + t * kTile + (lane & 31);
+    return (t < ntiles && tok < end) ? idx_row[tok] : 0;
+  };
+  auto issue = [&](int idxreg) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int id = __shfl(idxreg, i * RPI + rsub, WAVE);
+      kreg[i] = *(const u32x4_t*)(kbase + (int64_t)id * kst);
+      vreg[i] = *(const u32x4_t*)(vbase + (int64_t)id * vst);
+    }
+  };
+
+  int tile = w;
+  int idx_next = 0;
+  if (tile < ntiles) {
+    issue(load_idx(tile));
+    idx_next = load_idx(tile + NW);
+  }
+
+  for (; tile < ntiles; tile += NW) {
+    const int tok0 = start + tile * kTile;
+    // ---- staged registers -> swizzled LDS images (wave private, no barrier) ----
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int row = i * RPI + rsub;
+      const int fk = (row / RPB) & KMASK;
+      const int fv = (row / RPB) & VMASK;
+      *(u32x4_t*)(kl + row * ROWB + ((c16 ^ fk) << 4)) = kreg[i];
+      u32x4_t vv = vreg[i];
+      if (tok0 + row >= end) vv = u32x4_t{0u, 0u, 0u, 0u};  // 0 * garbage must stay 0
+      *(u32x4_t*)(vl + row * ROWB + ((((c16 >> 1) ^ fv) << 5) | ((c16 & 1) << 4))) = vv;
+    }
+    // ---- issue the gather of this wave's next tile, prefetch indices two tiles ahead ----
+    if (tile + NW < ntiles) issue(idx_next);
+    idx_next = load_idx(tile + 2 * NW);
+
+    // ---- S^T = K Q^T for two 16-token halves ----
+    f32x4_t s[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      s[tt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      const int row = 16 * tt + a;
+      const int fk = (row / RPB) & KMASK;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int chunk = 4 * ks + g;
+        const vec8 kf = *(const vec8*)(kl + row * ROWB + ((chunk ^ fk) << 4));
+        s[tt] = Tr::mfma16(kf, qf[ks], s[tt]);
+      }
+    }
+    // ---- online softmax; lane (a,g) holds head a, tokens 16*tt + 4*g + r ----
+    float x[2][4];
+    float mt = -INFINITY;
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int tok = tok0 + 16 * tt + 4 * g + r;
+        float v = use_cap ? softcap_log2(s[tt][r] * p.sm_scale, p.logit_cap) : s[tt][r] * scale_log2;
+        v = (tok < end) ? v : -INFINITY;
+        x[tt][r] = v;
+        mt = fmaxf(mt, v);
+      }
+    }
+    mt = fmaxf(mt, __shfl_xor(mt, 16, WAVE));
+    mt = fmaxf(mt, __shfl_xor(mt, 32, WAVE));
+    const float m_new = fmaxf(m_i, mt);  // finite: every tile holds >= 1 valid token
+    const float alpha = __builtin_amdgcn_exp2f(m_i - m_new);
+    float lsum = 0.0f;
+    vec8 pf;
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pv = __builtin_amdgcn_exp2f(x[tt][r] - m_new);
+        lsum += pv;
+        pf[4 * tt + r] = Tr::from_f32(pv);  // P is rounded to the V dtype before PV (decode_attention.py:373)
+      }
+    }
+    l_i = l_i * alpha + lsum;  // per-lane partial; the 4 g-lanes of a head are summed once at the end
+    m_i = m_new;
+    // ---- O^T += V^T P^T ----
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      acc[n] *= alpha;
+      s16x4_t t0, t1;
+      {
+        const int row = 4 * g + (a >> 2);
+        const int fv = (row / RPB) & VMASK;
+        t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (s16x4_t __attribute__((address_space(3)))*)(vl + row * ROWB + ((n ^ fv) << 5) + ((a & 3) << 3)));
+      }
+      {
+        const int row = 16 + 4 * g + (a >> 2);
+        const int fv = (row / RPB) & VMASK;
+        t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (s16x4_t __attribute__((address_space(3)))*)(vl + row * ROWB + ((n ^ fv) << 5) + ((a & 3) << 3)));
+      }
+      const s16x8_t t01 = __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+      acc[n] = Tr::mfma16(__builtin_bit_cast(vec8, t01), pf, acc[n]);
+    }
+  }
+
+  // ---- merge the NW wave-private states, write the split partial ----
+  l_i += __shfl_xor(l_i, 16, WAVE);
+  l_i += __shfl_xor(l_i, 32, WAVE);
+  __syncthreads();
+  float* red_m = (float*)smem;       // [NW][16]
+  float* red_l = red_m + NW * 16;    // [NW][16]
+  float* red_acc = red_l + NW * 16;  // [NW][16][D]
+  if (a < nh) {
+    if (g == 0) {
+      red_m[w * 16 + a] = m_i;
+      red_l[w * 16 + a] = l_i;
+    }
+#pragma unroll
+    for (int n = 0; n < NT; ++n) *(f32x4_t*)(red_acc + (w * 16 + a) * D + 16 * n + 4 * g) = acc[n];
+  }
+  __syncthreads();
+  for (int out = tid; out < nh * D; out += NW * 64) {
+    const int h = out / D, d = out - h * D;
+    float M = -INFINITY;
+#pragma unroll
+    for (int ww = 0; ww < NW; ++ww) M = fmaxf(M, red_m[ww * 16 + h]);
+    float L = 0.f, val = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < NW; ++ww) {
+      const float sc = __builtin_amdgcn_exp2f(red_m[ww * 16 + h] - M);
+      L += red_l[ww * 16 + h] * sc;
+      val += red_acc[(ww * 16 + h) * D + d] * sc;
+    }
+    const int64_t slot = ((int64_t)b * p.hq + (h0 + h)) * p.max_kv_splits + split;
+    p.attn_logits[slot * D + d] = val / L;
+    if (d == 0) p.attn_lse[slot] = M * kLn2 + __logf(L);
+  }
+}
+
+// Any-head-dim fallback (D, Dv <= 256, not multiples of 32 allowed): one wave per
+// (request, q head, split).  Correctness path for the reference's odd test shapes
+// (test_triton_attention_kernels.py: D in {96, 80, 13}); not a performance path.
+template <typename T>
+__global__ __launch_bounds__(64) void decode_attn_stage1_generic(const DecodeParams p, int d_qk) {
+  __shared__ float p_lds[64];
+  __shared__ int id_lds[64];
+  const int h = blockIdx.x, split = blockIdx.y, b = blockIdx.z;
+  const int kh = h / p.group;
+  const int lane = threadIdx.x;
+  const int32_t* idx_row;
+  int seq_len;
+  request_range(p, b, idx_row, seq_len);
+  int nsplit = max(1, min(p.num_kv_splits[b], p.max_kv_splits));
+  if (split >= nsplit) return;
+  const int per = split_len(seq_len, nsplit);
+  const int start = split * per, end = min(start + per, seq_len);
+  if (start >= end) return;
+  const T* qrow = (const T*)p.q + (int64_t)b * p.q_stride_t + (int64_t)h * d_qk;
+  const int dv = p.dv;
+  float accv[4] = {0.f, 0.f, 0.f, 0.f};  // dv <= 256: lane owns columns lane, lane+64, ...
+  float m_i = -INFINITY, l_i = 0.f;
+  for (int t0 = start; t0 < end; t0 += 64) {
+    const int tok = t0 + lane;
+    const bool valid = tok < end;
+    const int id = valid ? idx_row[tok] : 0;
+    float sdot = 0.f;
+    if (valid) {
+      const T* krow = (const T*)p.k_buf + (int64_t)id * p.k_stride_t + (int64_t)kh * p.k_stride_h;
+      for (int d = 0; d < d_qk; ++d) sdot += (float)qrow[d] * (float)krow[d];
+    }
+    float xv = sdot * p.sm_scale;
+    xv = (p.logit_cap > 0.f) ? softcap_log2(xv, p.logit_cap) : xv * kLog2e;
+    xv = valid ? xv : -INFINITY;
+    const float m_new = fmaxf(m_i, wave_reduce_max(xv));
+    const float alpha = __builtin_amdgcn_exp2f(m_i - m_new);
+    const float pv = __builtin_amdgcn_exp2f(xv - m_new);
+    l_i = l_i * alpha + wave_reduce_sum(pv);
+    m_i = m_new;
+    __syncthreads();
+    p_lds[lane] = (float)(T)pv;
+    id_lds[lane] = id;
+    __syncthreads();
+    const int nt = min(64, end - t0);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int d = lane + 64 * c;
+      float av = accv[c] * alpha;
+      if (d < dv) {
+        for (int t = 0; t < nt; ++t) {
+          const T* vrow = (const T*)p.v_buf + (int64_t)id_lds[t] * p.v_stride_t + (int64_t)kh * p.v_stride_h;
+          av += p_lds[t] * (float)vrow[d];
+        }
+      }
+      accv[c] = av;
+    }
+  }
+  const int64_t slot = ((int64_t)b * p.hq + h) * p.max_kv_splits + split;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int d = lane + 64 * c;
+    if (d < dv) p.attn_logits[slot * dv + d] = accv[c] / l_i;
+  }
+  if (lane == 0) p.attn_lse[slot] = m_i * kLn2 + __logf(l_i);
+}
+
+// Stage 2: LSE merge of the split partials (decode_attention.py:492-552).
+template <typename T>
+__global__ __launch_bounds__(128) void decode_attn_stage2(const DecodeParams p) {
+  const int b = blockIdx.x, h = blockIdx.y;
+  const int32_t* idx_row;
+  int seq_len;
+  request_range(p, b, idx_row, seq_len);
+  const int nsplit = max(1, min(p.num_kv_splits[b], p.max_kv_splits));
+  const int per = split_len(seq_len, nsplit);
+  const int dv = p.dv;
+  const int64_t slot0 = ((int64_t)b * p.hq + h) * p.max_kv_splits;
+  for (int d = threadIdx.x; d < dv; d += blockDim.x) {
+    float M = -INFINITY, L = 0.f, accv = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+      if (s * per < seq_len) {
+        const float lse = p.attn_lse[slot0 + s];
+        const float v = p.attn_logits[(slot0 + s) * dv + d];
+        const float nM = fmaxf(M, lse);
+        const float so = __expf(M - nM), sn = __expf(lse - nM);
+        accv = accv * so + v * sn;
+        L = L * so + sn;
+        M = nM;
+      }
+    }
+    const float r = (L > 0.f) ? accv / L : 0.f;
+    ((T*)p.o)[(int64_t)b * p.o_stride_t + (int64_t)h * dv + d] = ElemTraits<T>::from_f32(r);
+  }
+}
+
+template <typename T, int D>
+int launch_mfma(const DecodeParams& p, hipStream_t st) {
+  constexpr int NW = 4;
+  constexpr int smem = NW * 2 * kTile * D * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)decode_attn_stage1<T, D, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  const int hchunks = (p.group + 15) / 16;
+  dim3 grid(p.hkv * hchunks, p.max_kv_splits, p.bs);
+  hipLaunchKernelGGL((decode_attn_stage1<T, D, NW>), grid, dim3(NW * 64), smem, st, p);
+  SGL_HIP_LAUNCH_CHECK();
+  return SGL_MI355_OK;
+}
+
+template <typename T>
+int launch_all(const DecodeParams& p, int d_qk, hipStream_t st) {
+  int rc;
+  if (d_qk == p.dv && d_qk == 128) {
+    rc = launch_mfma<T, 128>(p, st);
+  } else if (d_qk == p.dv && d_qk == 64) {
+    rc = launch_mfma<T, 64>(p, st);
+  } else {
+    dim3 grid(p.hq, p.max_kv_splits, p.bs);
+    hipLaunchKernelGGL((decode_attn_stage1_generic<T>), grid, dim3(64), 0, st, p, d_qk);
+    SGL_HIP_LAUNCH_CHECK();
+    rc = SGL_MI355_OK;
+  }
+  if (rc != SGL_MI355_OK) return rc;
+  hipLaunchKernelGGL((decode_attn_stage2<T>), dim3(p.bs, p.hq), dim3(128), 0, st, p);
+  SGL_HIP_LAUNCH_CHECK();
+  return SGL_MI355_OK;
+}
+
+}  // namespace
+
+extern "C" int sgl_mi355_decode_attention(
+    const void* q, int64_t q_stride_t, const void* k_buffer, const void* v_buffer, int64_t k_stride_t,
+    int64_t k_stride_h, int64_t v_stride_t, int64_t v_stride_h, void* o, int64_t o_stride_t, const int32_t* kv_indptr,
+    const int32_t* kv_indices, const int32_t* req_to_token, int64_t req_to_token_stride, const int64_t* req_pool_indices,
+    const int64_t* seq_lens, float* attn_logits, float* attn_lse, const int32_t* num_kv_splits, int max_kv_splits,
+    int batch, int num_q_heads, int num_kv_heads, int head_dim, int v_head_dim, float sm_scale, float logit_cap,
+    int dtype, void* stream) {
+  SGL_CHECK(batch >= 0, "decode_attention: negative batch %d", batch);
+  if (batch == 0) return SGL_MI355_OK;
+  SGL_CHECK(q && k_buffer && v_buffer && o, "decode_attention: null tensor pointer");
+  SGL_CHECK(attn_logits && attn_lse && num_kv_splits, "decode_attention: null split scratch pointer");
+  SGL_CHECK((kv_indptr && kv_indices) || (req_to_token && req_pool_indices && seq_lens),
+            "decode_attention: need either (kv_indptr, kv_indices) or (req_to_token, req_pool_indices, seq_lens)");
+  SGL_CHECK(num_kv_heads > 0 && num_q_heads % num_kv_heads == 0, "decode_attention: Hq=%d not a multiple of Hkv=%d",
+            num_q_heads, num_kv_heads);
+  SGL_CHECK(head_dim > 0 && head_dim <= 256 && v_head_dim > 0 && v_head_dim <= 256,
+            "decode_attention: head dims (%d, %d) outside (0, 256]", head_dim, v_head_dim);
+  SGL_CHECK(max_kv_splits >= 1 && max_kv_splits <= 65535, "decode_attention: max_kv_splits=%d out of range",
+            max_kv_splits);
+  SGL_CHECK(batch <= 65535, "decode_attention: batch %d exceeds grid.z limit", batch);
+  SGL_CHECK(dtype == SGL_BF16 || dtype == SGL_F16, "decode_attention: dtype code %d unsupported (bf16=0, f16=1)", dtype);
+  if (head_dim == v_head_dim && (head_dim == 128 || head_dim == 64)) {
+    SGL_CHECK(k_stride_t % 8 == 0 && v_stride_t % 8 == 0 && k_stride_h % 8 == 0 && v_stride_h % 8 == 0 &&
+                  q_stride_t % 8 == 0 && ((uintptr_t)k_buffer % 16) == 0 && ((uintptr_t)v_buffer % 16) == 0 &&
+                  ((uintptr_t)q % 16) == 0,
+              "decode_attention: q/k/v rows must be 16-byte aligned for the MFMA path");
+  }
+  DecodeParams p;
+  p.q = q; p.q_stride_t = q_stride_t;
+  p.k_buf = k_buffer; p.v_buf = v_buffer;
+  p.k_stride_t = k_stride_t; p.k_stride_h = k_stride_h; p.v_stride_t = v_stride_t; p.v_stride_h = v_stride_h;
+  p.o = o; p.o_stride_t = o_stride_t;
+  p.kv_indptr = kv_indptr; p.kv_indices = kv_indices;
+  p.req_to_token = req_to_token; p.req_to_token_stride = req_to_token_stride;
+  p.req_pool_indices = req_pool_indices; p.seq_lens = seq_lens;
+  p.attn_logits = attn_logits; p.attn_lse = attn_lse; p.num_kv_splits = num_kv_splits; p.max_kv_splits = max_kv_splits;
+  p.bs = batch; p.hq = num_q_heads; p.hkv = num_kv_heads; p.group = num_q_heads / num_kv_heads; p.dv = v_head_dim;
+  p.sm_scale = sm_scale; p.logit_cap = logit_cap;
+  hipStream_t st = (hipStream_t)stream;
+  return dtype == SGL_BF16 ? launch_all<__bf16>(p, head_dim, st) : launch_all<_Float16>(p, head_dim, st);
+}
