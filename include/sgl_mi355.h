@@ -1,0 +1,129 @@
+/*
+ * sgl_mi355.h -- C ABI of the MI355X (gfx950) hot path: attention over the paged token_to_kv_pool,
+ * fp8 / int4-AWQ dequant GEMM and their integer/elementwise neighbours.
+ *
+ * Conventions:
+ *  - every tensor argument is a raw DEVICE pointer plus sizes/strides (strides in ELEMENTS unless the
+ *    name says bytes); no torch types cross this boundary;
+ *  - every launcher is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream),
+ *    performs no allocation and no host synchronisation, so it can be captured into a hipGraph
+ *    (reference requirement: cuda_graph_runner.py:280,618,760);
+ *  - return value: 0 = ok, 1 = invalid argument, 2 = HIP launch error; the text is available from
+ *    sgl_mi355_last_error() (thread local).  The reference signals the same conditions with
+ *    TORCH_CHECK -> RuntimeError (sgl-kernel/csrc/gemm/fp8_gemm_kernel.cu:1078-1108); the Python shim
+ *    (ltp-sglang_amd/_cabi.py) converts a non-zero status into RuntimeError(message).
+ *  - dtype codes: 0 = bf16, 1 = f16, 2 = f32, 3 = fp8 e4m3fn (OCP; gfx950 is not fnuz).
+ *  - "*_is64" flags give the width of an index tensor (0 = int32, 1 = int64), because the reference
+ *    holds the same logical tensor as int64 on the scheduler side and int32 in CUDA-graph buffers.
+ *
+ * Each entry point cites the reference interface it replaces.
+ */
+#ifndef SGL_MI355_H
+#define SGL_MI355_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGL_MI355_BF16 0
+#define SGL_MI355_F16 1
+#define SGL_MI355_F32 2
+#define SGL_MI355_FP8_E4M3 3
+
+/* ---- plumbing --------------------------------------------------------------------------- */
+const char* sgl_mi355_last_error(void);
+int sgl_mi355_abi_version(void);
+/* python/sglang/srt/utils.py get_device_core_count (feeds triton_backend.py:124-158) */
+int sgl_mi355_device_cu_count(int device);
+
+/* ---- attention -------------------------------------------------------------------------- */
+/* Split-KV GQA decode attention + LSE merge.
+ * Replaces decode_attention_fwd (python/sglang/srt/layers/attention/triton_ops/decode_attention.py:677-728)
+ * when (kv_indptr, kv_indices) are given, and decode_attention_cpu's addressing
+ * (sgl-kernel/csrc/cpu/decode.cpp:1375-1575, schema torch_extension_cpu.cpp:264-268) when
+ * (req_to_token, req_pool_indices, seq_lens) are given instead (kv_indices == NULL).
+ * q [batch, Hq, D] (heads contiguous), k/v_buffer [slots, Hkv, D|Dv], o [batch, Hq, Dv],
+ * attn_logits f32 [batch, Hq, max_kv_splits, Dv], attn_lse f32 [batch, Hq, max_kv_splits]. */
+int sgl_mi355_decode_attention(const void* q, int64_t q_stride_t, const void* k_buffer, const void* v_buffer,
+                               int64_t k_stride_t, int64_t k_stride_h, int64_t v_stride_t, int64_t v_stride_h, void* o,
+                               int64_t o_stride_t, const int32_t* kv_indptr, const int32_t* kv_indices,
+                               const int32_t* req_to_token, int64_t req_to_token_stride, const int64_t* req_pool_indices,
+                               const int64_t* seq_lens, float* attn_logits, float* attn_lse, const int32_t* num_kv_splits,
+                               int max_kv_splits, int batch, int num_q_heads, int num_kv_heads, int head_dim,
+                               int v_head_dim, float sm_scale, float logit_cap, int dtype, void* stream);
+
+/* ---- KV pool / index kernels (bit-exact) -------------------------------------------------- */
+/* create_flashinfer_kv_indices_triton, python/sglang/srt/layers/attention/utils.py:10-45 */
+int sgl_mi355_create_kv_indices(const int32_t* req_to_token, int64_t req_to_token_stride, const void* req_pool_indices,
+                                int req_pool_indices_is64, const void* page_kernel_lens, int page_kernel_lens_is64,
+                                const int32_t* kv_indptr, const void* kv_start_idx, int kv_start_idx_is64,
+                                int32_t* kv_indices, int batch, void* stream);
+/* compute_position_triton / compute_position_torch, model_executor/forward_batch_info.py:885-955 */
+int sgl_mi355_compute_position(int64_t* positions, int32_t* extend_start_loc, const void* extend_prefix_lens,
+                               int prefix_is64, const void* extend_seq_lens, int seq_is64, int batch, void* stream);
+/* write_req_to_token_pool_triton, managers/schedule_batch.py:1920-1955 */
+int sgl_mi355_write_req_to_token(int32_t* req_to_token, int64_t req_to_token_stride, const void* req_pool_indices,
+                                 int req_pool_indices_is64, const void* pre_lens, int pre_is64, const void* seq_lens,
+                                 int seq_is64, const void* extend_lens, int ext_is64, const int64_t* out_cache_loc,
+                                 int batch, void* stream);
+/* get_last_loc_triton / get_last_loc_torch, managers/schedule_batch.py:1958-2028 */
+int sgl_mi355_get_last_loc(const int32_t* req_to_token, int64_t req_to_token_stride, const void* req_pool_indices,
+                           int req_pool_indices_is64, const void* prefix_lens, int prefix_is64, void* result,
+                           int result_is64, int64_t n, void* stream);
+/* MHATokenToKVPool.set_kv_buffer, mem_cache/memory_pool.py:369-407 (K and V scatter in one launch) */
+int sgl_mi355_set_kv_buffer(void* k_buffer, void* v_buffer, int64_t k_slot_bytes, int64_t v_slot_bytes,
+                            const int64_t* loc, const void* cache_k, const void* cache_v, int64_t cache_k_stride_bytes,
+                            int64_t cache_v_stride_bytes, int k_row_bytes, int v_row_bytes, int64_t tokens, void* stream);
+/* kv_indptr[1:bs+1] = cumsum(seq_lens) (triton_backend.py:172) and get_num_kv_splits_triton
+ * (triton_backend.py:876-924); either output may be NULL. */
+int sgl_mi355_decode_metadata(int32_t* kv_indptr, int32_t* num_kv_splits, const void* seq_lens, int seq_is64,
+                              int num_seq, int num_group, int num_head, int num_kv_head, int max_kv_splits,
+                              int device_core_count, int static_splits, void* stream);
+
+/* ---- fp8 activation quantisation (bit-exact with the reference's torch restatements) -------- */
+/* sgl_per_token_quant_fp8, sgl-kernel/csrc/gemm/per_token_quant_fp8.cu:15-228; python gemm.py:140-145 */
+int sgl_mi355_per_token_quant_fp8(const void* input, int64_t input_stride, void* output_q, float* output_s,
+                                  int64_t num_tokens, int64_t hidden_dim, int in_dtype, void* stream);
+/* sgl_per_tensor_quant_fp8, sgl-kernel/csrc/gemm/per_tensor_quant_fp8.cu:10-123; python gemm.py:129-137.
+ * Dynamic mode (is_static == 0) atomically maxes into *output_s, which the caller zero-initialises. */
+int sgl_mi355_per_tensor_quant_fp8(const void* input, void* output_q, float* output_s, int64_t num_elements,
+                                   int is_static, int in_dtype, void* stream);
+/* sgl_per_token_group_quant_fp8, sgl-kernel/csrc/gemm/per_token_group_quant_8bit.cu; python gemm.py:100-112
+ * (row-major float scales; scale_ue8m0 / column-major layouts are DeepSeek-only and out of scope) */
+int sgl_mi355_per_token_group_quant_fp8(const void* input, void* output_q, float* output_s, int64_t num_elements,
+                                        int group_size, float eps, float fp8_min, float fp8_max, int in_dtype,
+                                        void* stream);
+
+/* ---- GEMM --------------------------------------------------------------------------------- */
+/* Weight-streaming GEMM for M <= 64: Y = (X . W^T) * scales_x[m] * scales_w[n] + bias[n].
+ * in_dtype fp8: fp8_scaled_mm (sgl-kernel/csrc/gemm/fp8_gemm_kernel.cu:1071-1146, python gemm.py:34-42) with
+ * W = mat_b^T stored [N, K] row-major; in_dtype bf16/f16 with NULL scales: the unquantised linear
+ * (python/sglang/srt/layers/quantization/unquant.py) used by lm_head. */
+int sgl_mi355_skinny_gemm(const void* x, int64_t x_stride_elems, const void* w, int64_t w_stride_elems, void* y,
+                          int64_t y_stride_elems, const float* scales_x, const float* scales_w, const void* bias, int M,
+                          int N, int K, int in_dtype, int out_dtype, void* stream);
+
+/* ---- elementwise neighbours on the step path -------------------------------- */
+/* RMSNorm.forward_native, python/sglang/srt/layers/layernorm.py:135-171; sgl_kernel rmsnorm / fused_add_rmsnorm
+ * (sgl-kernel/csrc/elementwise/fused_add_rms_norm_kernel.cu).  residual != NULL: residual += x, out = norm(sum). */
+int sgl_mi355_rmsnorm(void* out, const void* x, void* residual, const void* weight, float eps, int64_t tokens,
+                      int hidden, int64_t x_stride, int64_t out_stride, int dtype, void* stream);
+/* SiluAndMul.forward_native, layers/activation.py:60-63; sgl_kernel silu_and_mul (csrc/elementwise/activation.cu) */
+int sgl_mi355_silu_and_mul(void* out, const void* x, int64_t tokens, int d, int dtype, void* stream);
+/* RotaryEmbedding.forward_native, layers/rotary_embedding.py:49-72,138-165 (in place on query/key) */
+int sgl_mi355_rotary_embedding(const int64_t* positions, void* query, void* key, const float* cos_sin_cache,
+                               int64_t tokens, int num_q_heads, int num_k_heads, int head_size, int rot_dim,
+                               int64_t q_stride, int64_t k_stride, int is_neox, int dtype, void* stream);
+/* VocabParallelEmbedding forward (F.embedding), layers/vocab_parallel_embedding.py */
+int sgl_mi355_embedding(void* out, const int64_t* ids, const void* table, int64_t tokens, int hidden, int dtype,
+                        void* stream);
+/* greedy sampling: torch.argmax(logits, -1), layers/sampler.py */
+int sgl_mi355_argmax(int64_t* out, const void* logits, int64_t rows, int64_t vocab, int64_t row_stride, int dtype,
+                     void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGL_MI355_H */

@@ -1,16 +1,47 @@
-"""ctypes binding of the C-ABI shared library (include/sgl_mi355.h).
+"""ctypes binding of the C-ABI shared library, generated from include/sgl_mi355.h.
 
-The product path has no CPU fallback: if the HIP library is missing or an entry
-point is absent, importing this module raises.  Errors reported by the library are
-re-raised as RuntimeError carrying the library's message, the same convention as the
+The product path has no CPU fallback: if the HIP library is missing, or lacks an entry
+point the header declares, importing this module raises.  Errors reported by the library
+are re-raised as RuntimeError carrying the library's message -- the convention of the
 reference's TORCH_CHECK (sgl-kernel/csrc/gemm/fp8_gemm_kernel.cu:1078-1108).
 """
 import ctypes
 import os
-from ctypes import c_float, c_int, c_int64, c_void_p
+import re
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libsgl_mi355.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "sgl_mi355.h")
+
+BF16, F16, F32, FP8_E4M3 = 0, 1, 2, 3
+
+
+def parse_header(path=HEADER_PATH):
+    """[(name, restype, [argtypes])] for every prototype in the header."""
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    protos = []
+    for m in re.finditer(r"\n\s*(const char\*|int)\s+(sgl_mi355_\w+)\s*\(([^)]*)\)\s*;", text):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        argtypes = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = " ".join(a.split())
+                if "*" in a:
+                    argtypes.append(c_void_p)
+                elif a.startswith("int64_t"):
+                    argtypes.append(c_int64)
+                elif a.startswith("int"):
+                    argtypes.append(c_int)
+                elif a.startswith("float"):
+                    argtypes.append(c_float)
+                else:
+                    raise RuntimeError(f"{name}: cannot map C parameter '{a}'")
+        protos.append((name, c_char_p if ret.startswith("const char") else c_int, argtypes))
+    return protos
+
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -19,26 +50,12 @@ if not os.path.exists(LIB_PATH):
     )
 
 lib = ctypes.CDLL(LIB_PATH)
-
-BF16, F16, F32, FP8_E4M3 = 0, 1, 2, 3
-
-# name -> (restype, argtypes); kept in one table so tests can check it against the header
-SIGNATURES = {
-    "sgl_mi355_last_error": (ctypes.c_char_p, []),
-    "sgl_mi355_abi_version": (c_int, []),
-    "sgl_mi355_device_cu_count": (c_int, [c_int]),
-    "sgl_mi355_decode_attention": (
-        c_int,
-        [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int64,
-         c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-         c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_int, c_void_p],
-    ),
-}
-
-for _name, (_res, _args) in SIGNATURES.items():
-    _fn = getattr(lib, _name)  # AttributeError here == library/header mismatch: fail loudly
+SIGNATURES = {}
+for _name, _res, _args in parse_header():
+    _fn = getattr(lib, _name)  # AttributeError == library/header mismatch: fail loudly
     _fn.restype = _res
     _fn.argtypes = _args
+    SIGNATURES[_name] = (_res, _args)
 
 
 def last_error() -> str:
@@ -67,6 +84,18 @@ def dtype_code(dtype) -> int:
 def ptr(t):
     """Raw device pointer of a tensor (None -> NULL)."""
     return None if t is None else t.data_ptr()
+
+
+def is64(t) -> int:
+    import torch
+
+    if t is None:
+        return 0
+    if t.dtype == torch.int64:
+        return 1
+    if t.dtype == torch.int32:
+        return 0
+    raise RuntimeError(f"index tensor must be int32 or int64, got {t.dtype}")
 
 
 def current_stream() -> int:

@@ -6,7 +6,9 @@ HERE="$(cd "$(dirname "$0")" && pwd)"
 OUT="$HERE/../lib"
 mkdir -p "$OUT" "$HERE/.obj"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffast-math -fno-finite-math-only -Wno-unused-result -I$HERE"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -I$HERE"
+# a flag change invalidates every object
+if [ "$(cat "$HERE/.obj/flags.txt" 2>/dev/null)" != "$FLAGS" ]; then rm -f "$HERE"/.obj/*.o; echo "$FLAGS" > "$HERE/.obj/flags.txt"; fi
 pids=()
 objs=()
 for src in "$HERE"/*.hip; do

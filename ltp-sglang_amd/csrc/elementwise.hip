@@ -1,0 +1,273 @@
+// Elementwise neighbours of the hot path on the decode/extend step: RMSNorm (+fused
+// residual add), SiLU*mul, rotary embedding, embedding gather, greedy argmax.
+//
+// Rounding points follow the reference's torch-native forwards so that an end-to-end step can be
+// compared with the torch-native model at the logits level:
+//   RMSNorm.forward_native       python/sglang/srt/layers/layernorm.py:135-171
+//       xf = f32(x) [+ f32(residual)]; residual' = T(xf); y = T((xf * rsqrt(mean(xf^2) + eps)) * w)
+//   SiluAndMul.forward_native    python/sglang/srt/layers/activation.py:60-63
+//       T(T(silu(a)) * b)   (silu evaluated in f32, rounded to T, product rounded to T)
+//   RotaryEmbedding.forward_native + _apply_rotary_emb  rotary_embedding.py:49-72,138-165
+//       cos/sin are cast to T first; every product and the add/sub round to T
+// Native CUDA counterparts (not built for ROCm by the reference): sgl-kernel/csrc/elementwise/*.cu.
+// All kernels are HBM/L2-bound byte work: 16-byte accesses, one workgroup (or wave) per token row.
+#include "common.h"
+
+namespace {
+
+template <typename T>
+struct V8 {
+  T v[8];
+};
+
+template <typename T>
+__device__ __forceinline__ V8<T> ld8(const T* p) {
+  return __builtin_bit_cast(V8<T>, *(const u32x4_t*)p);
+}
+template <typename T>
+__device__ __forceinline__ void st8(T* p, const V8<T>& x) {
+  *(u32x4_t*)p = __builtin_bit_cast(u32x4_t, x);
+}
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+  v = wave_reduce_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// x, residual updated in place when residual != null (sgl_kernel.fused_add_rmsnorm contract);
+// otherwise out = rmsnorm(x).  hidden % 8 == 0.  Up to 8192 columns stay in registers.
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(T* out, const T* x, T* residual, const T* weight, float eps,
+                                                      int hidden, int64_t x_stride, int64_t out_stride) {
+  __shared__ float red[4];
+  const int64_t row = blockIdx.x;
+  const T* xr = x + row * x_stride;
+  T* rr = residual ? residual + row * (int64_t)hidden : nullptr;
+  T* orow = out + row * out_stride;
+  const int nvec = hidden / 8;
+  float vals[MAXV][8];
+  float ss = 0.f;
+#pragma unroll
+  for (int it = 0; it < MAXV; ++it) {
+    const int i = threadIdx.x + it * 256;
+    if (i < nvec) {
+      const V8<T> a = ld8(xr + i * 8);
+      if (rr) {
+        const V8<T> r = ld8(rr + i * 8);
+        V8<T> ro;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float f = (float)a.v[j] + (float)r.v[j];
+          vals[it][j] = f;
+          ro.v[j] = (T)f;
+        }
+        st8(rr + i * 8, ro);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) vals[it][j] = (float)a.v[j];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ss += vals[it][j] * vals[it][j];
+    }
+  }
+  const float var = block_sum_256(ss, red) / (float)hidden;
+  const float rs = 1.0f / sqrtf(var + eps);
+#pragma unroll
+  for (int it = 0; it < MAXV; ++it) {
+    const int i = threadIdx.x + it * 256;
+    if (i < nvec) {
+      const V8<T> w = ld8(weight + i * 8);
+      V8<T> o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o.v[j] = (T)((vals[it][j] * rs) * (float)w.v[j]);
+      st8(orow + i * 8, o);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void silu_and_mul_kernel(T* out, const T* x, int64_t tokens, int d) {
+  const int nvec = d / 8;
+  const int64_t total = tokens * nvec;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t t = idx / nvec;
+    const int c = (int)(idx - t * nvec);
+    const V8<T> a = ld8(x + t * 2 * d + c * 8);
+    const V8<T> b = ld8(x + t * 2 * d + d + c * 8);
+    V8<T> o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float af = (float)a.v[j];
+      const T s = (T)(af / (1.0f + expf(-af)));
+      o.v[j] = (T)((float)s * (float)b.v[j]);
+    }
+    st8(out + t * d + c * 8, o);
+  }
+}
+
+// In-place rotary embedding on q [T, Hq, hs] and k [T, Hk, hs] (token strides given), cos_sin_cache f32
+// [max_pos, rot_dim] = cat(cos, sin).  One thread per rotation pair.
+template <typename T>
+__global__ __launch_bounds__(256) void rope_kernel(T* q, T* k, const int64_t* positions, const float* cache, int64_t tokens,
+                                                   int hq, int hk, int head_size, int rot_dim, int64_t q_stride,
+                                                   int64_t k_stride, int is_neox) {
+  const int half = rot_dim / 2;
+  const int pairs_per_token = (hq + hk) * half;
+  const int64_t total = tokens * pairs_per_token;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t t = idx / pairs_per_token;
+    const int rem = (int)(idx - t * pairs_per_token);
+    const int h = rem / half, i = rem - h * half;
+    T* base = (h < hq) ? q + t * q_stride + (int64_t)h * head_size : k + t * k_stride + (int64_t)(h - hq) * head_size;
+    const float* cs = cache + positions[t] * rot_dim;
+    const T c = (T)cs[i], s = (T)cs[half + i];
+    const int i1 = is_neox ? i : 2 * i, i2 = is_neox ? half + i : 2 * i + 1;
+    const T x1 = base[i1], x2 = base[i2];
+    const T p11 = (T)((float)x1 * (float)c), p22 = (T)((float)x2 * (float)s);
+    const T p21 = (T)((float)x2 * (float)c), p12 = (T)((float)x1 * (float)s);
+    base[i1] = (T)((float)p11 - (float)p22);
+    base[i2] = (T)((float)p21 + (float)p12);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void embedding_kernel(T* out, const int64_t* ids, const T* table, int64_t tokens, int hidden) {
+  const int nvec = hidden / 8;
+  const int64_t total = tokens * nvec;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t t = idx / nvec;
+    const int c = (int)(idx - t * nvec);
+    *(u32x4_t*)(out + t * hidden + c * 8) = *(const u32x4_t*)(table + ids[t] * hidden + c * 8);
+  }
+}
+
+// first index of the row maximum (torch.argmax tie-break on CPU/GPU: lowest index)
+template <typename T>
+__global__ __launch_bounds__(256) void argmax_kernel(int64_t* out, const T* logits, int64_t vocab, int64_t stride) {
+  __shared__ float rv[4];
+  __shared__ int64_t ri[4];
+  const T* row = logits + (int64_t)blockIdx.x * stride;
+  float best = -INFINITY;
+  int64_t bi = 0x7fffffffffffffffLL;
+  for (int64_t i = threadIdx.x; i < vocab; i += 256) {
+    const float v = (float)row[i];
+    if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    const float ov = __shfl_xor(best, m, WAVE);
+    const int64_t oi = __shfl_xor(bi, m, WAVE);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  if ((threadIdx.x & 63) == 0) { rv[threadIdx.x >> 6] = best; ri[threadIdx.x >> 6] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (rv[w] > best || (rv[w] == best && ri[w] < bi)) { best = rv[w]; bi = ri[w]; }
+    out[blockIdx.x] = bi;
+  }
+}
+
+inline unsigned grid_for(int64_t work_items) {
+  const int64_t b = (work_items + 255) / 256;
+  return (unsigned)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+#define DISPATCH_HALF(dtype, ...)                   \
+  if ((dtype) == SGL_BF16) {                        \
+    using T = __bf16;                               \
+    __VA_ARGS__                                     \
+  } else {                                          \
+    using T = _Float16;                             \
+    __VA_ARGS__                                     \
+  }
+
+}  // namespace
+
+// residual == NULL: out = rmsnorm(x) (out may alias x).  residual != NULL: residual += x (rounded to T),
+// out = rmsnorm(f32 sum) -- pass out == x for the reference's in-place fused_add_rmsnorm.
+extern "C" int sgl_mi355_rmsnorm(void* out, const void* x, void* residual, const void* weight, float eps, int64_t tokens,
+                                 int hidden, int64_t x_stride, int64_t out_stride, int dtype, void* stream) {
+  SGL_CHECK(tokens >= 0 && hidden > 0, "rmsnorm: bad shape");
+  if (tokens == 0) return SGL_MI355_OK;
+  SGL_CHECK(out && x && weight, "rmsnorm: null pointer");
+  SGL_CHECK(hidden % 8 == 0 && hidden <= 16384, "rmsnorm: hidden=%d must be a multiple of 8 and <= 16384", hidden);
+  SGL_CHECK(x_stride % 8 == 0 && out_stride % 8 == 0, "rmsnorm: row strides must be multiples of 8 elements");
+  SGL_CHECK(dtype == SGL_BF16 || dtype == SGL_F16, "rmsnorm: dtype must be bf16 or f16");
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_HALF(dtype, {
+    if (hidden <= 8192)
+      hipLaunchKernelGGL((rmsnorm_kernel<T, 4>), dim3((unsigned)tokens), dim3(256), 0, st, (T*)out, (const T*)x, (T*)residual,
+                         (const T*)weight, eps, hidden, x_stride, out_stride);
+    else
+      hipLaunchKernelGGL((rmsnorm_kernel<T, 8>), dim3((unsigned)tokens), dim3(256), 0, st, (T*)out, (const T*)x, (T*)residual,
+                         (const T*)weight, eps, hidden, x_stride, out_stride);
+  })
+  SGL_HIP_LAUNCH_CHECK();
+  return SGL_MI355_OK;
+}
+
+extern "C" int sgl_mi355_silu_and_mul(void* out, const void* x, int64_t tokens, int d, int dtype, void* stream) {
+  SGL_CHECK(tokens >= 0 && d > 0 && d % 8 == 0, "silu_and_mul: d=%d must be a positive multiple of 8", d);
+  if (tokens == 0) return SGL_MI355_OK;
+  SGL_CHECK(out && x, "silu_and_mul: null pointer");
+  SGL_CHECK(dtype == SGL_BF16 || dtype == SGL_F16, "silu_and_mul: dtype must be bf16 or f16");
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_HALF(dtype, {
+    hipLaunchKernelGGL((silu_and_mul_kernel<T>), dim3(grid_for(tokens * (d / 8))), dim3(256), 0, st, (T*)out, (const T*)x, tokens, d);
+  })
+  SGL_HIP_LAUNCH_CHECK();
+  return SGL_MI355_OK;
+}
+
+extern "C" int sgl_mi355_rotary_embedding(const int64_t* positions, void* query, void* key, const float* cos_sin_cache,
+                                          int64_t tokens, int num_q_heads, int num_k_heads, int head_size, int rot_dim,
+                                          int64_t q_stride, int64_t k_stride, int is_neox, int dtype, void* stream) {
+  SGL_CHECK(tokens >= 0, "rotary_embedding: negative token count");
+  if (tokens == 0) return SGL_MI355_OK;
+  SGL_CHECK(positions && query && key && cos_sin_cache, "rotary_embedding: null pointer");
+  SGL_CHECK(rot_dim > 0 && rot_dim % 2 == 0 && rot_dim <= head_size, "rotary_embedding: rot_dim=%d invalid for head_size=%d", rot_dim, head_size);
+  SGL_CHECK(dtype == SGL_BF16 || dtype == SGL_F16, "rotary_embedding: dtype must be bf16 or f16");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t work = tokens * (num_q_heads + num_k_heads) * (rot_dim / 2);
+  DISPATCH_HALF(dtype, {
+    hipLaunchKernelGGL((rope_kernel<T>), dim3(grid_for(work)), dim3(256), 0, st, (T*)query, (T*)key, positions, cos_sin_cache,
+                       tokens, num_q_heads, num_k_heads, head_size, rot_dim, q_stride, k_stride, is_neox);
+  })
+  SGL_HIP_LAUNCH_CHECK();
+  return SGL_MI355_OK;
+}
+
+extern "C" int sgl_mi355_embedding(void* out, const int64_t* ids, const void* table, int64_t tokens, int hidden, int dtype,
+                                   void* stream) {
+  SGL_CHECK(tokens >= 0 && hidden > 0 && hidden % 8 == 0, "embedding: hidden=%d must be a positive multiple of 8", hidden);
+  if (tokens == 0) return SGL_MI355_OK;
+  SGL_CHECK(out && ids && table, "embedding: null pointer");
+  SGL_CHECK(dtype == SGL_BF16 || dtype == SGL_F16, "embedding: dtype must be bf16 or f16");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL((embedding_kernel<__bf16>), dim3(grid_for(tokens * (hidden / 8))), dim3(256), 0, st, (__bf16*)out, ids,
+                     (const __bf16*)table, tokens, hidden);  // pure 16-bit copy: one instantiation serves both dtypes
+  SGL_HIP_LAUNCH_CHECK();
+  return SGL_MI355_OK;
+}
+
+extern "C" int sgl_mi355_argmax(int64_t* out, const void* logits, int64_t rows, int64_t vocab, int64_t row_stride, int dtype,
+                                void* stream) {
+  SGL_CHECK(rows >= 0 && vocab > 0, "argmax: bad shape");
+  if (rows == 0) return SGL_MI355_OK;
+  SGL_CHECK(out && logits, "argmax: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SGL_F32) {
+    hipLaunchKernelGGL((argmax_kernel<float>), dim3((unsigned)rows), dim3(256), 0, st, out, (const float*)logits, vocab, row_stride);
+  } else {
+    SGL_CHECK(dtype == SGL_BF16 || dtype == SGL_F16, "argmax: dtype must be f32, bf16 or f16");
+    DISPATCH_HALF(dtype, {
+      hipLaunchKernelGGL((argmax_kernel<T>), dim3((unsigned)rows), dim3(256), 0, st, out, (const T*)logits, vocab, row_stride);
+    })
+  }
+  SGL_HIP_LAUNCH_CHECK();
+  return SGL_MI355_OK;
+}

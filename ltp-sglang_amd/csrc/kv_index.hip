@@ -1,0 +1,276 @@
+// Integer / byte kernels around the paged token_to_kv_pool.  Every result here is BIT-EXACT with
+// the reference (these are index tensors and raw row copies):
+//   create_kv_indices   python/sglang/srt/layers/attention/utils.py:10-45 (create_flashinfer_kv_indices_triton)
+//   compute_position    python/sglang/srt/model_executor/forward_batch_info.py:885-955
+//   write_req_to_token  python/sglang/srt/managers/schedule_batch.py:1920-1955 (write_req_to_token_pool_triton)
+//   get_last_loc        python/sglang/srt/managers/schedule_batch.py:1958-2028
+//   set_kv_buffer       python/sglang/srt/mem_cache/memory_pool.py:369-407 (two index_put launches -> one kernel)
+//   num_kv_splits       python/sglang/srt/layers/attention/triton_backend.py:876-924 (get_num_kv_splits_triton)
+//   kv_indptr           triton_backend.py:172 (cumsum of seq_lens into kv_indptr[1:bs+1])
+// The reference walks the batch serially inside each program to get its output offset
+// ("NOTE: This can be slow for large bs"); here the prefix offset is a workgroup reduction.
+// Index tensors arrive as int32 or int64 exactly as the reference's callers hold them
+// (SURVEY.md 8a "Index dtypes"); a width flag per array selects the load.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ int64_t ld_idx(const void* p, int64_t i, int is64) {
+  return is64 ? ((const int64_t*)p)[i] : (int64_t)((const int32_t*)p)[i];
+}
+
+// sum_{i < pid} lens[i], computed by the whole workgroup
+__device__ __forceinline__ int64_t prefix_before(const void* lens, int is64, int pid, int64_t* red) {
+  int64_t s = 0;
+  for (int i = threadIdx.x; i < pid; i += blockDim.x) s += ld_idx(lens, i, is64);
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, WAVE);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  int64_t t = 0;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+  return t;
+}
+
+__global__ __launch_bounds__(256) void create_kv_indices_kernel(const int32_t* req_to_token, int64_t stride,
+                                                                const void* req_pool_indices, int rpi64,
+                                                                const void* page_kernel_lens, int pkl64,
+                                                                const int32_t* kv_indptr, const void* kv_start_idx,
+                                                                int ksi64, int32_t* kv_indices) {
+  const int pid = blockIdx.x;
+  const int64_t req = ld_idx(req_pool_indices, pid, rpi64);
+  const int64_t out0 = kv_indptr[pid];
+  const int32_t kv_start = kv_start_idx ? (int32_t)ld_idx(kv_start_idx, pid, ksi64) : 0;
+  const int32_t n = (int32_t)ld_idx(page_kernel_lens, pid, pkl64);
+  const int32_t* src = req_to_token + req * stride + kv_start;
+  for (int i = threadIdx.x; i < n; i += 256) kv_indices[out0 + i] = src[i];
+}
+
+__global__ __launch_bounds__(256) void compute_position_kernel(int64_t* positions, int32_t* extend_start_loc,
+                                                               const void* prefix_lens, int pl64,
+                                                               const void* seq_lens, int sl64) {
+  __shared__ int64_t red[4];
+  const int pid = blockIdx.x;
+  const int64_t pre = prefix_lens ? ld_idx(prefix_lens, pid, pl64) : 0;
+  const int64_t n = ld_idx(seq_lens, pid, sl64);
+  const int64_t start = prefix_before(seq_lens, sl64, pid, red);
+  for (int64_t i = threadIdx.x; i < n; i += 256) positions[start + i] = pre + i;
+  if (threadIdx.x == 0) extend_start_loc[pid] = (int32_t)start;
+}
+
+__global__ __launch_bounds__(256) void write_req_to_token_kernel(int32_t* req_to_token, int64_t stride,
+                                                                 const void* req_pool_indices, int rpi64,
+                                                                 const void* pre_lens, int pl64, const void* seq_lens,
+                                                                 int sl64, const void* extend_lens, int el64,
+                                                                 const int64_t* out_cache_loc) {
+  __shared__ int64_t red[4];
+  const int pid = blockIdx.x;
+  const int64_t req = ld_idx(req_pool_indices, pid, rpi64);
+  const int64_t pre = ld_idx(pre_lens, pid, pl64);
+  const int64_t n = ld_idx(seq_lens, pid, sl64) - pre;
+  const int64_t start = prefix_before(extend_lens, el64, pid, red);
+  int32_t* dst = req_to_token + req * stride + pre;
+  for (int64_t i = threadIdx.x; i < n; i += 256) dst[i] = (int32_t)out_cache_loc[start + i];
+}
+
+__global__ __launch_bounds__(256) void get_last_loc_kernel(const int32_t* req_to_token, int64_t stride,
+                                                           const void* req_pool_indices, int rpi64,
+                                                           const void* prefix_lens, int pl64, void* result, int res64,
+                                                           int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int64_t pre = ld_idx(prefix_lens, i, pl64);
+  const int64_t v = pre > 0 ? (int64_t)req_to_token[ld_idx(req_pool_indices, i, rpi64) * stride + pre - 1] : -1;
+  if (res64)
+    ((int64_t*)result)[i] = v;
+  else
+    ((int32_t*)result)[i] = (int32_t)v;
+}
+
+// One wave per token: copies the token's K row and V row (row_bytes each) into the pool slot loc[t].
+__global__ __launch_bounds__(256) void set_kv_buffer_kernel(char* k_buf, char* v_buf, int64_t k_slot_bytes,
+                                                            int64_t v_slot_bytes, const int64_t* loc, const char* cache_k,
+                                                            const char* cache_v, int64_t ck_stride_bytes,
+                                                            int64_t cv_stride_bytes, int k_row_bytes, int v_row_bytes,
+                                                            int64_t tokens) {
+  const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= tokens) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t slot = loc[t];
+  const char* ks = cache_k + t * ck_stride_bytes;
+  const char* vs = cache_v + t * cv_stride_bytes;
+  char* kd = k_buf + slot * k_slot_bytes;
+  char* vd = v_buf + slot * v_slot_bytes;
+  for (int o = lane * 16; o < k_row_bytes; o += 64 * 16) *(u32x4_t*)(kd + o) = *(const u32x4_t*)(ks + o);
+  for (int o = lane * 16; o < v_row_bytes; o += 64 * 16) *(u32x4_t*)(vd + o) = *(const u32x4_t*)(vs + o);
+}
+
+// Single workgroup: kv_indptr[1..bs] = inclusive cumsum(seq_lens) (int32, as torch.cumsum into the
+// int32 buffer does), and the reference's per-request split heuristic.
+__global__ __launch_bounds__(1024) void decode_meta_kernel(int32_t* kv_indptr, int32_t* num_kv_splits, const void* seq_lens,
+                                                           int sl64, int num_seq, int num_group, int num_head,
+                                                           int num_kv_head, int max_kv_splits, int device_core_count,
+                                                           int static_splits) {
+  __shared__ int64_t scan[1024];
+  __shared__ int32_t smax[16], smin[16];
+  const int tid = threadIdx.x;
+  // ---- cumsum (chunked Hillis-Steele over 1024 lanes) ----
+  if (kv_indptr) {
+    int64_t carry = 0;
+    if (tid == 0) kv_indptr[0] = 0;
+    for (int base = 0; base < num_seq; base += 1024) {
+      const int i = base + tid;
+      int64_t v = i < num_seq ? ld_idx(seq_lens, i, sl64) : 0;
+      scan[tid] = v;
+      __syncthreads();
+      for (int off = 1; off < 1024; off <<= 1) {
+        const int64_t add = tid >= off ? scan[tid - off] : 0;
+        __syncthreads();
+        scan[tid] += add;
+        __syncthreads();
+      }
+      if (i < num_seq) kv_indptr[i + 1] = (int32_t)(carry + scan[tid]);
+      carry += scan[1023];
+      __syncthreads();
+    }
+  }
+  if (!num_kv_splits) return;
+  if (static_splits || device_core_count <= 0) {
+    for (int i = tid; i < num_seq * num_group; i += 1024) num_kv_splits[i] = max_kv_splits;
+    return;
+  }
+  // ---- max / min of seq_lens ----
+  int32_t mx = 0;
+  for (int i = tid; i < num_seq; i += 1024) mx = max(mx, (int32_t)ld_idx(seq_lens, i, sl64));
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) mx = max(mx, __shfl_xor(mx, m, WAVE));
+  if ((tid & 63) == 0) smax[tid >> 6] = mx;
+  __syncthreads();
+  mx = 0;
+  for (int w = 0; w < 16; ++w) mx = max(mx, smax[w]);
+  int32_t mn = mx;
+  for (int i = tid; i < num_seq; i += 1024) mn = min(mn, (int32_t)ld_idx(seq_lens, i, sl64));
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) mn = min(mn, __shfl_xor(mn, m, WAVE));
+  if ((tid & 63) == 0) smin[tid >> 6] = mn;
+  __syncthreads();
+  mn = mx;
+  for (int w = 0; w < 16; ++w) mn = min(mn, smin[w]);
+  if ((int64_t)mx * 8 < (int64_t)mn * 10) mn = mx;
+  auto cdiv = [](int a, int b) { return (a + b - 1) / b; };
+  if (mx <= 0 || mn <= 0) {  // degenerate batch (the reference would divide by zero)
+    for (int i = tid; i < num_seq * num_group; i += 1024) num_kv_splits[i] = 1;
+    return;
+  }
+  const int splits1 = min(cdiv(mx, mn), max_kv_splits);
+  const int chunk1 = cdiv(mx, splits1);
+  const float ext_seq = (float)mx / 64.0f;
+  const int ext_cores = (int)((float)device_core_count * fmaxf(log2f(ext_seq), 1.0f));
+  int block_h = 16;
+  const int kv_group = num_head / num_kv_head;
+  int token_grid;
+  if (kv_group == 1) {
+    token_grid = num_seq * num_group * num_head;
+  } else {
+    block_h = min(block_h, kv_group);
+    token_grid = num_seq * num_group * cdiv(num_head, block_h);
+  }
+  const int splits2 = max(1, min(cdiv(ext_cores, token_grid), max_kv_splits));
+  const int chunk2 = cdiv(mx, splits2);
+  for (int i = tid; i < num_seq; i += 1024) {
+    const int len = (int32_t)ld_idx(seq_lens, i, sl64);
+    const int ns = max(cdiv(len, chunk1), cdiv(len, chunk2));
+    for (int gI = 0; gI < num_group; ++gI) num_kv_splits[i * num_group + gI] = ns;
+  }
+}
+
+}  // namespace
+
+extern "C" int sgl_mi355_create_kv_indices(const int32_t* req_to_token, int64_t req_to_token_stride,
+                                           const void* req_pool_indices, int req_pool_indices_is64,
+                                           const void* page_kernel_lens, int page_kernel_lens_is64,
+                                           const int32_t* kv_indptr, const void* kv_start_idx, int kv_start_idx_is64,
+                                           int32_t* kv_indices, int batch, void* stream) {
+  SGL_CHECK(batch >= 0, "create_kv_indices: negative batch");
+  if (batch == 0) return SGL_MI355_OK;
+  SGL_CHECK(req_to_token && req_pool_indices && page_kernel_lens && kv_indptr, "create_kv_indices: null pointer");
+  hipLaunchKernelGGL(create_kv_indices_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, req_to_token,
+                     req_to_token_stride, req_pool_indices, req_pool_indices_is64, page_kernel_lens, page_kernel_lens_is64,
+                     kv_indptr, kv_start_idx, kv_start_idx_is64, kv_indices);
+  SGL_HIP_LAUNCH_CHECK();
+  return SGL_MI355_OK;
+}
+
+extern "C" int sgl_mi355_compute_position(int64_t* positions, int32_t* extend_start_loc, const void* extend_prefix_lens,
+                                          int prefix_is64, const void* extend_seq_lens, int seq_is64, int batch,
+                                          void* stream) {
+  SGL_CHECK(batch >= 0, "compute_position: negative batch");
+  if (batch == 0) return SGL_MI355_OK;
+  SGL_CHECK(positions && extend_start_loc && extend_seq_lens, "compute_position: null pointer");
+  hipLaunchKernelGGL(compute_position_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, positions, extend_start_loc,
+                     extend_prefix_lens, prefix_is64, extend_seq_lens, seq_is64);
+  SGL_HIP_LAUNCH_CHECK();
+  return SGL_MI355_OK;
+}
+
+extern "C" int sgl_mi355_write_req_to_token(int32_t* req_to_token, int64_t req_to_token_stride,
+                                            const void* req_pool_indices, int req_pool_indices_is64, const void* pre_lens,
+                                            int pre_is64, const void* seq_lens, int seq_is64, const void* extend_lens,
+                                            int ext_is64, const int64_t* out_cache_loc, int batch, void* stream) {
+  SGL_CHECK(batch >= 0, "write_req_to_token: negative batch");
+  if (batch == 0) return SGL_MI355_OK;
+  SGL_CHECK(req_to_token && req_pool_indices && pre_lens && seq_lens && extend_lens && out_cache_loc,
+            "write_req_to_token: null pointer");
+  hipLaunchKernelGGL(write_req_to_token_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, req_to_token,
+                     req_to_token_stride, req_pool_indices, req_pool_indices_is64, pre_lens, pre_is64, seq_lens, seq_is64,
+                     extend_lens, ext_is64, out_cache_loc);
+  SGL_HIP_LAUNCH_CHECK();
+  return SGL_MI355_OK;
+}
+
+extern "C" int sgl_mi355_get_last_loc(const int32_t* req_to_token, int64_t req_to_token_stride,
+                                      const void* req_pool_indices, int req_pool_indices_is64, const void* prefix_lens,
+                                      int prefix_is64, void* result, int result_is64, int64_t n, void* stream) {
+  SGL_CHECK(n >= 0, "get_last_loc: negative size");
+  if (n == 0) return SGL_MI355_OK;
+  SGL_CHECK(req_to_token && req_pool_indices && prefix_lens && result, "get_last_loc: null pointer");
+  hipLaunchKernelGGL(get_last_loc_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, req_to_token,
+                     req_to_token_stride, req_pool_indices, req_pool_indices_is64, prefix_lens, prefix_is64, result,
+                     result_is64, n);
+  SGL_HIP_LAUNCH_CHECK();
+  return SGL_MI355_OK;
+}
+
+// k_buffer/v_buffer: pool bases for one layer; slot strides in bytes.  cache_k/cache_v: [tokens, row] with byte strides.
+extern "C" int sgl_mi355_set_kv_buffer(void* k_buffer, void* v_buffer, int64_t k_slot_bytes, int64_t v_slot_bytes,
+                                       const int64_t* loc, const void* cache_k, const void* cache_v,
+                                       int64_t cache_k_stride_bytes, int64_t cache_v_stride_bytes, int k_row_bytes,
+                                       int v_row_bytes, int64_t tokens, void* stream) {
+  SGL_CHECK(tokens >= 0, "set_kv_buffer: negative token count");
+  if (tokens == 0) return SGL_MI355_OK;
+  SGL_CHECK(k_buffer && v_buffer && loc && cache_k && cache_v, "set_kv_buffer: null pointer");
+  SGL_CHECK(k_row_bytes % 16 == 0 && v_row_bytes % 16 == 0 && k_slot_bytes % 16 == 0 && v_slot_bytes % 16 == 0 &&
+                cache_k_stride_bytes % 16 == 0 && cache_v_stride_bytes % 16 == 0 && ((uintptr_t)k_buffer % 16) == 0 &&
+                ((uintptr_t)v_buffer % 16) == 0 && ((uintptr_t)cache_k % 16) == 0 && ((uintptr_t)cache_v % 16) == 0,
+            "set_kv_buffer: rows must be 16-byte aligned (k_row_bytes=%d, v_row_bytes=%d)", k_row_bytes, v_row_bytes);
+  hipLaunchKernelGGL(set_kv_buffer_kernel, dim3((unsigned)((tokens + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     (char*)k_buffer, (char*)v_buffer, k_slot_bytes, v_slot_bytes, loc, (const char*)cache_k,
+                     (const char*)cache_v, cache_k_stride_bytes, cache_v_stride_bytes, k_row_bytes, v_row_bytes, tokens);
+  SGL_HIP_LAUNCH_CHECK();
+  return SGL_MI355_OK;
+}
+
+// kv_indptr and/or num_kv_splits may be NULL to skip that part.
+extern "C" int sgl_mi355_decode_metadata(int32_t* kv_indptr, int32_t* num_kv_splits, const void* seq_lens, int seq_is64,
+                                         int num_seq, int num_group, int num_head, int num_kv_head, int max_kv_splits,
+                                         int device_core_count, int static_splits, void* stream) {
+  SGL_CHECK(num_seq >= 0, "decode_metadata: negative batch");
+  if (num_seq == 0) return SGL_MI355_OK;
+  SGL_CHECK(seq_lens, "decode_metadata: null seq_lens");
+  SGL_CHECK(num_group >= 1 && num_kv_head >= 1 && num_head >= num_kv_head && max_kv_splits >= 1, "decode_metadata: bad head/split arguments");
+  hipLaunchKernelGGL(decode_meta_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, kv_indptr, num_kv_splits, seq_lens,
+                     seq_is64, num_seq, num_group, num_head, num_kv_head, max_kv_splits, device_core_count, static_splits);
+  SGL_HIP_LAUNCH_CHECK();
+  return SGL_MI355_OK;
+}

@@ -1,0 +1,129 @@
+"""GEMM / quantisation ops with the reference's ``sgl_kernel`` signatures
+(sgl-kernel/python/sgl_kernel/gemm.py:7-10,34-42,100-146)."""
+from typing import Optional
+
+import torch
+
+from .._cabi import check, current_stream, dtype_code, lib, ptr
+
+
+def _cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("sgl_kernel (MI355X) ops need device tensors; there is no CPU path")
+
+
+def fp8_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype, bias=None):
+    """out[M,N] = (mat_a[M,K] @ mat_b[K,N]) * scales_a[m] * scales_b[n] (+ bias[n]).
+
+    Argument checks and messages follow fp8_scaled_mm in
+    sgl-kernel/csrc/gemm/fp8_gemm_kernel.cu:1078-1108.
+    """
+    if not mat_a.is_cuda:
+        raise RuntimeError("mat_a must be a CUDA tensor")
+    if not mat_b.is_cuda:
+        raise RuntimeError("mat_b must be a CUDA tensor")
+    if mat_a.dim() != 2:
+        raise RuntimeError("mat_a must be a 2D tensor")
+    if mat_b.dim() != 2:
+        raise RuntimeError("mat_b must be a 2D tensor")
+    if mat_a.stride(1) != 1:
+        raise RuntimeError("mat_a must be a row major tensor")
+    if mat_b.stride(0) != 1:
+        raise RuntimeError("mat_a must be a column major tensor")  # (sic) reference wording
+    if mat_a.size(1) != mat_b.size(0):
+        raise RuntimeError("mat_a and mat_b shapes cannot be multiplied")
+    if (mat_a.size(1) * mat_a.element_size()) % 16 != 0:
+        raise RuntimeError("mat_a must be multiple of 16 bytes for memory alignment")
+    if (mat_b.size(0) * mat_b.element_size()) % 16 != 0:
+        raise RuntimeError("mat_b must be multiple of 16 bytes for memory alignment")
+    if mat_a.dtype != torch.float8_e4m3fn:
+        raise RuntimeError("mat_a must be Float8_e4m3fn")
+    if mat_b.dtype != torch.float8_e4m3fn:
+        raise RuntimeError("mat_b must be Float8_e4m3fn")
+    if out_dtype not in (torch.float16, torch.bfloat16):
+        raise RuntimeError("out_dtype must be Half or BFloat16")
+    if scales_a.numel() != mat_a.size(0):
+        raise RuntimeError("size of scales_a is not matched")
+    if scales_b.numel() != mat_b.size(1):
+        raise RuntimeError("size of scales_b is not matched")
+    if not scales_a.is_contiguous():
+        raise RuntimeError("scales_a must be contiguous")
+    if not scales_b.is_contiguous():
+        raise RuntimeError("scales_b msut be contiguous")
+    if scales_a.dtype != torch.float32:
+        raise RuntimeError("scales_a must be Float32")
+    if scales_b.dtype != torch.float32:
+        raise RuntimeError("scales_b must be Float32")
+    if bias is not None:
+        if bias.numel() != mat_b.size(1):
+            raise RuntimeError("size of bias is not matched")
+        if not bias.is_contiguous():
+            raise RuntimeError("bias must be contiguous")
+        if bias.dtype != out_dtype:
+            raise RuntimeError("bias dtype must match output dtype")
+    m, k = mat_a.shape
+    n = mat_b.size(1)
+    out = torch.empty((m, n), dtype=out_dtype, device=mat_a.device)
+    if (out.size(1) * out.element_size()) % 16 != 0:
+        raise RuntimeError("out must be multiple of 16 bytes for memory alignment")
+    w_stride = mat_b.stride(1)  # W[n, :] = mat_b[:, n]
+    if m <= 64:
+        check(lib.sgl_mi355_skinny_gemm(ptr(mat_a), mat_a.stride(0), ptr(mat_b), w_stride, ptr(out), out.stride(0),
+                                        ptr(scales_a), ptr(scales_b), ptr(bias), m, n, k, dtype_code(mat_a.dtype),
+                                        dtype_code(out_dtype), current_stream()))
+    else:
+        check(lib.sgl_mi355_fp8_gemm(ptr(mat_a), mat_a.stride(0), ptr(mat_b), w_stride, ptr(out), out.stride(0),
+                                     ptr(scales_a), ptr(scales_b), ptr(bias), m, n, k, dtype_code(out_dtype),
+                                     current_stream()))
+    return out
+
+
+def dense_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, out_dtype=None) -> torch.Tensor:
+    """Unquantised F.linear(x, weight, bias) for bf16/f16 (UnquantizedLinearMethod.apply,
+    python/sglang/srt/layers/quantization/unquant.py); weight [N, K] row-major."""
+    _cuda(x, weight, bias)
+    assert x.dim() == 2 and weight.dim() == 2 and x.stride(1) == 1 and weight.stride(1) == 1
+    m, k = x.shape
+    n = weight.shape[0]
+    out_dtype = out_dtype or x.dtype
+    out = torch.empty((m, n), dtype=out_dtype, device=x.device)
+    if m <= 64:
+        check(lib.sgl_mi355_skinny_gemm(ptr(x), x.stride(0), ptr(weight), weight.stride(0), ptr(out), out.stride(0), None,
+                                        None, ptr(bias), m, n, k, dtype_code(x.dtype), dtype_code(out_dtype),
+                                        current_stream()))
+    else:
+        check(lib.sgl_mi355_dense_gemm(ptr(x), x.stride(0), ptr(weight), weight.stride(0), ptr(out), out.stride(0),
+                                       ptr(bias), m, n, k, dtype_code(x.dtype), dtype_code(out_dtype), current_stream()))
+    return out
+
+
+def sgl_per_token_quant_fp8(input: torch.Tensor, output_q: torch.Tensor, output_s: torch.Tensor) -> None:
+    """gemm.py:140-145; in-place outputs: output_q e4m3fn [M,K], output_s f32 [M] or [M,1]."""
+    _cuda(input, output_q, output_s)
+    assert input.dim() == 2 and input.stride(1) == 1 and output_q.is_contiguous() and output_s.is_contiguous()
+    assert output_q.dtype == torch.float8_e4m3fn and output_s.dtype == torch.float32
+    check(lib.sgl_mi355_per_token_quant_fp8(ptr(input), input.stride(0), ptr(output_q), ptr(output_s), input.shape[0],
+                                            input.shape[1], dtype_code(input.dtype), current_stream()))
+
+
+def sgl_per_tensor_quant_fp8(input: torch.Tensor, output_q: torch.Tensor, output_s: torch.Tensor, is_static: bool) -> None:
+    """gemm.py:129-137; dynamic mode expects output_s zero-initialised (fp8_kernel.py scaled_fp8_quant does torch.zeros)."""
+    _cuda(input, output_q, output_s)
+    assert input.is_contiguous() and output_q.is_contiguous()
+    assert output_q.dtype == torch.float8_e4m3fn and output_s.dtype == torch.float32
+    check(lib.sgl_mi355_per_tensor_quant_fp8(ptr(input), ptr(output_q), ptr(output_s), input.numel(), int(bool(is_static)),
+                                             dtype_code(input.dtype), current_stream()))
+
+
+def sgl_per_token_group_quant_fp8(input, output_q, output_s, group_size, eps, fp8_min, fp8_max, scale_ue8m0=False) -> None:
+    """gemm.py:100-112 (row-major float scales only)."""
+    _cuda(input, output_q, output_s)
+    if scale_ue8m0:
+        raise RuntimeError("scale_ue8m0 (DeepSeek block-fp8 layout) is out of scope of this build")
+    assert input.is_contiguous() and output_q.is_contiguous() and output_s.is_contiguous()
+    if input.numel() % group_size != 0:
+        raise RuntimeError("input.numel() must be divisible by group_size")
+    check(lib.sgl_mi355_per_token_group_quant_fp8(ptr(input), ptr(output_q), ptr(output_s), input.numel(), int(group_size),
+                                                  float(eps), float(fp8_min), float(fp8_max), dtype_code(input.dtype),
+                                                  current_stream()))

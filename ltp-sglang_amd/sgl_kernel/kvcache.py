@@ -1,0 +1,68 @@
+"""KV-pool / index ops (bit-exact integer work) -- host-callable forms of the Triton helpers the
+reference launches from forward_batch_info.py, schedule_batch.py, attention/utils.py and
+memory_pool.py (citations in include/sgl_mi355.h)."""
+from typing import Optional
+
+import torch
+
+from .._cabi import check, current_stream, is64, lib, ptr
+
+
+def create_kv_indices(req_to_token, req_pool_indices, page_kernel_lens, kv_indptr, kv_start_idx, kv_indices) -> None:
+    """kv_indices[kv_indptr[i]:kv_indptr[i]+len_i] = req_to_token[req_pool_indices[i], start_i:start_i+len_i]."""
+    assert req_to_token.dtype == torch.int32 and kv_indptr.dtype == torch.int32 and kv_indices.dtype == torch.int32
+    check(lib.sgl_mi355_create_kv_indices(ptr(req_to_token), req_to_token.stride(0), ptr(req_pool_indices),
+                                          is64(req_pool_indices), ptr(page_kernel_lens), is64(page_kernel_lens),
+                                          ptr(kv_indptr), ptr(kv_start_idx), is64(kv_start_idx), ptr(kv_indices),
+                                          req_pool_indices.numel(), current_stream()))
+
+
+def compute_position(extend_prefix_lens: Optional[torch.Tensor], extend_seq_lens: torch.Tensor, extend_seq_lens_sum: int):
+    """-> (positions int64 [sum], extend_start_loc int32 [bs]); forward_batch_info.py:885-955."""
+    bs = extend_seq_lens.shape[0]
+    dev = extend_seq_lens.device
+    positions = torch.empty(extend_seq_lens_sum, dtype=torch.int64, device=dev)
+    extend_start_loc = torch.empty(bs, dtype=torch.int32, device=dev)
+    has_prefix = extend_prefix_lens is not None and extend_prefix_lens.shape[0] == bs
+    pl = extend_prefix_lens if has_prefix else None
+    check(lib.sgl_mi355_compute_position(ptr(positions), ptr(extend_start_loc), ptr(pl), is64(pl), ptr(extend_seq_lens),
+                                         is64(extend_seq_lens), bs, current_stream()))
+    return positions, extend_start_loc
+
+
+def write_req_to_token(req_to_token, req_pool_indices, pre_lens, seq_lens, extend_lens, out_cache_loc) -> None:
+    """req_to_token[req_pool_indices[i], pre_i:seq_i] = out_cache_loc[cumsum(ext)[:i] ...]; schedule_batch.py:1920-1955."""
+    assert req_to_token.dtype == torch.int32 and out_cache_loc.dtype == torch.int64
+    check(lib.sgl_mi355_write_req_to_token(ptr(req_to_token), req_to_token.stride(0), ptr(req_pool_indices),
+                                           is64(req_pool_indices), ptr(pre_lens), is64(pre_lens), ptr(seq_lens),
+                                           is64(seq_lens), ptr(extend_lens), is64(extend_lens), ptr(out_cache_loc),
+                                           req_pool_indices.numel(), current_stream()))
+
+
+def get_last_loc(req_to_token, req_pool_indices, prefix_lens) -> torch.Tensor:
+    result = torch.empty_like(prefix_lens)
+    check(lib.sgl_mi355_get_last_loc(ptr(req_to_token), req_to_token.stride(0), ptr(req_pool_indices),
+                                     is64(req_pool_indices), ptr(prefix_lens), is64(prefix_lens), ptr(result), is64(result),
+                                     prefix_lens.numel(), current_stream()))
+    return result
+
+
+def set_kv_buffer(k_buffer, v_buffer, loc, cache_k, cache_v) -> None:
+    """k_buffer[loc] = cache_k ; v_buffer[loc] = cache_v for one layer's [slots, Hkv, D] pools."""
+    assert loc.dtype == torch.int64 and k_buffer.dtype == cache_k.dtype and v_buffer.dtype == cache_v.dtype
+    t = loc.numel()
+    ck, cv = cache_k.reshape(t, -1), cache_v.reshape(t, -1)
+    assert ck.stride(1) == 1 and cv.stride(1) == 1 and k_buffer[0].is_contiguous() and v_buffer[0].is_contiguous()
+    es = k_buffer.element_size()
+    check(lib.sgl_mi355_set_kv_buffer(ptr(k_buffer), ptr(v_buffer), k_buffer.stride(0) * es, v_buffer.stride(0) * es,
+                                      ptr(loc), ptr(ck), ptr(cv), ck.stride(0) * es, cv.stride(0) * es, ck.shape[1] * es,
+                                      cv.shape[1] * es, t, current_stream()))
+
+
+def decode_metadata(kv_indptr, num_kv_splits, seq_lens, num_group, num_head, num_kv_head, max_kv_splits,
+                    device_core_count, static_splits=False) -> None:
+    """kv_indptr[1:bs+1] = cumsum(seq_lens) and the reference's num_kv_splits heuristic, one launch."""
+    check(lib.sgl_mi355_decode_metadata(ptr(kv_indptr), ptr(num_kv_splits), ptr(seq_lens), is64(seq_lens),
+                                        seq_lens.numel(), int(num_group), int(num_head), int(num_kv_head),
+                                        int(max_kv_splits), int(device_core_count), int(bool(static_splits)),
+                                        current_stream()))

@@ -1,0 +1,69 @@
+"""fp8 / AWQ oracle: CPU restatements of the reference's own torch reference formulas.
+
+  per_token_quant_fp8   scale = absmax/448 as computed by sgl-kernel/csrc/gemm/per_token_quant_fp8.cu:49-57;
+                        q as torch_per_token_quant_fp8, sgl-kernel/tests/test_per_token_quant_fp8.py:14-23
+  per_tensor_quant_fp8  sgl-kernel/csrc/gemm/per_tensor_quant_fp8.cu:10-52 + torch_scaled_fp8_quant,
+                        sgl-kernel/tests/test_per_tensor_quant_fp8.py:30-37
+  per_token_group_quant sgl-kernel/csrc/gemm/per_token_group_quant_8bit.cu (y_s = max(absmax, eps)/max; q = clamp(x / y_s))
+  scaled_mm             torch_scaled_mm, sgl-kernel/tests/test_fp8_gemm.py:6-14
+  awq_dequantize        awq_dequantize_torch + reverse_awq_order, sgl-kernel/tests/test_awq_dequant.py:9-58
+
+TEST INFRASTRUCTURE: see oracle/__init__.py.
+"""
+import torch
+
+FP8_MAX = 448.0
+AWQ_ORDER = [0, 4, 1, 5, 2, 6, 3, 7]
+
+
+def _to_fp8(x32):
+    return x32.clamp(min=-FP8_MAX, max=FP8_MAX).to(torch.float8_e4m3fn)
+
+
+def per_token_quant_fp8(x):
+    """x [M,K] bf16/f16 -> (q e4m3fn [M,K], scale f32 [M,1])."""
+    xf = x.to(torch.float32)
+    scale = xf.abs().amax(dim=1, keepdim=True) / FP8_MAX
+    inv = torch.where(scale == 0, torch.zeros_like(scale), scale.reciprocal())
+    return _to_fp8(xf * inv), scale
+
+
+def per_tensor_quant_fp8(x, scale=None):
+    """Dynamic (scale=None) or static per-tensor quantisation -> (q, scale f32 [1])."""
+    xf = x.to(torch.float32)
+    if scale is None:
+        scale = (xf.abs().amax() / FP8_MAX).reshape(1)
+    return _to_fp8(xf * scale.reciprocal()), scale
+
+
+def per_token_group_quant_fp8(x, group_size, eps=1e-10, fp8_min=-FP8_MAX, fp8_max=FP8_MAX):
+    xf = x.to(torch.float32).reshape(-1, group_size)
+    amax = xf.abs().amax(dim=1, keepdim=True).clamp(min=eps)
+    ys = amax / fp8_max
+    q = (xf / ys).clamp(min=fp8_min, max=fp8_max).to(torch.float8_e4m3fn)
+    return q.reshape(x.shape), ys.reshape(*x.shape[:-1], x.shape[-1] // group_size)
+
+
+def scaled_mm(a, b, scale_a, scale_b, out_dtype, bias=None):
+    """a [M,K] fp8, b [K,N] fp8 -> out_dtype [M,N]; same op order as the reference test."""
+    o = torch.matmul(a.to(torch.float32), b.to(torch.float32))
+    o = (o * scale_a.view(-1, 1)) * scale_b.view(1, -1)
+    o = o.to(out_dtype)
+    if bias is not None:
+        o = o + bias.view(1, -1)
+    return o
+
+
+def _awq_unpack(packed):
+    """int32 [R, C] -> int [R, 8C] in AWQ column order (nibble order[j] holds column 8c + j)."""
+    shifts = torch.tensor([4 * o for o in AWQ_ORDER], dtype=torch.int32)
+    return ((packed.unsqueeze(-1) >> shifts) & 0xF).reshape(packed.shape[0], -1)
+
+
+def awq_dequantize(qweight, scales, qzeros, group_size=None):
+    """qweight [K, N/8] i32, scales [K/G, N] f16/bf16, qzeros [K/G, N/8] i32 -> [K, N] in scales.dtype."""
+    k = qweight.shape[0]
+    g = group_size or k // scales.shape[0]
+    w = _awq_unpack(qweight).to(torch.int8)
+    z = _awq_unpack(qzeros).to(torch.int8).repeat_interleave(g, dim=0)
+    return (w - z) * scales.repeat_interleave(g, dim=0)

@@ -116,3 +116,134 @@ def bits16(t):
 
 def from_bits16(a, dtype):
     return torch.from_numpy(a.view(np.int16).copy()).view(dtype)
+
+
+# ----------------------------------------------------------------------------------------------
+# index cases (int tensors; tiny, stored whole in the fixtures by make_golden.py)
+# ----------------------------------------------------------------------------------------------
+INDEX_CASES = [
+    dict(name="idx_small", bs=5, max_ctx=64, pre=[0, 3, 10, 0, 31], ext=[7, 1, 20, 33, 1]),
+    dict(name="idx_one", bs=1, max_ctx=16, pre=[0], ext=[5]),
+    dict(name="idx_ragged", bs=9, max_ctx=700, pre=[0, 512, 1, 77, 600, 0, 0, 13, 255], ext=[600, 1, 1, 513, 64, 2, 129, 300, 257]),
+]
+
+
+def build_index_case(case, seed=0):
+    rng = np.random.RandomState(seed + 100)
+    bs, max_ctx = case["bs"], case["max_ctx"]
+    pre, ext = np.array(case["pre"], dtype=np.int64), np.array(case["ext"], dtype=np.int64)
+    seq = pre + ext
+    max_reqs = bs + 4
+    req_pool_indices = rng.permutation(max_reqs)[:bs].astype(np.int64)
+    pool = int(seq.sum()) + 11
+    perm = (1 + rng.permutation(pool)).astype(np.int64)
+    req_to_token = np.zeros((max_reqs, max_ctx), dtype=np.int32)
+    cur = 0
+    for i in range(bs):  # prefix part already present in the table
+        req_to_token[req_pool_indices[i], : pre[i]] = perm[cur : cur + pre[i]]
+        cur += pre[i]
+    out_cache_loc = perm[cur : cur + int(ext.sum())].copy()
+    return dict(bs=bs, pre=pre, ext=ext, seq=seq, req_pool_indices=req_pool_indices, req_to_token=req_to_token,
+                out_cache_loc=out_cache_loc)
+
+
+SPLIT_CASES = [
+    dict(name="spl_uniform", seq=[2048] * 32, num_head=32, num_kv_head=8, max_splits=16, cores=256),
+    dict(name="spl_ragged", seq=[5, 100, 4096, 300, 2048, 17], num_head=32, num_kv_head=8, max_splits=16, cores=256),
+    dict(name="spl_mha", seq=[128, 50, 1], num_head=12, num_kv_head=12, max_splits=8, cores=256),
+    dict(name="spl_tp8", seq=[600 + 37 * i for i in range(128)], num_head=8, num_kv_head=1, max_splits=16, cores=256),
+]
+
+# ----------------------------------------------------------------------------------------------
+# quant / GEMM / elementwise cases
+# ----------------------------------------------------------------------------------------------
+QUANT_CASES = [
+    dict(name="q_bf16_8x4096", m=8, k=4096, dtype="bf16"),
+    dict(name="q_f16_7x1368", m=7, k=1368, dtype="f16"),
+    dict(name="q_bf16_edge", m=6, k=512, dtype="bf16", edge=True),
+]
+
+
+def build_quant_case(case, seed=0):
+    rng = np.random.RandomState(seed + 200)
+    x = torch.from_numpy((rng.standard_normal((case["m"], case["k"])) * 3).astype(np.float32)).to(DTYPES[case["dtype"]])
+    if case.get("edge"):
+        x[0] = 0  # all-zero row: scale 0, scale_inv 0 (per_token_quant_fp8.cu:52-57)
+        x[1, :4] = torch.tensor([448.0, -448.0, 1000.0, -1e4]).to(x.dtype)  # saturation
+        x[2] = x[2] * 1e-6  # tiny values: fp8 subnormals after scaling
+        x[3, 5] = 6e4 if x.dtype == torch.float16 else 3e38
+    return x
+
+
+GEMM_CASES = [
+    # (M, N, K) from the reference's bench table (bench_fp8_gemm.py:19-52) sliced to stay small
+    dict(name="g_m1", m=1, n=128, k=512, bias=False, out="bf16"),
+    dict(name="g_m32_qkvslice", m=32, n=256, k=4096, bias=True, out="bf16"),
+    dict(name="g_m17_f16", m=17, n=48, k=1024, bias=True, out="f16"),
+    dict(name="g_m64_k14336", m=64, n=64, k=14336, bias=False, out="bf16"),
+    dict(name="g_m128", m=128, n=256, k=512, bias=True, out="bf16"),
+    dict(name="g_m300_ragged", m=300, n=144, k=1024, bias=False, out="f16"),
+]
+
+
+def build_gemm_case(case, seed=0):
+    rng = np.random.RandomState(seed + 300)
+    m, n, k = case["m"], case["n"], case["k"]
+    a = torch.from_numpy(((rng.random_sample((m, k)) - 0.5) * 2 * 448).astype(np.float32)).clamp(-448, 448).to(torch.float8_e4m3fn)
+    w = torch.from_numpy(((rng.random_sample((n, k)) - 0.5) * 2 * 448).astype(np.float32)).clamp(-448, 448).to(torch.float8_e4m3fn)
+    sa = torch.from_numpy((rng.standard_normal(m) * 0.001).astype(np.float32))
+    sb = torch.from_numpy((rng.standard_normal(n) * 0.001).astype(np.float32))
+    od = DTYPES[case["out"]]
+    bias = torch.from_numpy(rng.standard_normal(n).astype(np.float32)).to(od) if case["bias"] else None
+    return dict(a=a, w=w, sa=sa, sb=sb, bias=bias, out_dtype=od)
+
+
+AWQ_CASES = [
+    # small slices (fixtures must stay KB-scale); the Qwen2-7B shapes of test_awq_dequant.py:66-70 are
+    # checked on the GPU against the oracle directly
+    dict(name="awq_f16_g32", k=64, nc=72, g=32, dtype="f16"),
+    dict(name="awq_bf16_g32", k=64, nc=56, g=32, dtype="bf16"),
+    dict(name="awq_single_group", k=32, nc=16, g=32, dtype="f16"),
+    dict(name="awq_g128", k=256, nc=8, g=128, dtype="bf16"),
+]
+
+
+def build_awq_case(case, seed=0):
+    rng = np.random.RandomState(seed + 400)
+    k, nc, g = case["k"], case["nc"], case["g"]
+    qweight = torch.from_numpy(rng.randint(0, 2**31 - 1, size=(k, nc), dtype=np.int64).astype(np.int32))
+    qzeros = torch.from_numpy(rng.randint(0, 2**31 - 1, size=(k // g, nc), dtype=np.int64).astype(np.int32))
+    scales = torch.from_numpy(rng.random_sample((k // g, nc * 8)).astype(np.float32)).to(DTYPES[case["dtype"]])
+    return dict(qweight=qweight, qzeros=qzeros, scales=scales, g=g)
+
+
+NORM_CASES = [
+    dict(name="n_bf16_4096", t=5, h=4096, dtype="bf16"),
+    dict(name="n_f16_768", t=3, h=768, dtype="f16"),
+    dict(name="n_bf16_8192", t=2, h=8192, dtype="bf16"),
+]
+
+
+def build_norm_case(case, seed=0):
+    rng = np.random.RandomState(seed + 500)
+    dt = DTYPES[case["dtype"]]
+    x = _randn(rng, (case["t"], case["h"]), dt)
+    res = _randn(rng, (case["t"], case["h"]), dt)
+    w = torch.from_numpy((1 + 0.1 * rng.standard_normal(case["h"])).astype(np.float32)).to(dt)
+    return dict(x=x, res=res, w=w, eps=1e-5)
+
+
+ROPE_CASES = [
+    dict(name="r_llama_bf16", t=6, hq=32, hk=8, hs=128, rot=128, neox=True, dtype="bf16", base=500000),
+    dict(name="r_partial_f16", t=4, hq=4, hk=4, hs=64, rot=32, neox=True, dtype="f16", base=10000),
+    dict(name="r_gptj_bf16", t=3, hq=8, hk=2, hs=128, rot=128, neox=False, dtype="bf16", base=10000),
+]
+
+
+def build_rope_case(case, seed=0):
+    rng = np.random.RandomState(seed + 600)
+    dt = DTYPES[case["dtype"]]
+    q = _randn(rng, (case["t"], case["hq"] * case["hs"]), dt)
+    k = _randn(rng, (case["t"], case["hk"] * case["hs"]), dt)
+    positions = torch.from_numpy(rng.randint(0, 4096, size=case["t"]).astype(np.int64))
+    return dict(q=q, k=k, positions=positions)

@@ -10,6 +10,8 @@ so each fixture stores the expected outputs and the small integer tensors only.
 import os
 import sys
 
+os.environ.setdefault("TRITON_INTERPRET", "1")  # the reference's Triton index kernels run on the CPU interpreter
+
 import numpy as np
 import torch
 
@@ -75,12 +77,172 @@ def gen_attention():
     np.savez_compressed(os.path.join(HERE, "attention.npz"), **out)
 
 
+def _ref_functions(path, names, extra_globals=None):
+    """Executes selected top-level function definitions of a reference source file in a scratch
+    namespace (for modules whose import drags in absent third-party packages).  Nothing is copied:
+    the text is read from /root/reference at generation time only."""
+    import ast
+
+    src = open(path).read()
+    tree = ast.parse(src)
+    ns = dict(extra_globals or {})
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in names:
+            mod = ast.Module(body=[node], type_ignores=[])
+            exec(compile(mod, path, "exec"), ns)
+    return ns
+
+
+def gen_index():
+    """Needs TRITON_INTERPRET=1 (set by the __main__ block before triton is imported)."""
+    import triton
+    import triton.language as tl
+
+    from sglang.srt.layers.attention.triton_backend import get_num_kv_splits_triton
+    from sglang.srt.layers.attention.utils import create_flashinfer_kv_indices_triton
+    from sglang.srt.model_executor.forward_batch_info import compute_position_torch, compute_position_triton
+
+    sb = _ref_functions(
+        os.path.join(_ref_import.REF_ROOT, "python/sglang/srt/managers/schedule_batch.py"),
+        {"get_last_loc_torch", "write_req_to_token_pool_triton"},
+        {"torch": torch, "triton": triton, "tl": tl},
+    )
+    out = {}
+    for case in _cases.INDEX_CASES:
+        c = _cases.build_index_case(case)
+        bs = c["bs"]
+        r2t = torch.from_numpy(c["req_to_token"].copy())
+        rpi = torch.from_numpy(c["req_pool_indices"])
+        pre, seq, ext = (torch.from_numpy(c[k]) for k in ("pre", "seq", "ext"))
+        loc = torch.from_numpy(c["out_cache_loc"])
+        sb["write_req_to_token_pool_triton"][(bs,)](r2t, rpi, pre, seq, ext, loc, r2t.shape[1])
+        out[case["name"] + ".req_to_token"] = r2t.numpy().copy()
+        # decode-style kv indices over the full sequences, and extend-style over the prefixes
+        for tag, lens in (("seq", seq), ("pre", pre)):
+            kv_indptr = torch.zeros(bs + 1, dtype=torch.int32)
+            kv_indptr[1:] = torch.cumsum(lens, dim=0)
+            kv_indices = torch.zeros(int(lens.sum()), dtype=torch.int32)
+            create_flashinfer_kv_indices_triton[(bs,)](r2t, rpi, lens, kv_indptr, None, kv_indices, r2t.stride(0))
+            out[f"{case['name']}.kv_indptr_{tag}"] = kv_indptr.numpy().copy()
+            out[f"{case['name']}.kv_indices_{tag}"] = kv_indices.numpy().copy()
+        # sliding-window style start offsets
+        win = torch.minimum(seq, torch.tensor(9))
+        kv_indptr = torch.zeros(bs + 1, dtype=torch.int32)
+        kv_indptr[1:] = torch.cumsum(win, dim=0)
+        kv_indices = torch.zeros(int(win.sum()), dtype=torch.int32)
+        create_flashinfer_kv_indices_triton[(bs,)](r2t, rpi, win, kv_indptr, seq - win, kv_indices, r2t.stride(0))
+        out[case["name"] + ".kv_indices_win"] = kv_indices.numpy().copy()
+        pos_t, start_t = compute_position_torch(pre.int(), ext.int())
+        pos_k, start_k = compute_position_triton(pre.int(), ext.int(), int(ext.sum()))
+        assert torch.equal(pos_t, pos_k) and torch.equal(start_t.int(), start_k)
+        out[case["name"] + ".positions"] = pos_k.numpy().copy()
+        out[case["name"] + ".extend_start_loc"] = start_k.numpy().copy()
+        out[case["name"] + ".last_loc"] = sb["get_last_loc_torch"](r2t, rpi, pre).numpy().copy()
+    for case in _cases.SPLIT_CASES:
+        seq = torch.tensor(case["seq"], dtype=torch.int64)
+        n = len(case["seq"])
+        res = torch.zeros(n, dtype=torch.int32)
+        sched = 256 if n < 256 else triton.next_power_of_2(n)
+        get_num_kv_splits_triton[(1,)](res, seq, n, 1, case["num_head"], case["num_kv_head"], case["max_splits"],
+                                       case["cores"], MAX_NUM_SEQ=sched)
+        out[case["name"]] = res.numpy().copy()
+        print(case["name"], res[:8].tolist())
+    np.savez_compressed(os.path.join(HERE, "index.npz"), **out)
+
+
+def _load_ref_test_module(relpath, name):
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location(name, os.path.join(_ref_import.REF_ROOT, relpath))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def gen_quant():
+    t_tok = _load_ref_test_module("sgl-kernel/tests/test_per_token_quant_fp8.py", "ref_t_tok")
+    t_ten = _load_ref_test_module("sgl-kernel/tests/test_per_tensor_quant_fp8.py", "ref_t_ten")
+    t_mm = _load_ref_test_module("sgl-kernel/tests/test_fp8_gemm.py", "ref_t_mm")
+    t_awq = _load_ref_test_module("sgl-kernel/tests/test_awq_dequant.py", "ref_t_awq")
+    out = {}
+    for case in _cases.QUANT_CASES:
+        x = _cases.build_quant_case(case)
+        # the scale is what the kernel computes (per_token_quant_fp8.cu:49-57); q is the reference's restatement
+        scale = x.float().abs().amax(dim=1, keepdim=True) / 448.0
+        q = t_tok.torch_per_token_quant_fp8(x, scale) if not case.get("edge") else None
+        if q is None:
+            # the test restatement divides by zero for the all-zero row; the kernel defines scale_inv = 0 there
+            safe = torch.where(scale == 0, torch.ones_like(scale), scale)
+            q = t_tok.torch_per_token_quant_fp8(x, safe)
+        out[case["name"] + ".tok_q"] = q.view(torch.uint8).numpy()
+        out[case["name"] + ".tok_s"] = scale.numpy()
+        ts = (x.float().abs().amax() / 448.0).reshape(1)
+        out[case["name"] + ".ten_q"] = t_ten.torch_scaled_fp8_quant(x, ts).view(torch.uint8).numpy()
+        out[case["name"] + ".ten_s"] = ts.numpy()
+        static = torch.tensor([0.37], dtype=torch.float32)
+        out[case["name"] + ".ten_static_q"] = t_ten.torch_scaled_fp8_quant(x, static).view(torch.uint8).numpy()
+    for case in _cases.GEMM_CASES:
+        c = _cases.build_gemm_case(case)
+        o = t_mm.torch_scaled_mm(c["a"], c["w"].t(), c["sa"], c["sb"], c["out_dtype"], c["bias"])
+        out[case["name"] + ".mm"] = _cases.bits16(o)
+    for case in _cases.AWQ_CASES:
+        c = _cases.build_awq_case(case)
+        o = t_awq.awq_dequantize_torch(c["qweight"], c["scales"], c["qzeros"], c["g"])
+        out[case["name"] + ".deq"] = _cases.bits16(o)
+    np.savez_compressed(os.path.join(HERE, "quant.npz"), **out)
+    print("quant.npz", len(out), "arrays")
+
+
+def gen_elementwise():
+    from types import SimpleNamespace
+
+    from sglang.srt.layers.rotary_embedding import RotaryEmbedding
+
+    ln = _ref_functions  # layernorm.py imports vllm at module import on non-CUDA hosts; take the class method text
+    import ast
+
+    path = os.path.join(_ref_import.REF_ROOT, "python/sglang/srt/layers/layernorm.py")
+    tree = ast.parse(open(path).read())
+    fn = None
+    for node in tree.body:
+        if isinstance(node, ast.ClassDef) and node.name == "RMSNorm":
+            for item in node.body:
+                if isinstance(item, ast.FunctionDef) and item.name == "forward_native":
+                    fn = item
+    ns = {"torch": torch, "Optional": __import__("typing").Optional, "Union": __import__("typing").Union,
+          "Tuple": __import__("typing").Tuple}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), path, "exec"), ns)
+    rms_forward_native = ns["forward_native"]
+    out = {}
+    for case in _cases.NORM_CASES:
+        c = _cases.build_norm_case(case)
+        self = SimpleNamespace(weight=c["w"], variance_epsilon=c["eps"], hidden_size=case["h"], variance_size_override=None)
+        y = rms_forward_native(self, c["x"].clone())
+        y2, r2 = rms_forward_native(self, c["x"].clone(), c["res"].clone())
+        out[case["name"] + ".y"] = _cases.bits16(y)
+        out[case["name"] + ".y_res"] = _cases.bits16(y2)
+        out[case["name"] + ".res"] = _cases.bits16(r2)
+    for case in _cases.ROPE_CASES:
+        c = _cases.build_rope_case(case)
+        self = SimpleNamespace(head_size=case["hs"], rotary_dim=case["rot"], max_position_embeddings=4096,
+                               base=case["base"], is_neox_style=case["neox"])
+        self._compute_inv_freq = lambda base, s=self: RotaryEmbedding._compute_inv_freq(s, base)
+        cache = RotaryEmbedding._compute_cos_sin_cache(self)
+        self.cos_sin_cache = cache
+        q, k = RotaryEmbedding.forward_native(self, c["positions"], c["q"].clone(), c["k"].clone())
+        out[case["name"] + ".q"] = _cases.bits16(q)
+        out[case["name"] + ".k"] = _cases.bits16(k)
+        out[case["name"] + ".cache_sum"] = np.array([cache.double().sum().item(), cache.double().abs().sum().item()])
+    np.savez_compressed(os.path.join(HERE, "elementwise.npz"), **out)
+    print("elementwise.npz", len(out), "arrays")
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     torch.manual_seed(0)
     if what in ("attention", "all"):
         gen_attention()
-    for extra in ("index", "quant", "radix"):
+    for extra in ("index", "quant", "elementwise", "radix"):
         fn = globals().get("gen_" + extra)
         if fn is not None and what in (extra, "all"):
             fn()

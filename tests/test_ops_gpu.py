@@ -1,0 +1,222 @@
+"""GPU parity (through the C-ABI) of the index, fp8-quant, skinny-GEMM and elementwise kernels against the
+golden vectors of the reference and against the CPU oracle.  Integer / byte results: bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+import _cases
+from oracle import elementwise as oe
+from oracle import kv_index as oi
+from oracle import quant as oq
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def sk(pkg):
+    from ltp_sglang_amd import sgl_kernel
+
+    return sgl_kernel
+
+
+# ---------------------------------------------------------------- index kernels (bit exact)
+@pytest.mark.parametrize("case", _cases.INDEX_CASES, ids=lambda c: c["name"])
+@pytest.mark.parametrize("idx_dtype", [torch.int64, torch.int32])
+def test_index_kernels_bit_exact(case, idx_dtype, sk, golden):
+    g = golden("index")
+    c = _cases.build_index_case(case)
+    n, bs = case["name"], c["bs"]
+    r2t = torch.from_numpy(c["req_to_token"].copy()).to(DEV)
+    rpi = torch.from_numpy(c["req_pool_indices"]).to(idx_dtype).to(DEV)
+    pre, seq, ext = (torch.from_numpy(c[k]).to(idx_dtype).to(DEV) for k in ("pre", "seq", "ext"))
+    loc = torch.from_numpy(c["out_cache_loc"]).to(DEV)
+    sk.write_req_to_token(r2t, rpi, pre, seq, ext, loc)
+    assert np.array_equal(r2t.cpu().numpy(), g[n + ".req_to_token"])
+    for tag, lens in (("seq", seq), ("pre", pre)):
+        kv_indptr = torch.zeros(bs + 1, dtype=torch.int32, device=DEV)
+        sk.decode_metadata(kv_indptr, None, lens, 1, 32, 8, 16, 256)
+        assert np.array_equal(kv_indptr.cpu().numpy(), g[f"{n}.kv_indptr_{tag}"])
+        kv_indices = torch.full((int(lens.sum()) + 3,), -7, dtype=torch.int32, device=DEV)
+        sk.create_kv_indices(r2t, rpi, lens, kv_indptr, None, kv_indices)
+        got = kv_indices.cpu().numpy()
+        assert np.array_equal(got[:-3], g[f"{n}.kv_indices_{tag}"]) and (got[-3:] == -7).all()
+    win = torch.minimum(seq, torch.tensor(9, device=DEV, dtype=idx_dtype))
+    kv_indptr = torch.zeros(bs + 1, dtype=torch.int32, device=DEV)
+    sk.decode_metadata(kv_indptr, None, win, 1, 32, 8, 16, 256)
+    kv_indices = torch.zeros(int(win.sum()), dtype=torch.int32, device=DEV)
+    sk.create_kv_indices(r2t, rpi, win, kv_indptr, seq - win, kv_indices)
+    assert np.array_equal(kv_indices.cpu().numpy(), g[n + ".kv_indices_win"])
+    pos, start = sk.compute_position(pre.int(), ext.int(), int(ext.sum()))
+    assert pos.dtype == torch.int64 and start.dtype == torch.int32
+    assert np.array_equal(pos.cpu().numpy(), g[n + ".positions"])
+    assert np.array_equal(start.cpu().numpy(), g[n + ".extend_start_loc"])
+    assert np.array_equal(sk.get_last_loc(r2t, rpi, pre).cpu().numpy(), g[n + ".last_loc"].astype(pre.cpu().numpy().dtype))
+
+
+@pytest.mark.parametrize("case", _cases.SPLIT_CASES, ids=lambda c: c["name"])
+def test_num_kv_splits_matches_reference_heuristic(case, sk, golden):
+    seq = torch.tensor(case["seq"], dtype=torch.int64, device=DEV)
+    out = torch.zeros(len(case["seq"]), dtype=torch.int32, device=DEV)
+    sk.decode_metadata(None, out, seq, 1, case["num_head"], case["num_kv_head"], case["max_splits"], case["cores"])
+    assert np.array_equal(out.cpu().numpy(), golden("index")[case["name"]])
+
+
+def test_large_batch_cumsum_and_positions(sk):
+    rng = np.random.RandomState(5)
+    bs = 3000  # > one 1024-lane scan chunk
+    ext = rng.randint(1, 40, size=bs).astype(np.int64)
+    pre = rng.randint(0, 50, size=bs).astype(np.int64)
+    kv_indptr = torch.zeros(bs + 1, dtype=torch.int32, device=DEV)
+    sk.decode_metadata(kv_indptr, None, torch.from_numpy(ext).to(DEV), 1, 32, 8, 16, 256)
+    assert np.array_equal(kv_indptr.cpu().numpy(), oi.kv_indptr(ext))
+    pos, start = sk.compute_position(torch.from_numpy(pre).int().to(DEV), torch.from_numpy(ext).int().to(DEV), int(ext.sum()))
+    rp, rs = oi.compute_position(pre, ext)
+    assert np.array_equal(pos.cpu().numpy(), rp) and np.array_equal(start.cpu().numpy(), rs)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_set_kv_buffer_bit_exact(dtype, sk):
+    g = torch.Generator().manual_seed(2)
+    slots, hkv, d, t = 301, 8, 128, 77
+    kb = torch.randn(slots, hkv, d, generator=g).to(dtype)
+    vb = torch.randn(slots, hkv, d, generator=g).to(dtype)
+    ck = torch.randn(t, hkv, d, generator=g).to(dtype)
+    cv = torch.randn(t, hkv, d, generator=g).to(dtype)
+    loc = (torch.randperm(slots - 1, generator=g)[:t] + 1)
+    kd, vd = kb.to(DEV), vb.to(DEV)
+    sk.set_kv_buffer(kd, vd, loc.to(DEV), ck.to(DEV), cv.to(DEV))
+    kb[loc] = ck
+    vb[loc] = cv
+    assert torch.equal(kd.cpu(), kb) and torch.equal(vd.cpu(), vb)
+
+
+# ---------------------------------------------------------------- fp8 quant (bit exact)
+@pytest.mark.parametrize("case", _cases.QUANT_CASES, ids=lambda c: c["name"])
+def test_fp8_quant_bit_exact(case, sk, golden):
+    g = golden("quant")
+    x = _cases.build_quant_case(case)
+    n = case["name"]
+    xd = x.to(DEV)
+    q = torch.empty(x.shape, dtype=torch.float8_e4m3fn, device=DEV)
+    s = torch.zeros(x.shape[0], 1, dtype=torch.float32, device=DEV)
+    sk.sgl_per_token_quant_fp8(xd, q, s)
+    assert np.array_equal(s.cpu().numpy(), g[n + ".tok_s"])
+    assert np.array_equal(q.cpu().view(torch.uint8).numpy(), g[n + ".tok_q"])
+    s1 = torch.zeros(1, dtype=torch.float32, device=DEV)
+    sk.sgl_per_tensor_quant_fp8(xd, q, s1, False)
+    assert np.array_equal(s1.cpu().numpy(), g[n + ".ten_s"])
+    assert np.array_equal(q.cpu().view(torch.uint8).numpy(), g[n + ".ten_q"])
+    s2 = torch.tensor([0.37], dtype=torch.float32, device=DEV)
+    sk.sgl_per_tensor_quant_fp8(xd, q, s2, True)
+    assert np.array_equal(q.cpu().view(torch.uint8).numpy(), g[n + ".ten_static_q"])
+
+
+@pytest.mark.parametrize("m,k", [(128, 512), (256, 1368), (3000, 4096)])
+def test_per_token_quant_large_batch_vs_oracle(m, k, sk):
+    # reference test shapes (test_per_token_quant_fp8.py:38-41) incl. the wave-per-token path (m >= 2048)
+    x = (torch.rand(m, k, generator=torch.Generator().manual_seed(m)) * 4 - 2).half()
+    q = torch.empty(m, k, dtype=torch.float8_e4m3fn, device=DEV)
+    s = torch.zeros(m, dtype=torch.float32, device=DEV)
+    sk.sgl_per_token_quant_fp8(x.to(DEV), q, s)
+    rq, rs = oq.per_token_quant_fp8(x)
+    assert torch.equal(s.cpu(), rs.flatten()) and torch.equal(q.cpu().view(torch.uint8), rq.view(torch.uint8))
+
+
+def test_per_token_group_quant_vs_oracle(sk):
+    x = torch.randn(37, 1024, generator=torch.Generator().manual_seed(3)).bfloat16()
+    q = torch.empty(37, 1024, dtype=torch.float8_e4m3fn, device=DEV)
+    s = torch.zeros(37, 8, dtype=torch.float32, device=DEV)
+    sk.sgl_per_token_group_quant_fp8(x.to(DEV), q, s, 128, 1e-10, -448.0, 448.0, False)
+    rq, rs = oq.per_token_group_quant_fp8(x, 128)
+    assert torch.equal(s.cpu(), rs) and torch.equal(q.cpu().view(torch.uint8), rq.view(torch.uint8))
+
+
+def test_quant_rejects_bad_hidden(sk):
+    x = torch.zeros(4, 20, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(RuntimeError, match="divisible by 8"):
+        sk.sgl_per_token_quant_fp8(x, torch.empty(4, 20, dtype=torch.float8_e4m3fn, device=DEV), torch.zeros(4, device=DEV))
+
+
+# ---------------------------------------------------------------- fp8 scaled mm
+@pytest.mark.parametrize("case", _cases.GEMM_CASES, ids=lambda c: c["name"])
+def test_fp8_scaled_mm_vs_golden(case, sk, golden):
+    c = _cases.build_gemm_case(case)
+    o = sk.fp8_scaled_mm(c["a"].to(DEV), c["w"].to(DEV).t(), c["sa"].to(DEV), c["sb"].to(DEV), c["out_dtype"],
+                         None if c["bias"] is None else c["bias"].to(DEV))
+    want = _cases.from_bits16(golden("quant")[case["name"] + ".mm"], c["out_dtype"]).reshape(o.shape)
+    # reference tolerance is rtol 0.02 / atol 1 (test_fp8_gemm.py:32-34); products are exact in f32 so only the
+    # summation order and the single (vs double, with bias) output rounding differ: 2 ulp of the output dtype
+    torch.testing.assert_close(o.cpu().float(), want.float(), rtol=1.6e-2, atol=0.3)
+
+
+def test_fp8_scaled_mm_checks(sk):
+    a = torch.zeros(4, 64, dtype=torch.float8_e4m3fn, device=DEV)
+    b = torch.zeros(32, 64, dtype=torch.float8_e4m3fn, device=DEV)
+    sa, sb = torch.ones(4, device=DEV), torch.ones(32, device=DEV)
+    with pytest.raises(RuntimeError, match="column major"):
+        sk.fp8_scaled_mm(a, b.t().contiguous(), sa, sb, torch.bfloat16)
+    with pytest.raises(RuntimeError, match="out_dtype must be Half or BFloat16"):
+        sk.fp8_scaled_mm(a, b.t(), sa, sb, torch.float32)
+    with pytest.raises(RuntimeError, match="size of scales_b"):
+        sk.fp8_scaled_mm(a, b.t(), sa, sb[:5], torch.bfloat16)
+
+
+@pytest.mark.parametrize("m,n,k,dtype", [(32, 1000, 4096, torch.bfloat16), (5, 64, 768, torch.float16), (64, 48, 1024, torch.bfloat16)])
+def test_dense_skinny_linear(m, n, k, dtype, sk):
+    g = torch.Generator().manual_seed(k)
+    x = torch.randn(m, k, generator=g).to(dtype)
+    w = (torch.randn(n, k, generator=g) * 0.05).to(dtype)
+    b = torch.randn(n, generator=g).to(dtype)
+    o = sk.dense_linear(x.to(DEV), w.to(DEV), b.to(DEV))
+    ref = torch.nn.functional.linear(x.float(), w.float(), b.float())
+    tol = 3e-2 if dtype == torch.bfloat16 else 4e-3
+    assert (o.cpu().float() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+
+
+# ---------------------------------------------------------------- elementwise
+@pytest.mark.parametrize("case", _cases.NORM_CASES, ids=lambda c: c["name"])
+def test_rmsnorm_vs_golden(case, sk, golden):
+    g = golden("elementwise")
+    c = _cases.build_norm_case(case)
+    n, dt = case["name"], c["x"].dtype
+    ulp = 2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10
+    y = sk.rmsnorm(c["x"].to(DEV), c["w"].to(DEV), c["eps"])
+    torch.testing.assert_close(y.cpu().float(), _cases.from_bits16(g[n + ".y"], dt).float(), rtol=ulp, atol=ulp)
+    x, r = c["x"].to(DEV), c["res"].to(DEV)
+    sk.fused_add_rmsnorm(x, r, c["w"].to(DEV), c["eps"])
+    assert np.array_equal(_cases.bits16(r.cpu()), g[n + ".res"])  # the residual sum has one rounding: exact
+    torch.testing.assert_close(x.cpu().float(), _cases.from_bits16(g[n + ".y_res"], dt).float(), rtol=ulp, atol=ulp)
+
+
+@pytest.mark.parametrize("case", _cases.ROPE_CASES, ids=lambda c: c["name"])
+def test_rope_vs_golden(case, sk, golden):
+    g = golden("elementwise")
+    c = _cases.build_rope_case(case)
+    cache = oe.rope_cache(case["hs"], case["rot"], 4096, case["base"])
+    q, k = c["q"].to(DEV), c["k"].to(DEV)
+    sk.apply_rope_with_cos_sin_cache_inplace(c["positions"].to(DEV), q, k, case["hs"], cache.to(DEV), case["neox"])
+    # same rounding points as the reference's forward_native: bit exact
+    assert np.array_equal(_cases.bits16(q.cpu()), g[case["name"] + ".q"])
+    assert np.array_equal(_cases.bits16(k.cpu()), g[case["name"] + ".k"])
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_silu_and_mul_vs_oracle(dtype, sk):
+    x = (torch.randn(9, 2 * 1408, generator=torch.Generator().manual_seed(1)) * 3).to(dtype)
+    o = sk.silu_and_mul(x.to(DEV))
+    ref = oe.silu_and_mul(x)
+    ulp = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+    torch.testing.assert_close(o.cpu().float(), ref.float(), rtol=ulp, atol=1e-6)
+    assert (o.cpu() == ref).float().mean().item() > 0.995  # identical rounding points; exp ulp differences only
+
+
+def test_embedding_and_argmax(sk):
+    g = torch.Generator().manual_seed(4)
+    table = torch.randn(1000, 256, generator=g).bfloat16()
+    ids = torch.randint(0, 1000, (33,), generator=g)
+    assert torch.equal(sk.embedding(ids.to(DEV), table.to(DEV)).cpu(), table[ids])
+    logits = torch.randn(7, 128256, generator=g).bfloat16()
+    logits[3, 77] = logits[3, 90000] = 50.0  # tie -> lowest index
+    assert torch.equal(sk.argmax(logits.to(DEV)).cpu(), torch.argmax(logits.float(), dim=-1))
+    assert torch.equal(sk.argmax(logits.float().to(DEV)).cpu(), torch.argmax(logits.float(), dim=-1))
