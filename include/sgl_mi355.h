@@ -105,6 +105,21 @@ int sgl_mi355_skinny_gemm(const void* x, int64_t x_stride_elems, const void* w, 
                           int64_t y_stride_elems, const float* scales_x, const float* scales_w, const void* bias, int M,
                           int N, int K, int in_dtype, int out_dtype, void* stream);
 
+/* Tiled MFMA GEMM for M > 64 with the same contract as sgl_mi355_skinny_gemm's fp8 case:
+ * fp8_scaled_mm, sgl-kernel/csrc/gemm/fp8_gemm_kernel.cu:1071-1146 (CUTLASS tile dispatch :303-440,739-796). */
+int sgl_mi355_fp8_gemm(const void* x, int64_t x_stride_elems, const void* w, int64_t w_stride_elems, void* y,
+                       int64_t y_stride_elems, const float* scales_x, const float* scales_w, const void* bias, int M,
+                       int N, int K, int out_dtype, void* stream);
+/* Unquantised bf16/f16 linear for M > 64 (UnquantizedLinearMethod.apply, layers/quantization/unquant.py);
+ * also the matmul half of AWQLinearMethod.apply (layers/quantization/awq.py:401-418). */
+int sgl_mi355_dense_gemm(const void* x, int64_t x_stride_elems, const void* w, int64_t w_stride_elems, void* y,
+                         int64_t y_stride_elems, const void* bias, int M, int N, int K, int in_dtype, int out_dtype,
+                         void* stream);
+/* awq_dequantize, sgl-kernel/csrc/gemm/awq_kernel.cu:127-221 (python gemm.py:7-10); HIP reference path
+ * awq_dequantize_triton, layers/quantization/awq_triton.py:14-108.  out [K, 8*num_packed_cols] in the scale dtype. */
+int sgl_mi355_awq_dequantize(const void* qweight, const void* scales, const void* qzeros, void* out, int K,
+                             int num_packed_cols, int group_size, int scale_dtype, void* stream);
+
 /* ---- elementwise neighbours on the step path -------------------------------- */
 /* RMSNorm.forward_native, python/sglang/srt/layers/layernorm.py:135-171; sgl_kernel rmsnorm / fused_add_rmsnorm
  * (sgl-kernel/csrc/elementwise/fused_add_rms_norm_kernel.cu).  residual != NULL: residual += x, out = norm(sum). */

@@ -29,6 +29,18 @@ __device__ __forceinline__ void st8(T* p, const V8<T>& x) {
   *(u32x4_t*)p = __builtin_bit_cast(u32x4_t, x);
 }
 
+// Round an f32 to T and come back as f32 through the BIT PATTERN, so that the front end cannot keep the value in
+// excess precision across the cast (clang evaluates __bf16/_Float16 expressions in float and may elide a
+// T -> float -> T round trip); these are the reference's rounding points and must really happen.
+template <typename T>
+__device__ __forceinline__ float round_via(float x) {
+  const T t = (T)x;
+  const uint16_t u = __builtin_bit_cast(uint16_t, t);
+  uint16_t v;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "v"(u));
+  return (float)__builtin_bit_cast(T, v);
+}
+
 __device__ __forceinline__ float block_sum_256(float v, float* red) {
   v = wave_reduce_sum(v);
   __syncthreads();
@@ -101,8 +113,8 @@ __global__ __launch_bounds__(256) void silu_and_mul_kernel(T* out, const T* x, i
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float af = (float)a.v[j];
-      const T s = (T)(af / (1.0f + expf(-af)));
-      o.v[j] = (T)((float)s * (float)b.v[j]);
+      const float s = round_via<T>(af / (1.0f + expf(-af)));
+      o.v[j] = (T)(s * (float)b.v[j]);
     }
     st8(out + t * d + c * 8, o);
   }
@@ -123,13 +135,13 @@ __global__ __launch_bounds__(256) void rope_kernel(T* q, T* k, const int64_t* po
     const int h = rem / half, i = rem - h * half;
     T* base = (h < hq) ? q + t * q_stride + (int64_t)h * head_size : k + t * k_stride + (int64_t)(h - hq) * head_size;
     const float* cs = cache + positions[t] * rot_dim;
-    const T c = (T)cs[i], s = (T)cs[half + i];
+    const float c = round_via<T>(cs[i]), s = round_via<T>(cs[half + i]);
     const int i1 = is_neox ? i : 2 * i, i2 = is_neox ? half + i : 2 * i + 1;
-    const T x1 = base[i1], x2 = base[i2];
-    const T p11 = (T)((float)x1 * (float)c), p22 = (T)((float)x2 * (float)s);
-    const T p21 = (T)((float)x2 * (float)c), p12 = (T)((float)x1 * (float)s);
-    base[i1] = (T)((float)p11 - (float)p22);
-    base[i2] = (T)((float)p21 + (float)p12);
+    const float x1 = (float)base[i1], x2 = (float)base[i2];
+    const float p11 = round_via<T>(x1 * c), p22 = round_via<T>(x2 * s);
+    const float p21 = round_via<T>(x2 * c), p12 = round_via<T>(x1 * s);
+    base[i1] = (T)(p11 - p22);
+    base[i2] = (T)(p21 + p12);
   }
 }
 

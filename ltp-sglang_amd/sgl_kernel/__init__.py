@@ -14,6 +14,7 @@ from .elementwise import (
     silu_and_mul,
 )
 from .gemm import (
+    awq_dequantize,
     dense_linear,
     fp8_scaled_mm,
     sgl_per_tensor_quant_fp8,

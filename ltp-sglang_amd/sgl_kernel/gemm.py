@@ -13,6 +13,22 @@ def _cuda(*ts):
             raise RuntimeError("sgl_kernel (MI355X) ops need device tensors; there is no CPU path")
 
 
+def awq_dequantize(qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.Tensor) -> torch.Tensor:
+    """qweight [K, N/8] int32, scales [K/G, N] f16/bf16, qzeros [K/G, N/8] int32 -> [K, N] (gemm.py:7-10)."""
+    _cuda(qweight, scales, qzeros)
+    if qweight.dtype != torch.int32 or qzeros.dtype != torch.int32:
+        raise RuntimeError("qweight and qzeros must be int32")
+    assert qweight.is_contiguous() and scales.is_contiguous() and qzeros.is_contiguous()
+    k, nc = qweight.shape
+    groups = scales.shape[0]
+    if scales.shape[1] != nc * 8 or tuple(qzeros.shape) != (groups, nc) or k % groups != 0:
+        raise RuntimeError("awq_dequantize: inconsistent qweight / scales / qzeros shapes")
+    out = torch.empty((k, nc * 8), dtype=scales.dtype, device=qweight.device)
+    check(lib.sgl_mi355_awq_dequantize(ptr(qweight), ptr(scales), ptr(qzeros), ptr(out), k, nc, k // groups,
+                                       dtype_code(scales.dtype), current_stream()))
+    return out
+
+
 def fp8_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype, bias=None):
     """out[M,N] = (mat_a[M,K] @ mat_b[K,N]) * scales_a[m] * scales_b[n] (+ bias[n]).
 

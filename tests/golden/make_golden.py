@@ -233,6 +233,8 @@ def gen_elementwise():
         out[case["name"] + ".q"] = _cases.bits16(q)
         out[case["name"] + ".k"] = _cases.bits16(k)
         out[case["name"] + ".cache_sum"] = np.array([cache.double().sum().item(), cache.double().abs().sum().item()])
+        # cos/sin differ in the last ulp between host libm code paths, so the rows used travel with the fixture
+        out[case["name"] + ".cache_rows"] = cache[c["positions"]].numpy().copy()
     np.savez_compressed(os.path.join(HERE, "elementwise.npz"), **out)
     print("elementwise.npz", len(out), "arrays")
 

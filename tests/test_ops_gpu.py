@@ -193,7 +193,8 @@ def test_rmsnorm_vs_golden(case, sk, golden):
 def test_rope_vs_golden(case, sk, golden):
     g = golden("elementwise")
     c = _cases.build_rope_case(case)
-    cache = oe.rope_cache(case["hs"], case["rot"], 4096, case["base"])
+    cache = torch.zeros(4096, case["rot"], dtype=torch.float32)
+    cache[c["positions"]] = torch.from_numpy(g[case["name"] + ".cache_rows"])  # the generating host's cos/sin rows
     q, k = c["q"].to(DEV), c["k"].to(DEV)
     sk.apply_rope_with_cos_sin_cache_inplace(c["positions"].to(DEV), q, k, case["hs"], cache.to(DEV), case["neox"])
     # same rounding points as the reference's forward_native: bit exact
@@ -220,3 +221,46 @@ def test_embedding_and_argmax(sk):
     logits[3, 77] = logits[3, 90000] = 50.0  # tie -> lowest index
     assert torch.equal(sk.argmax(logits.to(DEV)).cpu(), torch.argmax(logits.float(), dim=-1))
     assert torch.equal(sk.argmax(logits.float().to(DEV)).cpu(), torch.argmax(logits.float(), dim=-1))
+
+
+# ---------------------------------------------------------------- AWQ dequant (bit exact)
+@pytest.mark.parametrize("case", _cases.AWQ_CASES, ids=lambda c: c["name"])
+def test_awq_dequantize_bit_exact_vs_golden(case, sk, golden):
+    c = _cases.build_awq_case(case)
+    o = sk.awq_dequantize(c["qweight"].to(DEV), c["scales"].to(DEV), c["qzeros"].to(DEV))
+    assert o.dtype == c["scales"].dtype
+    assert np.array_equal(_cases.bits16(o.cpu()), golden("quant")[case["name"] + ".deq"])
+
+
+@pytest.mark.parametrize("k,nc", [(3584, 576), (3584, 448), (1536, 4736), (18944, 448), (128, 72)])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_awq_dequantize_qwen2_shapes_vs_oracle(k, nc, dtype, sk):
+    # the reference's own shape list (sgl-kernel/tests/test_awq_dequant.py:66-70), group size 128
+    g = torch.Generator().manual_seed(k + nc)
+    qw = torch.randint(0, 2**31 - 1, (k, nc), generator=g, dtype=torch.int32)
+    qz = torch.randint(0, 2**31 - 1, (k // 128, nc), generator=g, dtype=torch.int32)
+    sc = torch.rand(k // 128, nc * 8, generator=g).to(dtype)
+    o = sk.awq_dequantize(qw.to(DEV), sc.to(DEV), qz.to(DEV))
+    assert torch.equal(o.cpu(), oq.awq_dequantize(qw, sc, qz, 128))
+
+
+# ---------------------------------------------------------------- tiled GEMM at prefill-sized M
+@pytest.mark.parametrize("m,n,k", [(256, 384, 4096), (1000, 136, 1024), (129, 6144, 512)])
+def test_fp8_scaled_mm_large_m_vs_oracle(m, n, k, sk):
+    case = dict(m=m, n=n, k=k, bias=True, out="bf16")
+    c = _cases.build_gemm_case(case, seed=m)
+    o = sk.fp8_scaled_mm(c["a"].to(DEV), c["w"].to(DEV).t(), c["sa"].to(DEV), c["sb"].to(DEV), c["out_dtype"], c["bias"].to(DEV))
+    ref = oq.scaled_mm(c["a"], c["w"].t(), c["sa"], c["sb"], c["out_dtype"], c["bias"])
+    torch.testing.assert_close(o.cpu().float(), ref.float(), rtol=1.6e-2, atol=0.3)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_dense_gemm_large_m(dtype, sk):
+    g = torch.Generator().manual_seed(9)
+    m, n, k = 300, 200, 1032
+    x = torch.randn(m, k, generator=g).to(dtype)
+    w = (torch.randn(n, k, generator=g) * 0.05).to(dtype)
+    o = sk.dense_linear(x.to(DEV), w.to(DEV))
+    ref = x.float() @ w.float().t()
+    tol = 3e-2 if dtype == torch.bfloat16 else 4e-3
+    assert (o.cpu().float() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
