@@ -54,6 +54,23 @@ int sgl_mi355_decode_attention(const void* q, int64_t q_stride_t, const void* k_
                                int max_kv_splits, int batch, int num_q_heads, int num_kv_heads, int head_dim,
                                int v_head_dim, float sm_scale, float logit_cap, int dtype, void* stream);
 
+/* Extend (prefill / chunked prefill / prefix-cache hit) attention: cached prefix from the paged pool + causal
+ * triangle over the contiguous new K/V.  Replaces extend_attention_fwd
+ * (python/sglang/srt/layers/attention/triton_ops/extend_attention.py:306-438) with (qo_indptr, kv_indptr,
+ * kv_indices), and extend_attention_cpu's addressing (sgl-kernel/csrc/cpu/extend.cpp:579-723, schema
+ * torch_extension_cpu.cpp:270-275) with (req_to_token, req_pool_indices, seq_lens, extend_seq_lens,
+ * extend_start_loc) when qo_indptr == NULL.  q/o [T, Hq, D], k/v_extend [T, Hkv, D] (heads contiguous).
+ * custom masks and sliding windows (speculative decoding / Gemma) are not part of this build. */
+int sgl_mi355_extend_attention(const void* q_extend, const void* k_extend, const void* v_extend, void* o_extend,
+                               int64_t q_stride_t, int64_t k_stride_t_ext, int64_t v_stride_t_ext, int64_t o_stride_t,
+                               const void* k_buffer, const void* v_buffer, int64_t k_stride_t, int64_t k_stride_h,
+                               int64_t v_stride_t, int64_t v_stride_h, const int32_t* qo_indptr,
+                               const int32_t* kv_indptr, const int32_t* kv_indices, const int32_t* req_to_token,
+                               int64_t req_to_token_stride, const int64_t* req_pool_indices, const int64_t* seq_lens,
+                               const int32_t* extend_seq_lens, const int32_t* extend_start_loc, int batch,
+                               int total_q_tokens, int max_len_extend, int num_q_heads, int num_kv_heads, int head_dim,
+                               int v_head_dim, float sm_scale, float logit_cap, int is_causal, int dtype, void* stream);
+
 /* ---- KV pool / index kernels (bit-exact) -------------------------------------------------- */
 /* create_flashinfer_kv_indices_triton, python/sglang/srt/layers/attention/utils.py:10-45 */
 int sgl_mi355_create_kv_indices(const int32_t* req_to_token, int64_t req_to_token_stride, const void* req_pool_indices,

@@ -57,7 +57,7 @@ constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 
 __device__ __forceinline__ void request_range(const DecodeParams& p, int b, const int32_t*& idx_row, int& seq_len) {
-  if (p.kv_indices != nullptr) {
+  if (p.kv_indptr != nullptr) {
     const int s0 = p.kv_indptr[b];
     seq_len = p.kv_indptr[b + 1] - s0;
     idx_row = p.kv_indices + s0;
@@ -439,7 +439,7 @@ extern "C" int sgl_mi355_decode_attention(
   if (batch == 0) return SGL_MI355_OK;
   SGL_CHECK(q && k_buffer && v_buffer && o, "decode_attention: null tensor pointer");
   SGL_CHECK(attn_logits && attn_lse && num_kv_splits, "decode_attention: null split scratch pointer");
-  SGL_CHECK((kv_indptr && kv_indices) || (req_to_token && req_pool_indices && seq_lens),
+  SGL_CHECK(kv_indptr || (req_to_token && req_pool_indices && seq_lens),
             "decode_attention: need either (kv_indptr, kv_indices) or (req_to_token, req_pool_indices, seq_lens)");
   SGL_CHECK(num_kv_heads > 0 && num_q_heads % num_kv_heads == 0, "decode_attention: Hq=%d not a multiple of Hkv=%d",
             num_q_heads, num_kv_heads);

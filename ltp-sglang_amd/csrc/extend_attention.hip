@@ -1,0 +1,480 @@
+// Extend (prefill / chunked-prefill / RadixAttention-hit) attention, gfx950.
+//
+// Replaces extend_attention_fwd / _fwd_kernel
+//   (python/sglang/srt/layers/attention/triton_ops/extend_attention.py:41-438): stage 1 scores the new query
+//   tokens against the cached PREFIX gathered from the paged pool through kv_indices, stage 2 runs the causal
+//   triangle against the contiguous k_extend / v_extend of the same request; o = acc / l.
+// and, through the req_to_token addressing mode, extend_attention_cpu (sgl-kernel/csrc/cpu/extend.cpp:579-723).
+// Semantics match the oracle torch_native_backend.py:27-110 (causal, top-left aligned with the prefix offset).
+//
+// Structure: one 256-thread workgroup = one (request, kv head [8-head chunk], block of BQ query positions):
+// 128 query "rows" = (q head of the GQA group) x (position), so every K/V tile staged in LDS is shared by all
+// heads of the group.  K/V tiles of 64 tokens are gathered (prefix: 256-B pool rows through kv_indices;
+// extend: contiguous rows) with 16-B loads, register-staged one tile ahead and written to double-buffered,
+// XOR-swizzled LDS images (conflict-free ds_read_b128 K fragments and ds_read_b64_tr_b16 V^T fragments).
+// Math per wave (2 x 16 query rows): S^T = K Q^T and O^T += V^T P^T with v_mfma_f32_16x16x32, online softmax in
+// registers with two xor-shuffles per row reduction -- the decode kernel's formulation with (head, position)
+// pairs in place of heads.  Workgroups of the same (request, kv head) are mapped to the same XCD so the K/V they
+// re-read stay in that XCD's L2.
+#include "common.h"
+
+namespace {
+
+struct ExtendParams {
+  const void* q;   // [T, Hq, D]
+  const void* ke;  // [T, Hkv, D]
+  const void* ve;  // [T, Hkv, D]
+  void* o;         // [T, Hq, D]
+  int64_t q_stride_t, ke_stride_t, ve_stride_t, o_stride_t;  // elements; heads contiguous (stride D)
+  const void* k_buf;
+  const void* v_buf;
+  int64_t k_stride_t, k_stride_h, v_stride_t, v_stride_h;
+  const int32_t* qo_indptr;   // [bs+1]
+  const int32_t* kv_indptr;   // [bs+1] prefix lengths cumsum
+  const int32_t* kv_indices;  // prefix slots
+  // alternative addressing (CPU op schema): prefix = req_to_token[req_pool_indices[b], :seq_lens[b]-ext]
+  const int32_t* req_to_token;
+  int64_t req_to_token_stride;
+  const int64_t* req_pool_indices;
+  const int64_t* seq_lens;
+  const int32_t* extend_seq_lens;
+  const int32_t* extend_start_loc;
+  int bs, hq, hkv, group, nqb, bq_log2, hchunks;
+  float sm_scale, logit_cap;
+  int is_causal;
+};
+
+constexpr int kKT = 64;  // kv tokens per tile
+constexpr float kLog2e = 1.4426950408889634f;
+
+__device__ __forceinline__ float softcap2(float s_scaled, float cap) {
+  const float y = s_scaled / cap;
+  const float t = 2.0f / (1.0f + __expf(-2.0f * y)) - 1.0f;
+  return cap * t * kLog2e;
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(256, 2) void extend_attn_kernel(const ExtendParams p) {
+  using Tr = ElemTraits<T>;
+  using vec8 = typename Tr::vec8;
+  constexpr int ROWB = D * 2;
+  constexpr int LPR = ROWB / 16;
+  constexpr int RPI = 256 / LPR;   // rows per workgroup-wide load instruction
+  constexpr int NI = kKT / RPI;    // load instructions per operand per tile
+  constexpr int KS = D / 32;
+  constexpr int NT = D / 16;
+  constexpr int TILE_B = kKT * ROWB;
+  constexpr int RPB = (ROWB >= 256) ? 1 : 256 / ROWB;
+  constexpr int KMASK = (LPR < 16 ? LPR : 16) - 1;
+  constexpr int VCH = ROWB / 32;
+  constexpr int VMASK = (VCH < 8 ? VCH : 8) - 1;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  // ---- block -> (request, kv head chunk, q block); same (request, kv head) => same blockIdx % 8 (one XCD) ----
+  const int bid = blockIdx.x;
+  const int lo = bid & 7, rest = bid >> 3;
+  const int qb = rest % p.nqb;
+  const int pair = (rest / p.nqb) * 8 + lo;
+  const int npairs = p.bs * p.hkv * p.hchunks;
+  if (pair >= npairs) return;
+  const int b = pair / (p.hkv * p.hchunks);
+  const int khc = pair - b * (p.hkv * p.hchunks);
+  const int kh = khc / p.hchunks, hc = khc - kh * p.hchunks;
+
+  const int bq = 1 << p.bq_log2;          // query positions per workgroup
+  const int gslots = 128 >> p.bq_log2;    // head slots per workgroup (<= 8)
+  const int q0 = p.qo_indptr ? p.qo_indptr[b] : p.extend_start_loc[b];
+  const int ext_len = p.qo_indptr ? p.qo_indptr[b + 1] - q0 : p.extend_seq_lens[b];
+  const int qpos0 = qb * bq;
+  if (qpos0 >= ext_len) return;
+  int pre_len;
+  const int32_t* idx_row;
+  if (p.kv_indptr) {  // mode by indptr: kv_indices may legitimately be NULL when no request has a prefix
+    const int s0 = p.kv_indptr[b];
+    pre_len = p.kv_indptr[b + 1] - s0;
+    idx_row = p.kv_indices + s0;
+  } else {
+    pre_len = (int)p.seq_lens[b] - ext_len;
+    idx_row = p.req_to_token + p.req_pool_indices[b] * p.req_to_token_stride;
+  }
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int a = lane & 15, g = lane >> 4;
+
+  // ---- this wave's two 16-row query tiles: tile t covers head slot (16 t) / bq, positions (16 t) % bq ... ----
+  int hq_idx[2], qpos[2];
+  bool head_ok[2];
+  vec8 qf[2][KS];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int t16 = (2 * w + qt) * 16;
+    const int hslot = t16 >> p.bq_log2;
+    const int hl = hc * 8 + hslot;  // head within the GQA group
+    head_ok[qt] = hl < p.group && hslot < gslots;
+    hq_idx[qt] = kh * p.group + min(hl, p.group - 1);
+    qpos[qt] = qpos0 + (t16 & (bq - 1)) + a;  // position of this lane's query row inside the extend part
+    const bool row_ok = head_ok[qt] && qpos[qt] < ext_len;
+    const T* qrow = (const T*)p.q + (int64_t)(q0 + min(qpos[qt], ext_len - 1)) * p.q_stride_t + (int64_t)hq_idx[qt] * D;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (row_ok) {
+        qf[qt][ks] = *(const vec8*)(qrow + 32 * ks + 8 * g);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[qt][ks][j] = (T)0.0f;
+      }
+    }
+  }
+
+  // ---- cooperative staging: thread loads chunk c16 of rows rsub + RPI*i ----
+  const int c16 = tid % LPR, rsub = tid / LPR;
+  const char* kpool = (const char*)p.k_buf + ((int64_t)kh * p.k_stride_h) * 2 + c16 * 16;
+  const char* vpool = (const char*)p.v_buf + ((int64_t)kh * p.v_stride_h) * 2 + c16 * 16;
+  const char* kext = (const char*)p.ke + ((int64_t)q0 * p.ke_stride_t + (int64_t)kh * D) * 2 + c16 * 16;
+  const char* vext = (const char*)p.ve + ((int64_t)q0 * p.ve_stride_t + (int64_t)kh * D) * 2 + c16 * 16;
+  const int64_t kpst = p.k_stride_t * 2, vpst = p.v_stride_t * 2, kest = p.ke_stride_t * 2, vest = p.ve_stride_t * 2;
+
+  const int npre_tiles = (pre_len + kKT - 1) / kKT;
+  const int ext_end = p.is_causal ? min(ext_len, qpos0 + bq) : ext_len;  // keys any row of this block may see
+  const int next_tiles = (ext_end + kKT - 1) / kKT;
+  const int ntiles = npre_tiles + next_tiles;
+
+  u32x4_t kreg[NI], vreg[NI];
+  const u32x4_t zero4 = {0u, 0u, 0u, 0u};
+  auto issue = [&](int t) {
+    if (t < npre_tiles) {
+      const int base = t * kKT;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int r = base + rsub + RPI * i;
+        const bool ok = r < pre_len;
+        const int id = ok ? idx_row[r] : 0;
+        kreg[i] = *(const u32x4_t*)(kpool + (int64_t)id * kpst);
+        const u32x4_t vv = *(const u32x4_t*)(vpool + (int64_t)id * vpst);
+        vreg[i] = ok ? vv : zero4;
+      }
+    } else {
+      const int base = (t - npre_tiles) * kKT;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int r = base + rsub + RPI * i;
+        const bool ok = r < ext_len;
+        const int rr = ok ? r : 0;
+        kreg[i] = *(const u32x4_t*)(kext + (int64_t)rr * kest);
+        const u32x4_t vv = *(const u32x4_t*)(vext + (int64_t)rr * vest);
+        vreg[i] = ok ? vv : zero4;
+      }
+    }
+  };
+  auto lstore = [&](int buf) {
+    char* kl = smem + buf * 2 * TILE_B;
+    char* vl = kl + TILE_B;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int row = rsub + RPI * i;
+      const int fk = (row / RPB) & KMASK, fv = (row / RPB) & VMASK;
+      *(u32x4_t*)(kl + row * ROWB + ((c16 ^ fk) << 4)) = kreg[i];
+      *(u32x4_t*)(vl + row * ROWB + ((((c16 >> 1) ^ fv) << 5) | ((c16 & 1) << 4))) = vreg[i];
+    }
+  };
+
+  float m_i[2] = {-INFINITY, -INFINITY}, l_i[2] = {0.f, 0.f};
+  f32x4_t acc[2][NT];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[qt][n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const float scale_log2 = p.sm_scale * kLog2e;
+  const bool use_cap = p.logit_cap > 0.0f;
+
+  if (ntiles > 0) {
+    issue(0);
+    lstore(0);
+  }
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < ntiles) issue(t + 1);
+    const char* kl = smem + buf * 2 * TILE_B;
+    const char* vl = kl + TILE_B;
+    const bool in_prefix = t < npre_tiles;
+    const int kbase = in_prefix ? t * kKT : (t - npre_tiles) * kKT;  // index of the tile's first key in its phase
+    const int klimit = in_prefix ? pre_len : ext_len;
+
+    // a wave whose rows all lie in the causal past of this tile skips it (wave-uniform)
+    const int wave_qmax = qpos0 + (((2 * w + 1) * 16) & (bq - 1)) + 15;
+    const int wave_qmax0 = qpos0 + (((2 * w) * 16) & (bq - 1)) + 15;
+    const bool skip = !in_prefix && p.is_causal && kbase > max(wave_qmax, wave_qmax0);
+    if (!skip) {
+      // ---- S^T tiles: s[qt][tt][r] = score(query row a of tile qt, key 16 tt + 4 g + r) ----
+      f32x4_t s[2][4];
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        const int row = 16 * tt + a;
+        const int fk = (row / RPB) & KMASK;
+        vec8 kf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) kf[ks] = *(const vec8*)(kl + row * ROWB + (((4 * ks + g) ^ fk) << 4));
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+          f32x4_t c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) c = Tr::mfma16(kf[ks], qf[qt][ks], c);
+          s[qt][tt] = c;
+        }
+      }
+      // ---- online softmax per query tile ----
+      vec8 pf[2][2];
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        float mt = -INFINITY;
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = kbase + 16 * tt + 4 * g + r;
+            float v = use_cap ? softcap2(s[qt][tt][r] * p.sm_scale, p.logit_cap) : s[qt][tt][r] * scale_log2;
+            bool ok = key < klimit;
+            if (!in_prefix && p.is_causal) ok = ok && (key <= qpos[qt]);
+            v = ok ? v : -INFINITY;
+            s[qt][tt][r] = v;
+            mt = fmaxf(mt, v);
+          }
+        }
+        mt = fmaxf(mt, __shfl_xor(mt, 16, WAVE));
+        mt = fmaxf(mt, __shfl_xor(mt, 32, WAVE));
+        const float m_new = fmaxf(m_i[qt], mt);
+        const bool dead = m_new == -INFINITY;  // row has seen no key yet
+        const float alpha = dead ? 1.0f : __builtin_amdgcn_exp2f(m_i[qt] - m_new);
+        float lsum = 0.f;
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pv = dead ? 0.0f : __builtin_amdgcn_exp2f(s[qt][tt][r] - m_new);
+            lsum += pv;
+            // PV k-step u = tt / 2 takes keys 32 u + {4 g + j, 16 + 4 g + j}: element index 4 (tt & 1) + r
+            pf[qt][tt >> 1][4 * (tt & 1) + r] = Tr::from_f32(pv);
+          }
+        }
+        l_i[qt] = l_i[qt] * alpha + lsum;
+        m_i[qt] = m_new;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[qt][n] *= alpha;
+      }
+      // ---- O^T += V^T P^T ----
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          s16x4_t t0, t1;
+          {
+            const int row = 32 * u + 4 * g + (a >> 2);
+            const int fv = (row / RPB) & VMASK;
+            t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (s16x4_t __attribute__((address_space(3)))*)(vl + row * ROWB + ((n ^ fv) << 5) + ((a & 3) << 3)));
+          }
+          {
+            const int row = 32 * u + 16 + 4 * g + (a >> 2);
+            const int fv = (row / RPB) & VMASK;
+            t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (s16x4_t __attribute__((address_space(3)))*)(vl + row * ROWB + ((n ^ fv) << 5) + ((a & 3) << 3)));
+          }
+          const vec8 vf = __builtin_bit_cast(vec8, __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+          for (int qt = 0; qt < 2; ++qt) acc[qt][n] = Tr::mfma16(vf, pf[qt][u], acc[qt][n]);
+        }
+      }
+    }
+    if (t + 1 < ntiles) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- o = acc / l ; lane (a, g) owns query row a, columns 16 n + 4 g + [0, 4) ----
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    float l = l_i[qt];
+    l += __shfl_xor(l, 16, WAVE);
+    l += __shfl_xor(l, 32, WAVE);
+    if (head_ok[qt] && qpos[qt] < ext_len) {
+      const float inv = l > 0.f ? 1.0f / l : 0.f;
+      T* orow = (T*)p.o + (int64_t)(q0 + qpos[qt]) * p.o_stride_t + (int64_t)hq_idx[qt] * D;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        typename Tr::vec4 ov;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ov[r] = Tr::from_f32(acc[qt][n][r] * inv);
+        *(typename Tr::vec4*)(orow + 16 * n + 4 * g) = ov;
+      }
+    }
+  }
+}
+
+// Any-head-dim fallback: one wave per (query token, q head); correctness path for odd head sizes.
+template <typename T>
+__global__ __launch_bounds__(64) void extend_attn_generic(const ExtendParams p, int d_qk, int dv, int total_q) {
+  __shared__ float p_lds[64];
+  __shared__ int id_lds[64];
+  const int tq = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
+  if (tq >= total_q) return;
+  // locate the request of this query token
+  int b = 0;
+  if (p.qo_indptr) {
+    while (b + 1 < p.bs && p.qo_indptr[b + 1] <= tq) ++b;
+  } else {
+    while (b + 1 < p.bs && p.extend_start_loc[b + 1] <= tq) ++b;
+  }
+  const int q0 = p.qo_indptr ? p.qo_indptr[b] : p.extend_start_loc[b];
+  const int ext_len = p.qo_indptr ? p.qo_indptr[b + 1] - q0 : p.extend_seq_lens[b];
+  const int qi = tq - q0;
+  if (qi >= ext_len) return;
+  int pre_len;
+  const int32_t* idx_row;
+  if (p.kv_indptr) {  // mode by indptr: kv_indices may legitimately be NULL when no request has a prefix
+    const int s0 = p.kv_indptr[b];
+    pre_len = p.kv_indptr[b + 1] - s0;
+    idx_row = p.kv_indices + s0;
+  } else {
+    pre_len = (int)p.seq_lens[b] - ext_len;
+    idx_row = p.req_to_token + p.req_pool_indices[b] * p.req_to_token_stride;
+  }
+  const int kh = h / p.group;
+  const int nvis = p.is_causal ? qi + 1 : ext_len;
+  const int total = pre_len + nvis;
+  const T* qrow = (const T*)p.q + (int64_t)tq * p.q_stride_t + (int64_t)h * d_qk;
+  float accv[4] = {0.f, 0.f, 0.f, 0.f};
+  float m_i = -INFINITY, l_i = 0.f;
+  for (int t0 = 0; t0 < total; t0 += 64) {
+    const int key = t0 + lane;
+    const bool valid = key < total;
+    const bool in_pre = key < pre_len;
+    const int id = valid ? (in_pre ? idx_row[key] : key - pre_len) : 0;
+    float sdot = 0.f;
+    if (valid) {
+      const T* krow = in_pre ? (const T*)p.k_buf + (int64_t)id * p.k_stride_t + (int64_t)kh * p.k_stride_h
+                             : (const T*)p.ke + (int64_t)(q0 + id) * p.ke_stride_t + (int64_t)kh * d_qk;
+      for (int d = 0; d < d_qk; ++d) sdot += (float)qrow[d] * (float)krow[d];
+    }
+    float xv = sdot * p.sm_scale;
+    xv = (p.logit_cap > 0.f) ? softcap2(xv, p.logit_cap) : xv * kLog2e;
+    xv = valid ? xv : -INFINITY;
+    const float m_new = fmaxf(m_i, wave_reduce_max(xv));
+    const float alpha = __builtin_amdgcn_exp2f(m_i - m_new);
+    const float pv = __builtin_amdgcn_exp2f(xv - m_new);
+    l_i = l_i * alpha + wave_reduce_sum(pv);
+    m_i = m_new;
+    __syncthreads();
+    p_lds[lane] = (float)(T)pv;
+    id_lds[lane] = valid ? (in_pre ? id : -(id + 1)) : 0;  // negative => row of v_extend
+    __syncthreads();
+    const int nt = min(64, total - t0);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int d = lane + 64 * c;
+      float av = accv[c] * alpha;
+      if (d < dv) {
+        for (int t = 0; t < nt; ++t) {
+          const int e = id_lds[t];
+          const T* vrow = e >= 0 && (t0 + t) < pre_len
+                              ? (const T*)p.v_buf + (int64_t)e * p.v_stride_t + (int64_t)kh * p.v_stride_h
+                              : (const T*)p.ve + (int64_t)(q0 + (-e - 1)) * p.ve_stride_t + (int64_t)kh * dv;
+          av += p_lds[t] * (float)vrow[d];
+        }
+      }
+      accv[c] = av;
+    }
+  }
+  T* orow = (T*)p.o + (int64_t)tq * p.o_stride_t + (int64_t)h * dv;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int d = lane + 64 * c;
+    if (d < dv) orow[d] = (T)(accv[c] / l_i);
+  }
+}
+
+template <typename T, int D>
+int launch_mfma(ExtendParams& p, int max_len_extend, hipStream_t st) {
+  constexpr int smem = 2 * 2 * kKT * D * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)extend_attn_kernel<T, D>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  // head slots per workgroup: smallest power of two >= min(group, 8); positions per workgroup = 128 / slots
+  int slots = 1;
+  while (slots < p.group && slots < 8) slots <<= 1;
+  int bq = 128 / slots, lg = 0;
+  while ((1 << lg) < bq) ++lg;
+  p.bq_log2 = lg;
+  p.hchunks = (p.group + 7) / 8;
+  p.nqb = (max_len_extend + bq - 1) / bq;
+  const int npairs = p.bs * p.hkv * p.hchunks;
+  const int64_t nblocks = (int64_t)((npairs + 7) / 8) * p.nqb * 8;
+  if (nblocks <= 0) return SGL_MI355_OK;
+  if (nblocks >= (1ll << 31)) {
+    snprintf(g_sgl_mi355_err, sizeof(g_sgl_mi355_err), "extend_attention: grid too large");
+    return SGL_MI355_EINVAL;
+  }
+  hipLaunchKernelGGL((extend_attn_kernel<T, D>), dim3((unsigned)nblocks), dim3(256), smem, st, p);
+  SGL_HIP_LAUNCH_CHECK();
+  return SGL_MI355_OK;
+}
+
+template <typename T>
+int launch_all(ExtendParams& p, int d_qk, int dv, int total_q, int max_len_extend, hipStream_t st) {
+  if (d_qk == dv && d_qk == 128) return launch_mfma<T, 128>(p, max_len_extend, st);
+  if (d_qk == dv && d_qk == 64) return launch_mfma<T, 64>(p, max_len_extend, st);
+  hipLaunchKernelGGL((extend_attn_generic<T>), dim3(total_q, p.hq), dim3(64), 0, st, p, d_qk, dv, total_q);
+  SGL_HIP_LAUNCH_CHECK();
+  return SGL_MI355_OK;
+}
+
+}  // namespace
+
+extern "C" int sgl_mi355_extend_attention(
+    const void* q_extend, const void* k_extend, const void* v_extend, void* o_extend, int64_t q_stride_t,
+    int64_t k_stride_t_ext, int64_t v_stride_t_ext, int64_t o_stride_t, const void* k_buffer, const void* v_buffer,
+    int64_t k_stride_t, int64_t k_stride_h, int64_t v_stride_t, int64_t v_stride_h, const int32_t* qo_indptr,
+    const int32_t* kv_indptr, const int32_t* kv_indices, const int32_t* req_to_token, int64_t req_to_token_stride,
+    const int64_t* req_pool_indices, const int64_t* seq_lens, const int32_t* extend_seq_lens,
+    const int32_t* extend_start_loc, int batch, int total_q_tokens, int max_len_extend, int num_q_heads,
+    int num_kv_heads, int head_dim, int v_head_dim, float sm_scale, float logit_cap, int is_causal, int dtype,
+    void* stream) {
+  SGL_CHECK(batch >= 0 && total_q_tokens >= 0, "extend_attention: negative sizes");
+  if (batch == 0 || total_q_tokens == 0 || max_len_extend <= 0) return SGL_MI355_OK;
+  SGL_CHECK(q_extend && k_extend && v_extend && o_extend, "extend_attention: null tensor pointer");
+  SGL_CHECK((qo_indptr && kv_indptr) || (req_to_token && req_pool_indices && seq_lens && extend_seq_lens && extend_start_loc),
+            "extend_attention: need (qo_indptr, kv_indptr, kv_indices) or (req_to_token, req_pool_indices, seq_lens, "
+            "extend_seq_lens, extend_start_loc)");
+  SGL_CHECK(num_kv_heads > 0 && num_q_heads % num_kv_heads == 0, "extend_attention: Hq=%d not a multiple of Hkv=%d",
+            num_q_heads, num_kv_heads);
+  SGL_CHECK(head_dim > 0 && head_dim <= 256 && v_head_dim > 0 && v_head_dim <= 256,
+            "extend_attention: head dims (%d, %d) outside (0, 256]", head_dim, v_head_dim);
+  SGL_CHECK(dtype == SGL_BF16 || dtype == SGL_F16, "extend_attention: dtype code %d unsupported (bf16=0, f16=1)", dtype);
+  if (head_dim == v_head_dim && (head_dim == 128 || head_dim == 64)) {
+    SGL_CHECK(q_stride_t % 8 == 0 && k_stride_t_ext % 8 == 0 && v_stride_t_ext % 8 == 0 && o_stride_t % 4 == 0 &&
+                  k_stride_t % 8 == 0 && v_stride_t % 8 == 0 && k_stride_h % 8 == 0 && v_stride_h % 8 == 0 &&
+                  ((uintptr_t)q_extend % 16) == 0 && ((uintptr_t)k_extend % 16) == 0 && ((uintptr_t)v_extend % 16) == 0 &&
+                  ((uintptr_t)o_extend % 8) == 0 && (!k_buffer || ((uintptr_t)k_buffer % 16) == 0) &&
+                  (!v_buffer || ((uintptr_t)v_buffer % 16) == 0),
+              "extend_attention: rows must be 16-byte aligned for the MFMA path");
+  }
+  ExtendParams p;
+  p.q = q_extend; p.ke = k_extend; p.ve = v_extend; p.o = o_extend;
+  p.q_stride_t = q_stride_t; p.ke_stride_t = k_stride_t_ext; p.ve_stride_t = v_stride_t_ext; p.o_stride_t = o_stride_t;
+  // with no prefix anywhere the pool may be absent: point at the extend tensors (never dereferenced for real rows)
+  p.k_buf = k_buffer ? k_buffer : k_extend; p.v_buf = v_buffer ? v_buffer : v_extend;
+  p.k_stride_t = k_stride_t; p.k_stride_h = k_stride_h; p.v_stride_t = v_stride_t; p.v_stride_h = v_stride_h;
+  p.qo_indptr = qo_indptr; p.kv_indptr = kv_indptr; p.kv_indices = kv_indices;
+  p.req_to_token = req_to_token; p.req_to_token_stride = req_to_token_stride; p.req_pool_indices = req_pool_indices;
+  p.seq_lens = seq_lens; p.extend_seq_lens = extend_seq_lens; p.extend_start_loc = extend_start_loc;
+  p.bs = batch; p.hq = num_q_heads; p.hkv = num_kv_heads; p.group = num_q_heads / num_kv_heads;
+  p.sm_scale = sm_scale; p.logit_cap = logit_cap; p.is_causal = is_causal;
+  p.nqb = 0; p.bq_log2 = 0; p.hchunks = 1;
+  hipStream_t st = (hipStream_t)stream;
+  return dtype == SGL_BF16 ? launch_all<__bf16>(p, head_dim, v_head_dim, total_q_tokens, max_len_extend, st)
+                           : launch_all<_Float16>(p, head_dim, v_head_dim, total_q_tokens, max_len_extend, st);
+}

@@ -74,3 +74,85 @@ def decode_attention_fwd(
             bs, hq, hkv, d, dv, float(sm_scale), float(logit_cap), dtype_code(q.dtype), current_stream(),
         )
     )
+
+
+def extend_attention_fwd(
+    q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr, kv_indptr, kv_indices, custom_mask,
+    is_causal, mask_indptr, max_len_extend, sm_scale=None, logit_cap=0.0, skip_prefix_custom_mask=True,
+    sliding_window_size=-1,
+) -> None:
+    """Same contract as extend_attention.py:306-438: q/o_extend [T, Hq, D], k/v_extend [T, Hkv, D] contiguous new
+    tokens, k/v_buffer the pool, kv_indices the cached prefix slots of each request."""
+    _require_cuda(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr, kv_indptr, kv_indices)
+    if custom_mask is not None:
+        raise RuntimeError("custom_mask (speculative decoding) is not supported by the MI355X extend kernel")
+    if sliding_window_size is not None and sliding_window_size > 0:
+        raise RuntimeError("sliding-window attention is not supported by the MI355X extend kernel")
+    t, hq, d = q_extend.shape
+    hkv, dv = v_extend.shape[1], v_extend.shape[2]
+    assert q_extend.stride(2) == 1 and q_extend.stride(1) == d and o_extend.stride(1) == dv
+    assert k_extend.stride(1) == d and v_extend.stride(1) == dv and k_extend.stride(2) == 1 and v_extend.stride(2) == 1
+    assert qo_indptr.dtype == torch.int32 and kv_indptr.dtype == torch.int32 and kv_indices.dtype == torch.int32
+    kst, ksh = _row_strides(k_buffer)
+    vst, vsh = _row_strides(v_buffer)
+    sm_scale = sm_scale or 1.0 / (d ** 0.5)
+    check(
+        lib.sgl_mi355_extend_attention(
+            ptr(q_extend), ptr(k_extend), ptr(v_extend), ptr(o_extend), q_extend.stride(0), k_extend.stride(0),
+            v_extend.stride(0), o_extend.stride(0), ptr(k_buffer), ptr(v_buffer), kst, ksh, vst, vsh, ptr(qo_indptr),
+            ptr(kv_indptr), ptr(kv_indices), None, 0, None, None, None, None, qo_indptr.numel() - 1, t,
+            int(max_len_extend), hq, hkv, d, dv, float(sm_scale), float(logit_cap), int(bool(is_causal)),
+            dtype_code(q_extend.dtype), current_stream(),
+        )
+    )
+
+
+def decode_attention(query, k_cache, v_cache, output, key, value, loc, attn_logits, req_to_token, req_pool_indices,
+                     seq_lens, sm_scale, logit_cap) -> None:
+    """Native-op form (decode_attention_cpu schema, torch_extension_cpu.cpp:264-268): writes (key, value) into the pool
+    at ``loc`` first (the fused decode_set_kv_buffer of decode.cpp:771), then attends through req_to_token directly.
+    attn_logits f32 [bs, Hq, num_kv_splits, Dv + 1] as in the reference (intel_amx_backend.py:36-45); the last column
+    of each split row holds the LSE."""
+    from .kvcache import set_kv_buffer
+
+    _require_cuda(query, k_cache, v_cache, output, key, value, loc, attn_logits, req_to_token, req_pool_indices, seq_lens)
+    bs, hq, d = query.shape
+    hkv, dv = v_cache.shape[1], v_cache.shape[2]
+    assert req_to_token.dtype == torch.int32 and req_pool_indices.dtype == torch.int64 and seq_lens.dtype == torch.int64
+    set_kv_buffer(k_cache, v_cache, loc.to(torch.int64), key, value)
+    splits = attn_logits.shape[2]
+    logits = torch.empty((bs, hq, splits, dv), dtype=torch.float32, device=query.device)
+    lse = torch.empty((bs, hq, splits), dtype=torch.float32, device=query.device)
+    nsplit = torch.full((bs,), splits, dtype=torch.int32, device=query.device)
+    kst, ksh = _row_strides(k_cache)
+    vst, vsh = _row_strides(v_cache)
+    check(
+        lib.sgl_mi355_decode_attention(
+            ptr(query), query.stride(0), ptr(k_cache), ptr(v_cache), kst, ksh, vst, vsh, ptr(output), output.stride(0),
+            None, None, ptr(req_to_token), req_to_token.stride(0), ptr(req_pool_indices), ptr(seq_lens), ptr(logits),
+            ptr(lse), ptr(nsplit), splits, bs, hq, hkv, d, dv, float(sm_scale), float(logit_cap), dtype_code(query.dtype),
+            current_stream(),
+        )
+    )
+
+
+def extend_attention(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, req_to_token, req_pool_indices, seq_lens,
+                     extend_seq_lens, extend_start_loc, max_len_extend, sm_scale, logit_cap) -> None:
+    """Native-op form (extend_attention_cpu schema, torch_extension_cpu.cpp:270-275): the prefix is addressed through
+    req_to_token[req_pool_indices[b], :seq_lens[b] - extend_seq_lens[b]]; causal."""
+    _require_cuda(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, req_to_token, req_pool_indices, seq_lens)
+    t, hq, d = q_extend.shape
+    hkv, dv = v_extend.shape[1], v_extend.shape[2]
+    assert req_to_token.dtype == torch.int32 and req_pool_indices.dtype == torch.int64 and seq_lens.dtype == torch.int64
+    assert extend_seq_lens.dtype == torch.int32 and extend_start_loc.dtype == torch.int32
+    kst, ksh = _row_strides(k_buffer)
+    vst, vsh = _row_strides(v_buffer)
+    check(
+        lib.sgl_mi355_extend_attention(
+            ptr(q_extend), ptr(k_extend), ptr(v_extend), ptr(o_extend), q_extend.stride(0), k_extend.stride(0),
+            v_extend.stride(0), o_extend.stride(0), ptr(k_buffer), ptr(v_buffer), kst, ksh, vst, vsh, None, None, None,
+            ptr(req_to_token), req_to_token.stride(0), ptr(req_pool_indices), ptr(seq_lens), ptr(extend_seq_lens),
+            ptr(extend_start_loc), seq_lens.numel(), t, int(max_len_extend), hq, hkv, d, dv, float(sm_scale),
+            float(logit_cap), 1, dtype_code(q_extend.dtype), current_stream(),
+        )
+    )
