@@ -1,0 +1,240 @@
+"""bench.py -- BASELINE.json metric on MI355X: decode tokens/s (+ prefill TFLOP/s) of Llama-3-8B fp8 (w8a8),
+batch 32 x seq 2048, synthetic random weights and token ids, every device op a hand-written HIP kernel.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one decode step of the whole model for the whole batch (32 new tokens).  Inputs (weights, the KV pool
+filled by a real prefill of 32 x 2048 tokens, index tensors) are resident in HBM before the timed region.
+Prints ONE JSON line (rank 0).  N > 1 shards the model tensor-parallel exactly like the reference
+(linear.py / llama.py:118-133) with one RCCL all-reduce per row-parallel layer: strong scaling of the same batch.
+
+Extra objects on the line:
+  roofline     dominant kernel = decode_attn_stage1 (KV stream).  achieved = algorithmic KV bytes of one launch
+               (bs * seq * Hkv * D * 2 B * 2) / mean launch duration measured here with HIP events on the launch stream.
+  cpu_baseline the oracle's torch-native restatement timed on this box's host cores on a bounded sample
+               (one of the 32 layers at the full batch 32 x 2048, extrapolated to the step) -- a baseline, not a target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--seq-len", type=int, default=2048)
+    ap.add_argument("--model", default="llama3-8b", choices=["llama3-8b", "llama3-70b", "qwen2-7b", "tiny"])
+    ap.add_argument("--quant", default="w8a8_fp8", choices=["w8a8_fp8", "fp8", "awq", "none"])
+    ap.add_argument("--layers", type=int, default=0, help="override layer count (debug only; invalidates the metric)")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prefill-chunk", type=int, default=8, help="requests per prefill call")
+    return ap.parse_args()
+
+
+def cpu_baseline_sample(cfg, batch, seq_len, layers):
+    """One decoder layer's hot path at the full batch on the host cores, with the oracle's restatements:
+    torch-native decode attention (per-request gather + SDPA) + the four w8a8 fp8 linears (reference test formula)."""
+    from oracle import attention as oa
+    from oracle import quant as oq
+
+    torch.set_num_threads(os.cpu_count())
+    g = torch.Generator().manual_seed(0)
+    hq, hkv, d, hid, inter = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim, cfg.hidden_size, cfg.intermediate_size
+    slots = batch * seq_len + 1
+    k_buf = torch.randn(slots, hkv, d, generator=g).bfloat16()
+    v_buf = torch.randn(slots, hkv, d, generator=g).bfloat16()
+    req_to_token = (torch.randperm(slots - 1, generator=g) + 1).int().view(batch, seq_len)
+    rpi = torch.arange(batch)
+    seq = torch.full((batch,), seq_len, dtype=torch.int64)
+    q = torch.randn(batch, hq, d, generator=g).bfloat16()
+    shapes = [(hq * d + 2 * hkv * d, hid), (hid, hq * d), (2 * inter, hid), (hid, inter)]
+    ws = []
+    for n, k in shapes:
+        w = (torch.randn(n, k, generator=g) * 0.02)
+        s = w.abs().amax(1, keepdim=True) / 448.0
+        ws.append(((w / s).to(torch.float8_e4m3fn), s.flatten()))
+    xs = [torch.randn(batch, k, generator=g).bfloat16() for _, k in shapes]
+
+    def layer_once():
+        oa.decode_attention_sdpa(q, k_buf, v_buf, req_to_token, rpi, seq, d ** -0.5)
+        for (wq, sw), x in zip(ws, xs):
+            xq, sx = oq.per_token_quant_fp8(x)
+            oq.scaled_mm(xq, wq.t(), sx.flatten(), sw, torch.bfloat16)
+
+    layer_once()
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        layer_once()
+        times.append(time.perf_counter() - t0)
+    t_layer = sorted(times)[1]
+    step = t_layer * layers
+    return {"value": batch / step, "unit": "tokens/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"1 of {layers} decoder layers (torch-native decode attention + 4 w8a8 linears) at batch {batch} x seq {seq_len}, "
+                      f"median of 3 = {t_layer:.3f} s, extrapolated x{layers}; lm_head/norms excluded"}
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+
+    from __graft_entry__ import load_package
+
+    load_package()
+    from ltp_sglang_amd.srt.distributed import communication_op as comm
+    from ltp_sglang_amd.srt.model_executor.synthetic_llama import LlamaShape, SyntheticModelRunner
+
+    comm.init_tensor_parallel()
+    cfg = {"llama3-8b": LlamaShape.llama3_8b, "llama3-70b": LlamaShape.llama3_70b, "qwen2-7b": LlamaShape.qwen2_7b,
+           "tiny": LlamaShape.tiny}[args.model]()
+    if args.layers:
+        cfg.num_hidden_layers = args.layers
+    quant = None if args.quant == "none" else args.quant
+    bs, seq = args.batch, args.seq_len
+    total_steps = args.steps + args.warmup + 4
+    runner = SyntheticModelRunner(cfg, quant, max_running_requests=bs, context_len=seq + total_steps + 8,
+                                  max_total_tokens=bs * (seq + total_steps) + 64, device=dev, seed=0)
+    tp = comm.get_tensor_model_parallel_world_size()
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- prefill: fills the KV pool (random token ids as bench_one_batch.py:215) and measures prefill TFLOP/s ----
+    import numpy as np
+
+    ids = torch.from_numpy(np.random.RandomState(0).randint(0, 10000, (bs, seq))).to(dev)
+    # the allocator hands out consecutive slots; a random permutation of the free list makes the gather non-contiguous
+    alloc = runner.token_to_kv_pool_allocator
+    gperm = torch.Generator(device=dev).manual_seed(1)
+    alloc.free_pages = alloc.free_pages[torch.randperm(alloc.free_pages.numel(), generator=gperm, device=dev)]
+    barrier()
+    t0 = time.perf_counter()
+    states, last_logits = [], []
+    for c0 in range(0, bs, args.prefill_chunk):
+        logits, st = runner.extend([ids[i] for i in range(c0, min(bs, c0 + args.prefill_chunk))])
+        states.append(st)
+        last_logits.append(logits)
+    barrier()
+    prefill_s = time.perf_counter() - t0
+    from types import SimpleNamespace
+
+    state = SimpleNamespace(req_pool_indices=torch.cat([s.req_pool_indices for s in states]),
+                            seq_lens=torch.cat([s.seq_lens for s in states]),
+                            seq_lens_cpu=sum([s.seq_lens_cpu for s in states], []))
+    L, hid, inter, V = cfg.num_hidden_layers, cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size
+    hq, hkv, d = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+    lin_params = L * ((hq * d + 2 * hkv * d) * hid + hq * d * hid + 3 * inter * hid)
+    prefill_flops = 2.0 * lin_params * bs * seq + L * bs * (4.0 * seq * seq * hq * d) / 2 + 2.0 * V * hid * bs
+    next_ids = K_argmax(torch.cat(last_logits))
+
+    # ---- decode: W warm-up + K timed steps ----
+    use_graph = not args.no_graph
+    if use_graph:
+        try:
+            runner.capture_decode_graph(bs)
+        except Exception as e:  # e.g. a collective that cannot be captured: measure eagerly instead
+            if rank == 0:
+                print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            use_graph = False
+    step_fn = runner.decode_graph if use_graph else runner.decode
+    for _ in range(args.warmup):
+        next_ids = K_argmax(step_fn(state, next_ids))
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        next_ids = K_argmax(step_fn(state, next_ids))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- dominant kernel: decode attention stage 1, HIP-event timed on the launch stream over all layers' pools ----
+    from ltp_sglang_amd import sgl_kernel as K
+
+    cur_seq = state.seq_lens_cpu[0]
+    md = runner.attn_backend.forward_metadata
+    hq_r, hkv_r = hq // tp, max(1, hkv // tp)
+    qd = torch.randn(bs, hq_r, d, device=dev).to(runner.dtype)
+    od = torch.empty_like(qd)
+    pool = runner.token_to_kv_pool
+    evs = []
+    for rep in range(3):
+        for l in range(L):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            K.decode_attention_fwd(qd, pool.get_key_buffer(l), pool.get_value_buffer(l), od, md.kv_indptr, md.kv_indices,
+                                   md.attn_logits, md.attn_lse, md.num_kv_splits, runner.attn_backend.max_kv_splits, d ** -0.5)
+            e1.record()
+            evs.append((e0, e1))
+    torch.cuda.synchronize()
+    attn_ms = sorted(a.elapsed_time(b) for a, b in evs[L:])  # first sweep = warm-up
+    attn_ms = sum(attn_ms) / len(attn_ms)
+    kv_bytes = float(sum(state.seq_lens_cpu)) * hkv_r * d * 2 * 2  # K and V rows of every cached token, bf16
+    achieved = kv_bytes / (attn_ms * 1e-3) / 1e9
+
+    if rank != 0:
+        return
+    tok_s = bs * args.steps / elapsed
+    weights_bytes = lin_params * (1 if quant in ("w8a8_fp8", "fp8") else (0.5 if quant == "awq" else 2)) + V * hid * 2
+    step_bytes = weights_bytes + bs * (seq + args.warmup + args.steps / 2) * L * 2 * hkv * d * 2
+    out = {
+        "metric": "decode tokens/sec (whole job) + prefill TFLOPS, Llama-3-8B fp8 batch=32 seq=2048",
+        "value": tok_s, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "fp8_e4m3 weights+activations (f32 accumulate), bf16 KV/attention" if quant in ("w8a8_fp8", "fp8") else str(quant or "bf16"),
+        "data": "synthetic",
+        "config": {"workload": f"{args.model} {args.quant} decode, batch {bs} x context {seq} (+{args.warmup}+{args.steps} steps), "
+                               f"KV pool filled by a real {bs}x{seq} prefill", "global_batch": bs, "seq_len": seq,
+                   "parallelism": f"tp{tp}", "hip_graph": bool(use_graph), "layers": L},
+        "prefill": {"tflops": prefill_flops / prefill_s / 1e12, "seconds": prefill_s, "tokens": bs * seq,
+                    "tokens_per_s": bs * seq / prefill_s, "flops": prefill_flops},
+        "step_roofline": {"algorithmic_bytes_per_step": step_bytes, "hbm_peak_GBps": 8000.0,
+                          "frac_of_hbm_roofline": step_bytes / (elapsed / args.steps) / (8e12 * world)},
+        "roofline": {"kernel": "decode_attn_stage1 (+stage2 merge)", "bound": "hbm", "achieved": achieved, "peak": 8000.0,
+                     "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                     "launch_us": attn_ms * 1e3, "algorithmic_bytes_per_launch": kv_bytes},
+    }
+    if not args.no_cpu_baseline and args.model != "tiny":
+        out["cpu_baseline"] = cpu_baseline_sample(cfg, bs, seq, L)
+    print(json.dumps(out))
+
+
+def K_argmax(logits):
+    from ltp_sglang_amd import sgl_kernel as K
+
+    return K.argmax(logits)
+
+
+if __name__ == "__main__":
+    main()

@@ -155,6 +155,10 @@ int sgl_mi355_embedding(void* out, const int64_t* ids, const void* table, int64_
 int sgl_mi355_argmax(int64_t* out, const void* logits, int64_t rows, int64_t vocab, int64_t row_stride, int dtype,
                      void* stream);
 
+/* out[cols, rows] = in[rows, cols]^T for 16-bit elements (weight re-layout between awq_dequantize's [K, N] and
+ * the [N, K] the GEMMs stream; AWQLinearMethod.apply, layers/quantization/awq.py:401-418) */
+int sgl_mi355_transpose_2d(void* out, const void* in, int rows, int cols, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -283,3 +283,30 @@ extern "C" int sgl_mi355_argmax(int64_t* out, const void* logits, int64_t rows, 
   SGL_HIP_LAUNCH_CHECK();
   return SGL_MI355_OK;
 }
+
+namespace {
+// out[c][r] = in[r][c] for 16-bit elements, 64x64 tiles through LDS (both sides coalesced).
+__global__ __launch_bounds__(256) void transpose16_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict__ in, int rows,
+                                                          int cols) {
+  __shared__ uint16_t tile[64][66];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4)
+    if (r0 + i < rows && c0 + tx < cols) tile[i][tx] = in[(int64_t)(r0 + i) * cols + c0 + tx];
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4)
+    if (c0 + i < cols && r0 + tx < rows) out[(int64_t)(c0 + i) * rows + r0 + tx] = tile[tx][i];
+}
+}  // namespace
+
+// out [cols, rows] = in[rows, cols]^T for bf16/f16 (weight re-layout for AWQLinearMethod: awq.py:401-418 multiplies
+// by the [K, N] dequantised weight, the GEMMs here stream W as [N, K]).
+extern "C" int sgl_mi355_transpose_2d(void* out, const void* in, int rows, int cols, void* stream) {
+  SGL_CHECK(rows >= 0 && cols >= 0, "transpose_2d: negative shape");
+  if (rows == 0 || cols == 0) return SGL_MI355_OK;
+  SGL_CHECK(out && in, "transpose_2d: null pointer");
+  hipLaunchKernelGGL(transpose16_kernel, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, (hipStream_t)stream,
+                     (uint16_t*)out, (const uint16_t*)in, rows, cols);
+  SGL_HIP_LAUNCH_CHECK();
+  return SGL_MI355_OK;
+}

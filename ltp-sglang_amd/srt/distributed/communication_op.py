@@ -1,0 +1,54 @@
+"""Tensor-parallel collectives at the reference's call sites.
+
+``tensor_model_parallel_all_reduce`` is called by RowParallelLinear.forward exactly where the reference calls it
+(python/sglang/srt/layers/linear.py:1302-1303 -> distributed/communication_op.py:11-13 ->
+GroupCoordinator.all_reduce, parallel_state.py:459-538).  The MI355X build routes it to RCCL over xGMI through
+torch.distributed (backend "nccl" is RCCL on ROCm); CPU tests use gloo.  One process per GPU; no other collective is
+added to the path: attention shards by head with no exchange.
+"""
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+_TP_GROUP: Optional[dist.ProcessGroup] = None
+_TP_SIZE = 1
+_TP_RANK = 0
+
+
+def init_tensor_parallel(group: Optional[dist.ProcessGroup] = None) -> None:
+    """Adopts an initialised torch.distributed group (default: WORLD) as the tensor-parallel group."""
+    global _TP_GROUP, _TP_SIZE, _TP_RANK
+    if not dist.is_initialized():
+        _TP_GROUP, _TP_SIZE, _TP_RANK = None, 1, 0
+        return
+    _TP_GROUP = group if group is not None else dist.group.WORLD
+    _TP_SIZE = dist.get_world_size(_TP_GROUP)
+    _TP_RANK = dist.get_rank(_TP_GROUP)
+
+
+def get_tensor_model_parallel_world_size() -> int:
+    return _TP_SIZE
+
+
+def get_tensor_model_parallel_rank() -> int:
+    return _TP_RANK
+
+
+def tensor_model_parallel_all_reduce(input_: torch.Tensor) -> torch.Tensor:
+    """In-place sum over the TP group (bypassed when tp == 1, parallel_state.py:466-468)."""
+    if _TP_SIZE == 1:
+        return input_
+    dist.all_reduce(input_, op=dist.ReduceOp.SUM, group=_TP_GROUP)
+    return input_
+
+
+def tensor_model_parallel_all_gather(input_: torch.Tensor, dim: int = -1) -> torch.Tensor:
+    """Concatenate shards along ``dim`` (logits all-gather, logits_processor.py:471-500)."""
+    if _TP_SIZE == 1:
+        return input_
+    if dim < 0:
+        dim += input_.dim()
+    parts = [torch.empty_like(input_) for _ in range(_TP_SIZE)]
+    dist.all_gather(parts, input_.contiguous(), group=_TP_GROUP)
+    return torch.cat(parts, dim=dim)

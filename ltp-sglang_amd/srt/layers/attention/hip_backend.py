@@ -1,0 +1,183 @@
+"""HipAttnBackend: the MI355X attention backend behind the reference's AttentionBackend plugin surface.
+
+Metadata semantics are those of the reference's GPU backend (TritonAttnBackend,
+python/sglang/srt/layers/attention/triton_backend.py:40-336,640-732): per batch it builds
+  decode : kv_indptr = cumsum(seq_lens), kv_indices = req_to_token rows, num_kv_splits, attn_logits / attn_lse scratch
+  extend : kv_indptr / kv_indices over the cached PREFIX, qo_indptr = cumsum(extend_seq_lens), max_extend_len
+and every forward writes the new K/V into the pool at out_cache_loc before attending (:647-650,706-709).
+All device work is hand-written HIP behind the C-ABI; the object reads exactly the model_runner fields listed in
+SURVEY.md 8b and is HIP-graph capturable (fixed-address metadata buffers, fill value 1: :338-630).
+"""
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from .... import sgl_kernel as K
+from ...._cabi import lib
+from .base_attn_backend import AttentionBackend
+
+
+@dataclass
+class ForwardMetadata:
+    attn_logits: Optional[torch.Tensor]
+    attn_lse: Optional[torch.Tensor]
+    max_extend_len: Optional[int]
+    num_kv_splits: Optional[torch.Tensor]
+    kv_indptr: torch.Tensor
+    kv_indices: torch.Tensor
+    qo_indptr: Optional[torch.Tensor]
+    custom_mask: Optional[torch.Tensor] = None
+    mask_indptr: Optional[torch.Tensor] = None
+
+
+def _rows(t):
+    """[T, H, D] view whose heads are contiguous (a qkv split view qualifies); copy only if it is not."""
+    return t if (t.stride(2) == 1 and t.stride(1) == t.shape[2]) else t.contiguous()
+
+
+def default_max_kv_splits() -> int:
+    """The reference forces 16 on HIP (server_args.py:454-456; 8 elsewhere, :238)."""
+    return 16
+
+
+class HipAttnBackend(AttentionBackend):
+    def __init__(self, model_runner, skip_prefill: bool = False, kv_indptr_buf: Optional[torch.Tensor] = None):
+        super().__init__()
+        self.device = model_runner.device
+        max_bs = model_runner.req_to_token_pool.size
+        self.req_to_token = model_runner.req_to_token_pool.req_to_token
+        self.kv_indptr = (
+            torch.zeros((max_bs + 1,), dtype=torch.int32, device=self.device) if kv_indptr_buf is None else kv_indptr_buf
+        )
+        self.skip_prefill = skip_prefill
+        if not skip_prefill:
+            self.qo_indptr = torch.zeros((max_bs + 1,), dtype=torch.int32, device=self.device)
+        if getattr(model_runner, "sliding_window_size", None):
+            raise RuntimeError("HipAttnBackend: sliding-window models are outside this build's hot path")
+        cfg = model_runner.model_config
+        tp = getattr(model_runner, "attention_tp_size", 1)
+        self.num_head = cfg.num_attention_heads // tp
+        self.num_kv_head = cfg.get_num_kv_heads(tp)
+        args = getattr(model_runner, "server_args", None)
+        self.max_kv_splits = getattr(args, "triton_attention_num_kv_splits", None) or default_max_kv_splits()
+        self.static_kv_splits = bool(getattr(args, "static_kv_splits", False))
+        self.v_head_dim = model_runner.token_to_kv_pool.get_value_buffer(0).shape[-1]
+        self.max_context_len = cfg.context_len
+        gpu_id = getattr(model_runner, "gpu_id", 0)
+        self.device_core_count = lib.sgl_mi355_device_cu_count(int(gpu_id))  # 256 on MI355X
+        self.forward_metadata: Optional[ForwardMetadata] = None
+        self._graph = None
+
+    # ------------------------------------------------------------------ metadata
+    def _decode_metadata(self, bs, req_pool_indices, seq_lens, seq_lens_sum, kv_indices=None, scratch=None):
+        kv_indptr = self.kv_indptr[: bs + 1]
+        if scratch is None:
+            num_kv_splits = torch.empty((bs,), dtype=torch.int32, device=self.device)
+            attn_logits = torch.empty((bs, self.num_head, self.max_kv_splits, self.v_head_dim), dtype=torch.float32, device=self.device)
+            attn_lse = torch.empty((bs, self.num_head, self.max_kv_splits), dtype=torch.float32, device=self.device)
+        else:
+            num_kv_splits, attn_logits, attn_lse = scratch
+        # one launch: kv_indptr[1:bs+1] = cumsum(seq_lens) and the per-request split heuristic
+        K.decode_metadata(kv_indptr, num_kv_splits, seq_lens, 1, self.num_head, self.num_kv_head, self.max_kv_splits,
+                          self.device_core_count, self.static_kv_splits)
+        if kv_indices is None:
+            kv_indices = torch.empty(seq_lens_sum, dtype=torch.int32, device=self.device)
+        K.create_kv_indices(self.req_to_token, req_pool_indices, seq_lens, kv_indptr, None, kv_indices)
+        return ForwardMetadata(attn_logits, attn_lse, None, num_kv_splits, kv_indptr, kv_indices, None)
+
+    def init_forward_metadata(self, forward_batch):
+        bs = forward_batch.batch_size
+        if forward_batch.spec_info is not None:
+            raise RuntimeError("HipAttnBackend: speculative decoding is outside this build's hot path")
+        if forward_batch.forward_mode.is_decode_or_idle():
+            self.forward_metadata = self._decode_metadata(bs, forward_batch.req_pool_indices, forward_batch.seq_lens,
+                                                          forward_batch.seq_lens_sum)
+            return
+        # extend: indices over the cached prefix only; the new tokens are read from k/v directly
+        kv_indptr = self.kv_indptr[: bs + 1]
+        K.decode_metadata(kv_indptr, None, forward_batch.extend_prefix_lens, 1, self.num_head, self.num_kv_head,
+                          self.max_kv_splits, self.device_core_count)
+        pre_cpu = forward_batch.extend_prefix_lens_cpu
+        prefix_sum = int(sum(pre_cpu)) if pre_cpu is not None else int(forward_batch.extend_prefix_lens.sum().item())
+        kv_indices = torch.empty(prefix_sum, dtype=torch.int32, device=self.device)
+        K.create_kv_indices(self.req_to_token, forward_batch.req_pool_indices, forward_batch.extend_prefix_lens, kv_indptr,
+                            None, kv_indices)
+        qo_indptr = self.qo_indptr[: bs + 1]
+        K.decode_metadata(qo_indptr, None, forward_batch.extend_seq_lens, 1, self.num_head, self.num_kv_head,
+                          self.max_kv_splits, self.device_core_count)
+        ext_cpu = forward_batch.extend_seq_lens_cpu
+        max_extend_len = int(max(ext_cpu)) if ext_cpu is not None else int(forward_batch.extend_seq_lens.max().item())
+        self.forward_metadata = ForwardMetadata(None, None, max_extend_len, None, kv_indptr, kv_indices, qo_indptr)
+
+    # ------------------------------------------------------------------ HIP-graph hooks
+    def init_cuda_graph_state(self, max_bs: int, max_num_tokens: int, kv_indices_buf: Optional[torch.Tensor] = None):
+        self._graph = dict(
+            kv_indices=(torch.zeros((max_num_tokens * self.max_context_len,), dtype=torch.int32, device=self.device)
+                        if kv_indices_buf is None else kv_indices_buf),
+            attn_logits=torch.zeros((max_num_tokens, self.num_head, self.max_kv_splits, self.v_head_dim), dtype=torch.float32, device=self.device),
+            attn_lse=torch.zeros((max_num_tokens, self.num_head, self.max_kv_splits), dtype=torch.float32, device=self.device),
+            num_kv_splits=torch.full((max_num_tokens,), self.max_kv_splits, dtype=torch.int32, device=self.device),
+        )
+
+    def init_forward_metadata_capture_cuda_graph(self, bs, num_tokens, req_pool_indices, seq_lens, encoder_lens,
+                                                 forward_mode, spec_info):
+        if not forward_mode.is_decode_or_idle() or spec_info is not None:
+            raise ValueError(f"Invalid forward mode: {forward_mode=} for HIP graph capture.")
+        g = self._graph
+        scratch = (g["num_kv_splits"][:bs], g["attn_logits"][:bs], g["attn_lse"][:bs])
+        self.forward_metadata = self._decode_metadata(bs, req_pool_indices, seq_lens, 0, g["kv_indices"], scratch)
+
+    def init_forward_metadata_replay_cuda_graph(self, bs, req_pool_indices, seq_lens, seq_lens_sum, encoder_lens,
+                                                forward_mode, spec_info, seq_lens_cpu):
+        if not forward_mode.is_decode_or_idle() or spec_info is not None:
+            raise ValueError(f"Invalid forward mode: {forward_mode=} for HIP graph replay.")
+        g = self._graph
+        scratch = (g["num_kv_splits"][:bs], g["attn_logits"][:bs], g["attn_lse"][:bs])
+        self.forward_metadata = self._decode_metadata(bs, req_pool_indices[:bs], seq_lens[:bs], seq_lens_sum,
+                                                      g["kv_indices"], scratch)
+
+    def get_cuda_graph_seq_len_fill_value(self):
+        return 1
+
+    # ------------------------------------------------------------------ forwards
+    @staticmethod
+    def _check_layer(layer):
+        if layer.sliding_window_size is not None and layer.sliding_window_size > -1:
+            raise RuntimeError("HipAttnBackend: sliding-window layers are outside this build's hot path")
+
+    def forward_extend(self, q, k, v, layer, forward_batch, save_kv_cache=True):
+        self._check_layer(layer)
+        o = q.new_empty((q.shape[0], layer.tp_q_head_num * layer.v_head_dim))
+        if save_kv_cache:
+            forward_batch.token_to_kv_pool.set_kv_buffer(layer, forward_batch.out_cache_loc, k, v)
+        md = self.forward_metadata
+        causal = not (layer.is_cross_attention or getattr(layer.attn_type, "value", "decoder") == "encoder_only")
+        K.extend_attention_fwd(
+            q.view(-1, layer.tp_q_head_num, layer.qk_head_dim), _rows(k), _rows(v),
+            o.view(-1, layer.tp_q_head_num, layer.v_head_dim),
+            forward_batch.token_to_kv_pool.get_key_buffer(layer.layer_id),
+            forward_batch.token_to_kv_pool.get_value_buffer(layer.layer_id),
+            md.qo_indptr, md.kv_indptr, md.kv_indices, None, causal, None, md.max_extend_len, layer.scaling, layer.logit_cap,
+        )
+        return o
+
+    def forward_decode(self, q, k, v, layer, forward_batch, save_kv_cache=True):
+        self._check_layer(layer)
+        q = q.reshape(-1, layer.tp_q_head_num * layer.qk_head_dim)
+        o = q.new_empty((q.shape[0], layer.tp_q_head_num * layer.v_head_dim))
+        if save_kv_cache:  # decode reads the new token from the pool, so this must precede the attention launch
+            forward_batch.token_to_kv_pool.set_kv_buffer(layer, forward_batch.out_cache_loc, k, v)
+        md = self.forward_metadata
+        K.decode_attention_fwd(
+            q.view(-1, layer.tp_q_head_num, layer.qk_head_dim),
+            forward_batch.token_to_kv_pool.get_key_buffer(layer.layer_id),
+            forward_batch.token_to_kv_pool.get_value_buffer(layer.layer_id),
+            o.view(-1, layer.tp_q_head_num, layer.v_head_dim),
+            md.kv_indptr, md.kv_indices, md.attn_logits, md.attn_lse, md.num_kv_splits, self.max_kv_splits,
+            layer.scaling, layer.logit_cap,
+        )
+        return o
+
+    def support_triton(self):
+        return False  # the host helpers use this build's HIP index kernels, never Triton

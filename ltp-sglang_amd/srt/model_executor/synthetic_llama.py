@@ -1,0 +1,333 @@
+"""Llama-shaped synthetic stack + a ModelRunner-shaped harness around the hot path.
+
+This is the CALLER side of the path (python/sglang/srt/models/llama.py:94-98,118-191,245-268,308-340 and the
+``bench_one_batch`` flow, python/sglang/bench_one_batch.py:214-269): random-weight layers of the Llama / Qwen2
+architecture whose every device op is one of this build's HIP kernels, the reference's own pools and allocator
+contracts, and the extend / decode drivers that build ForwardBatch objects the way ScheduleBatch.prepare_for_extend /
+prepare_for_decode do (schedule_batch.py:1123-1310,1520-1590).  No checkpoint loading, tokenizer or scheduler: the
+north star measures synthetic random-weight batches.
+"""
+from dataclasses import dataclass
+from types import SimpleNamespace
+from typing import List, Optional
+
+import torch
+from torch import nn
+
+from ... import sgl_kernel as K
+from ..distributed.communication_op import get_tensor_model_parallel_rank, get_tensor_model_parallel_world_size
+from ..layers.activation import SiluAndMul
+from ..layers.attention.hip_backend import HipAttnBackend
+from ..layers.layernorm import RMSNorm
+from ..layers.linear import MergedColumnParallelLinear, QKVParallelLinear, RowParallelLinear
+from ..layers.quantization import get_quantization_config
+from ..layers.quantization.w8a8_fp8 import per_channel_quant_fp8
+from ..layers.radix_attention import RadixAttention
+from ..layers.rotary_embedding import get_rope
+from ..mem_cache.allocator import TokenToKVPoolAllocator
+from ..mem_cache.memory_pool import MHATokenToKVPool, ReqToTokenPool
+from .forward_batch_info import ForwardBatch, ForwardMode
+
+
+@dataclass
+class LlamaShape:
+    hidden_size: int = 4096
+    num_attention_heads: int = 32
+    num_key_value_heads: int = 8
+    head_dim: int = 128
+    num_hidden_layers: int = 32
+    intermediate_size: int = 14336
+    vocab_size: int = 128256
+    rms_norm_eps: float = 1e-5
+    rope_theta: float = 500000.0
+    max_position_embeddings: int = 8192
+    attention_bias: bool = False  # Qwen2 sets True (qkv bias)
+
+    @staticmethod
+    def llama3_8b():
+        return LlamaShape()
+
+    @staticmethod
+    def llama3_70b():
+        return LlamaShape(hidden_size=8192, num_attention_heads=64, num_key_value_heads=8, num_hidden_layers=80,
+                          intermediate_size=28672)
+
+    @staticmethod
+    def qwen2_7b():
+        return LlamaShape(hidden_size=3584, num_attention_heads=28, num_key_value_heads=4, num_hidden_layers=28,
+                          intermediate_size=18944, vocab_size=152064, rms_norm_eps=1e-6, rope_theta=1e6,
+                          max_position_embeddings=32768, attention_bias=True)
+
+    @staticmethod
+    def tiny(layers=2):
+        return LlamaShape(hidden_size=512, num_attention_heads=8, num_key_value_heads=2, head_dim=64,
+                          num_hidden_layers=layers, intermediate_size=1024, vocab_size=2048, max_position_embeddings=1024)
+
+
+class LlamaMLP(nn.Module):
+    def __init__(self, cfg: LlamaShape, quant_config, dtype, prefix=""):
+        super().__init__()
+        self.gate_up_proj = MergedColumnParallelLinear(cfg.hidden_size, [cfg.intermediate_size] * 2, bias=False,
+                                                       quant_config=quant_config, params_dtype=dtype, prefix=f"{prefix}.gate_up_proj")
+        self.down_proj = RowParallelLinear(cfg.intermediate_size, cfg.hidden_size, bias=False, quant_config=quant_config,
+                                           params_dtype=dtype, prefix=f"{prefix}.down_proj")
+        self.act_fn = SiluAndMul()
+
+    def forward(self, x):
+        gate_up, _ = self.gate_up_proj(x)
+        x, _ = self.down_proj(self.act_fn(gate_up))
+        return x
+
+
+class LlamaAttention(nn.Module):
+    def __init__(self, cfg: LlamaShape, layer_id: int, quant_config, dtype, prefix=""):
+        super().__init__()
+        tp = get_tensor_model_parallel_world_size()
+        self.num_heads = cfg.num_attention_heads // tp
+        self.num_kv_heads = max(1, cfg.num_key_value_heads // tp)
+        self.head_dim = cfg.head_dim
+        self.q_size = self.num_heads * self.head_dim
+        self.kv_size = self.num_kv_heads * self.head_dim
+        self.qkv_proj = QKVParallelLinear(cfg.hidden_size, self.head_dim, cfg.num_attention_heads, cfg.num_key_value_heads,
+                                          bias=cfg.attention_bias, quant_config=quant_config, params_dtype=dtype,
+                                          prefix=f"{prefix}.qkv_proj")
+        self.o_proj = RowParallelLinear(cfg.num_attention_heads * self.head_dim, cfg.hidden_size, bias=False,
+                                        quant_config=quant_config, params_dtype=dtype, prefix=f"{prefix}.o_proj")
+        self.rotary_emb = get_rope(self.head_dim, self.head_dim, cfg.max_position_embeddings, cfg.rope_theta, True, dtype=dtype)
+        self.attn = RadixAttention(self.num_heads, self.head_dim, self.head_dim ** -0.5, self.num_kv_heads, layer_id)
+
+    def forward(self, positions, hidden_states, forward_batch):
+        qkv, _ = self.qkv_proj(hidden_states)
+        q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
+        q, k = self.rotary_emb(positions, q, k)
+        attn_output = self.attn(q, k, v, forward_batch)
+        output, _ = self.o_proj(attn_output)
+        return output
+
+
+class LlamaDecoderLayer(nn.Module):
+    def __init__(self, cfg: LlamaShape, layer_id: int, quant_config, dtype):
+        super().__init__()
+        self.self_attn = LlamaAttention(cfg, layer_id, quant_config, dtype, prefix=f"layers.{layer_id}.self_attn")
+        self.mlp = LlamaMLP(cfg, quant_config, dtype, prefix=f"layers.{layer_id}.mlp")
+        self.input_layernorm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps, dtype)
+        self.post_attention_layernorm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps, dtype)
+
+    def forward(self, positions, hidden_states, forward_batch, residual):
+        if residual is None:
+            residual = hidden_states
+            hidden_states = self.input_layernorm(hidden_states)
+        else:
+            hidden_states, residual = self.input_layernorm(hidden_states, residual)
+        hidden_states = self.self_attn(positions, hidden_states, forward_batch)
+        hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
+        hidden_states = self.mlp(hidden_states)
+        return hidden_states, residual
+
+
+class LlamaForCausalLM(nn.Module):
+    """embed -> L x decoder layer -> norm -> lm_head (last token of each request) -> logits."""
+
+    def __init__(self, cfg: LlamaShape, quantization: Optional[str], dtype=torch.bfloat16):
+        super().__init__()
+        self.cfg, self.dtype = cfg, dtype
+        qc = None
+        if quantization is not None:
+            cls = get_quantization_config(quantization)
+            qc = cls(4, 128, True) if quantization == "awq" else cls()
+        self.quant_config = qc
+        self.embed_tokens = nn.Parameter(torch.empty(cfg.vocab_size, cfg.hidden_size, dtype=dtype), requires_grad=False)
+        self.layers = nn.ModuleList([LlamaDecoderLayer(cfg, i, qc, dtype) for i in range(cfg.num_hidden_layers)])
+        self.norm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps, dtype)
+        # lm_head is vocab-sharded over TP ranks and the logits all-gathered (logits_processor.py:471-500);
+        # the embedding table is replicated (a row gather needs no collective)
+        self.tp_size, self.tp_rank = get_tensor_model_parallel_world_size(), get_tensor_model_parallel_rank()
+        assert cfg.vocab_size % self.tp_size == 0
+        self.lm_head = nn.Parameter(torch.empty(cfg.vocab_size // self.tp_size, cfg.hidden_size, dtype=dtype), requires_grad=False)
+
+    @torch.no_grad()
+    def init_random_weights(self, seed: int = 0, std: float = 0.02):
+        """bf16 N(0, std) weights, then each linear's own process_weights_after_loading (fp8 per-channel quantiser:
+        w8a8_fp8.py:119-126; AWQ: random int32 packs + U(0,1)*0.01 scales as test_awq_dequant.py:71-100)."""
+        dev = self.embed_tokens.device
+        g = torch.Generator(device=dev).manual_seed(seed)
+
+        def randn(shape, s=std):
+            return (torch.randn(shape, generator=g, device=dev, dtype=torch.float32) * s).to(self.dtype)
+
+        self.embed_tokens.copy_(randn(self.embed_tokens.shape, 1.0))
+        vs = self.cfg.vocab_size // self.tp_size
+        self.lm_head.copy_(randn((self.cfg.vocab_size, self.cfg.hidden_size))[self.tp_rank * vs : (self.tp_rank + 1) * vs])
+        for mod in self.modules():
+            if isinstance(mod, RMSNorm):
+                mod.weight.copy_((1.0 + 0.1 * torch.randn(mod.weight.shape, generator=g, device=dev)).to(self.dtype))
+            qm = getattr(mod, "quant_method", None)
+            if qm is None or not hasattr(mod, "input_size"):
+                continue
+            if hasattr(mod, "qweight"):  # AWQ
+                mod.qweight.copy_(torch.randint(0, 2**31 - 1, mod.qweight.shape, generator=g, device=dev, dtype=torch.int32))
+                mod.qzeros.copy_(torch.randint(0, 2**31 - 1, mod.qzeros.shape, generator=g, device=dev, dtype=torch.int32))
+                mod.scales.copy_((torch.rand(mod.scales.shape, generator=g, device=dev) * 0.01 * 0.3).to(self.dtype))
+            elif hasattr(mod, "shard_cols"):  # row parallel: every rank draws the full matrix and keeps its K slice
+                mod.weight.copy_(mod.shard_cols(randn((mod.output_size, mod.input_size))))
+            else:                             # column parallel (incl. merged / qkv): keep this rank's rows
+                full_rows = (mod.total_num_heads + 2 * mod.total_num_kv_heads) * mod.head_size if hasattr(mod, "total_num_heads") else mod.output_size
+                mod.weight.copy_(mod.shard_rows(randn((full_rows, mod.input_size))))
+            if getattr(mod, "bias", None) is not None:
+                if hasattr(mod, "shard_rows"):
+                    full_rows = (mod.total_num_heads + 2 * mod.total_num_kv_heads) * mod.head_size if hasattr(mod, "total_num_heads") else mod.output_size
+                    mod.bias.copy_(mod.shard_rows(randn((full_rows,))))
+                else:
+                    mod.bias.copy_(randn(mod.bias.shape))
+            qm.process_weights_after_loading(mod)
+
+    def forward(self, input_ids, positions, forward_batch: ForwardBatch, last_index: Optional[torch.Tensor] = None):
+        hidden_states = K.embedding(input_ids, self.embed_tokens)
+        residual = None
+        for layer in self.layers:
+            hidden_states, residual = layer(positions, hidden_states, forward_batch, residual)
+        hidden_states, _ = self.norm(hidden_states, residual)
+        if last_index is not None:  # extend: logits of the last token of each request only (logits_processor.py)
+            hidden_states = hidden_states.index_select(0, last_index)
+        logits = K.dense_linear(hidden_states, self.lm_head, None, out_dtype=self.dtype)
+        if self.tp_size > 1:
+            from ..distributed.communication_op import tensor_model_parallel_all_gather
+
+            logits = tensor_model_parallel_all_gather(logits)
+        return logits
+
+
+class SyntheticModelRunner:
+    """Owns the pools, allocator, backend and model; exposes the attributes an attention backend reads from a
+    ModelRunner and the extend()/decode() drivers of bench_one_batch."""
+
+    def __init__(self, cfg: LlamaShape, quantization: Optional[str], max_running_requests: int, context_len: int,
+                 max_total_tokens: int, device: str = "cuda:0", dtype=torch.bfloat16, seed: int = 0,
+                 kv_cache_dtype: Optional[torch.dtype] = None):
+        self.device = device
+        self.gpu_id = torch.device(device).index or 0
+        self.dtype = dtype
+        self.cfg = cfg
+        tp = get_tensor_model_parallel_world_size()
+        self.attention_tp_size = tp
+        self.tp_rank = get_tensor_model_parallel_rank()
+        kv_heads = max(1, cfg.num_key_value_heads // tp)
+        self.model_config = SimpleNamespace(
+            num_attention_heads=cfg.num_attention_heads, context_len=context_len, is_encoder_decoder=False,
+            get_num_kv_heads=lambda tp_size: max(1, cfg.num_key_value_heads // tp_size), hidden_size=cfg.hidden_size,
+            vocab_size=cfg.vocab_size, num_hidden_layers=cfg.num_hidden_layers, head_dim=cfg.head_dim,
+        )
+        self.sliding_window_size = None
+        self.server_args = SimpleNamespace(triton_attention_num_kv_splits=16, speculative_num_draft_tokens=None,
+                                           speculative_num_steps=None, page_size=1)
+        self.page_size = 1
+        self.req_to_token_pool = ReqToTokenPool(max_running_requests, context_len, device)
+        self.token_to_kv_pool = MHATokenToKVPool(max_total_tokens, 1, kv_cache_dtype or dtype, kv_heads, cfg.head_dim,
+                                                 cfg.num_hidden_layers, device)
+        self.token_to_kv_pool_allocator = TokenToKVPoolAllocator(max_total_tokens, kv_cache_dtype or dtype, device, self.token_to_kv_pool)
+        with torch.device(device):
+            self.model = LlamaForCausalLM(cfg, quantization, dtype)
+        self.model.init_random_weights(seed)
+        self.attn_backend = HipAttnBackend(self)
+        self._graphs = {}
+
+    # ---- bench_one_batch-style drivers -------------------------------------------------------------------
+    def clear(self):
+        self.req_to_token_pool.clear()
+        self.token_to_kv_pool_allocator.clear()
+
+    @torch.no_grad()
+    def extend(self, input_ids: List[torch.Tensor], prefix_indices: Optional[List[torch.Tensor]] = None):
+        """Prefill a batch: allocates request rows and KV slots, writes req_to_token, runs the model.
+        Returns (next-token logits [bs, vocab], batch state for decode)."""
+        bs = len(input_ids)
+        dev = self.device
+        req_pool_indices = torch.tensor(self.req_to_token_pool.alloc(bs), dtype=torch.int64, device=dev)
+        pre = [0 if prefix_indices is None else int(prefix_indices[i].numel()) for i in range(bs)]
+        ext = [int(x.numel()) for x in input_ids]
+        seq = [p + e for p, e in zip(pre, ext)]
+        out_cache_loc = self.token_to_kv_pool_allocator.alloc(sum(ext))
+        if out_cache_loc is None:
+            raise RuntimeError("Prefill out of memory. Try to lower your batch size.")
+        pre_t = torch.tensor(pre, dtype=torch.int64, device=dev)
+        ext_t = torch.tensor(ext, dtype=torch.int64, device=dev)
+        seq_t = torch.tensor(seq, dtype=torch.int64, device=dev)
+        if prefix_indices is not None:
+            for i in range(bs):
+                if pre[i]:
+                    self.req_to_token_pool.write((req_pool_indices[i], slice(0, pre[i])), prefix_indices[i].to(torch.int32))
+        K.write_req_to_token(self.req_to_token_pool.req_to_token, req_pool_indices, pre_t, seq_t, ext_t, out_cache_loc)
+        ids = torch.cat(input_ids).to(dev)
+        fb = ForwardBatch.init_new(ForwardMode.EXTEND, req_pool_indices, seq_t, out_cache_loc, ids, self.req_to_token_pool,
+                                   self.token_to_kv_pool, self.attn_backend, extend_prefix_lens=pre_t, extend_seq_lens=ext_t,
+                                   seq_lens_cpu=torch.tensor(seq, dtype=torch.int64))
+        self.attn_backend.init_forward_metadata(fb)
+        last_index = torch.cumsum(ext_t, 0) - 1
+        logits = self.model(ids, fb.positions, fb, last_index)
+        state = SimpleNamespace(req_pool_indices=req_pool_indices, seq_lens=seq_t, seq_lens_cpu=list(seq))
+        return logits, state
+
+    def _prepare_decode(self, state, next_ids):
+        """seq_lens += 1, one new slot per request, req_to_token[idx, seq_len - 1] = slot (schedule_batch.py:1560-1590)."""
+        bs = len(state.seq_lens_cpu)
+        out_cache_loc = self.token_to_kv_pool_allocator.alloc(bs)
+        if out_cache_loc is None:
+            raise RuntimeError("Decode out of memory. Try to lower your batch size.")
+        locs = state.seq_lens.clone()
+        state.seq_lens = state.seq_lens + 1
+        state.seq_lens_cpu = [s + 1 for s in state.seq_lens_cpu]
+        self.req_to_token_pool.write((state.req_pool_indices, locs), out_cache_loc.to(torch.int32))
+        return ForwardBatch.init_new(ForwardMode.DECODE, state.req_pool_indices, state.seq_lens, out_cache_loc, next_ids,
+                                     self.req_to_token_pool, self.token_to_kv_pool, self.attn_backend,
+                                     seq_lens_cpu=torch.tensor(state.seq_lens_cpu, dtype=torch.int64))
+
+    @torch.no_grad()
+    def decode(self, state, next_ids: torch.Tensor):
+        fb = self._prepare_decode(state, next_ids)
+        self.attn_backend.init_forward_metadata(fb)
+        return self.model(next_ids, fb.positions, fb)
+
+    # ---- HIP-graph decode (cuda_graph_runner.py:280,618,760 hooks) ------------------------------------------
+    @torch.no_grad()
+    def capture_decode_graph(self, bs: int):
+        dev = self.device
+        if self.attn_backend._graph is None:
+            self.attn_backend.init_cuda_graph_state(bs, bs)
+        buf = SimpleNamespace(
+            input_ids=torch.zeros(bs, dtype=torch.int64, device=dev),
+            req_pool_indices=torch.zeros(bs, dtype=torch.int64, device=dev),
+            seq_lens=torch.full((bs,), 1, dtype=torch.int64, device=dev),
+            out_cache_loc=torch.zeros(bs, dtype=torch.int64, device=dev),
+            positions=torch.zeros(bs, dtype=torch.int64, device=dev),
+        )
+        fb = ForwardBatch(forward_mode=ForwardMode.DECODE, batch_size=bs, input_ids=buf.input_ids,
+                          req_pool_indices=buf.req_pool_indices, seq_lens=buf.seq_lens, out_cache_loc=buf.out_cache_loc,
+                          seq_lens_sum=bs, positions=buf.positions, req_to_token_pool=self.req_to_token_pool,
+                          token_to_kv_pool=self.token_to_kv_pool, attn_backend=self.attn_backend)
+        self.attn_backend.init_forward_metadata_capture_cuda_graph(bs, bs, buf.req_pool_indices, buf.seq_lens, None,
+                                                                   ForwardMode.DECODE, None)
+        stream = torch.cuda.Stream()
+        stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(stream):
+            for _ in range(2):  # warm-up outside capture (first-launch attribute calls, allocator pools)
+                self.model(buf.input_ids, buf.positions, fb)
+        torch.cuda.current_stream().wait_stream(stream)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            buf.logits = self.model(buf.input_ids, buf.positions, fb)
+        self._graphs[bs] = (graph, buf)
+
+    @torch.no_grad()
+    def decode_graph(self, state, next_ids: torch.Tensor):
+        bs = len(state.seq_lens_cpu)
+        graph, buf = self._graphs[bs]
+        fb = self._prepare_decode(state, next_ids)
+        buf.input_ids.copy_(next_ids)
+        buf.req_pool_indices.copy_(fb.req_pool_indices)
+        buf.seq_lens.copy_(fb.seq_lens)
+        buf.out_cache_loc.copy_(fb.out_cache_loc)
+        buf.positions.copy_(fb.positions)
+        self.attn_backend.init_forward_metadata_replay_cuda_graph(bs, buf.req_pool_indices, buf.seq_lens, fb.seq_lens_sum,
+                                                                  None, ForwardMode.DECODE, None, fb.seq_lens_cpu)
+        graph.replay()
+        return buf.logits
