@@ -117,11 +117,17 @@ int sgl_mi355_per_token_group_quant_fp8(const void* input, void* output_q, float
 /* Weight-streaming GEMM for M <= 64: Y = (X . W^T) * scales_x[m] * scales_w[n] + bias[n].
  * in_dtype fp8: fp8_scaled_mm (sgl-kernel/csrc/gemm/fp8_gemm_kernel.cu:1071-1146, python gemm.py:34-42) with
  * W = mat_b^T stored [N, K] row-major; in_dtype bf16/f16 with NULL scales: the unquantised linear
- * (python/sglang/srt/layers/quantization/unquant.py) used by lm_head. */
+ * (python/sglang/srt/layers/quantization/unquant.py) used by lm_head.
+ * K * esize > 4096 bytes is split into k-ranges whose f32 partial sums go through `workspace`
+ * (sgl_mi355_skinny_gemm_num_kranges(...) slabs of M*N floats; NULL or too small -> the slower any-K kernel). */
 int sgl_mi355_skinny_gemm(const void* x, int64_t x_stride_elems, const void* w, int64_t w_stride_elems, void* y,
                           int64_t y_stride_elems, const float* scales_x, const float* scales_w, const void* bias, int M,
-                          int N, int K, int in_dtype, int out_dtype, void* stream);
+                          int N, int K, int in_dtype, int out_dtype, float* workspace, int64_t workspace_floats,
+                          void* stream);
+int sgl_mi355_skinny_gemm_num_kranges(int M, int N, int K, int in_dtype);
 
+/* Test hook: route every skinny GEMM through the generic (any-K) kernel instead of the X-stationary one. */
+int sgl_mi355_skinny_gemm_force_generic(int on);
 /* Tiled MFMA GEMM for M > 64 with the same contract as sgl_mi355_skinny_gemm's fp8 case:
  * fp8_scaled_mm, sgl-kernel/csrc/gemm/fp8_gemm_kernel.cu:1071-1146 (CUTLASS tile dispatch :303-440,739-796). */
 int sgl_mi355_fp8_gemm(const void* x, int64_t x_stride_elems, const void* w, int64_t w_stride_elems, void* y,

@@ -59,6 +59,8 @@ struct MfmaOp<ES_F16> {
   }
 };
 
+bool g_skinny_force_v1 = false;  // test hook: exercise the generic kernel on shapes the v2 kernel would take
+
 constexpr int kChunkB = 1024;  // bytes of one weight row per chunk = one wave-wide 16-B load
 constexpr int kRows = 16;      // weight rows (output columns) per workgroup
 constexpr int kWaves = 4;
@@ -157,8 +159,256 @@ int launch(const SkinnyParams& p, hipStream_t st) {
   return SGL_MI355_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// v2: "X-stationary" persistent form (the decode path's kernel).  One 512-thread workgroup per CU.  K is cut into
+// k-ranges of 8 * KW bytes (KW = 64 * DS bytes per wave); wave w of a workgroup owns the slice
+// [kr * 8 KW + w * KW, + KW) of k-range kr for the whole launch, so its X fragments are staged ONCE
+// (coalesced rows -> swizzled LDS image -> MT x DS A-fragment registers) and never re-read.  The workgroup walks
+// output tiles of `rpt` (8 or 16) weight rows; each wave streams its slice of the rows with coalesced buffer loads,
+// PD register sets ahead of the math, re-lays them through its private LDS image and runs MT x DS (x2 for fp8)
+// MFMAs; the 8 K-slice partials of TPP tiles meet in LDS between two barriers.
+//   * one k-range (K bytes <= 8 KW): every thread finishes one output element with the fused scale/bias epilogue;
+//   * several k-ranges (down_proj K = 14336, bf16 lm_head): blockIdx.y = k-range, raw f32 partial sums go to slab
+//     [kr][M][N] and are combined by the consumer (sgl_mi355_splitk_reduce, or fused into the next RMSNorm) -- the
+//     launch-boundary split-K reduce.
+// Notes from measurements on MI355X (tools/bench_skinny.py, tools/microbench/stream_patterns.hip):
+//  * global loads must be COALESCED (the lanes of a quarter wave read one contiguous >= 128-byte run of a row) and
+//    re-laid into MFMA fragment order through LDS; fragment-shaped global loads (16 rows x 64 B per instruction) are
+//    bound by the texture-address path, for W and for the one-off X fragments;
+//  * the loop body is BRANCH-FREE around memory operations (conditional loads make hipcc's wait-count insertion
+//    fall back to s_waitcnt vmcnt(0)); tiles past the workgroup's last one become out-of-range buffer offsets,
+//    which the hardware answers with zeros without touching memory;
+//  * waves run free for TPP tiles between workgroup barriers; a barrier per tile made every tile wait for the
+//    slowest of the 8 waves' loads.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kV2Waves = 8;
+
+template <int ES, int MT, int DS, int PD, int TPP, typename OutT>
+__global__ __launch_bounds__(kV2Waves * 64, 2) void skinny_gemm_v2_kernel(const SkinnyParams p, int rpt, int ntiles,
+                                                                          float* slabs) {
+  constexpr int kw = DS * 64;             // bytes of K per wave
+  constexpr int LPR = kw / 16;            // lanes per weight row in one load instruction
+  constexpr int RPI = 64 / LPR;           // rows per load instruction
+  constexpr int NLD = 16 / RPI;           // load instructions per 16-row tile (== DS)
+  constexpr int IMG = 16 * kw;            // bytes of one wave's LDS image (16 rows x kw)
+  static_assert(NLD == DS, "one 16-byte load per lane and k double-step");
+  static_assert(TPP == 1 || TPP % PD == 0, "static slot indices");
+  __shared__ __attribute__((aligned(16))) char wimg[kV2Waves * IMG];
+  __shared__ float red[TPP][kV2Waves][MT * 16][16];
+  constexpr bool SCALED = (ES == ES_FP8);  // fp8_scaled_mm always carries both scale vectors
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int a = lane & 15, g = lane >> 4;
+  const u32x4_t zero4 = {0u, 0u, 0u, 0u};
+  char* wl = wimg + w * IMG;
+  const int lc = lane % LPR, lr = lane / LPR;  // staging: 16-byte chunk lc of row lr + RPI * i
+  const int kr = blockIdx.y;
+  const int koff = kr * (kV2Waves * kw) + w * kw + lc * 16;  // this lane's byte offset inside a row
+  const bool kok = koff < p.kbytes;                          // K tail: lanes past the row end contribute zeros
+
+  const int G = gridDim.x;
+  const int cnt = (ntiles - (int)blockIdx.x + G - 1) / G;  // tiles of this workgroup: blockIdx.x + j * G, >= 1
+  const int nload = (rpt == 16) ? DS : DS / 2;             // 8-row tiles load half the instructions
+  // this thread's output element of every tile is (m = tid / 16, n = tid % 16)
+  const int em = tid >> 4, en = tid & 15;
+  const bool has_bias = p.bias != nullptr;
+  const OutT* biasp = has_bias ? (const OutT*)p.bias : (const OutT*)p.w;  // any readable address when absent
+  float sxv = 1.0f;
+  if constexpr (SCALED) sxv = p.sx[min(em, p.M - 1)];
+
+  const unsigned wbytes = (unsigned)min((int64_t)p.N * p.w_stride, (int64_t)0xFFFFFFF0ll);
+  const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, wbytes, 0x00020000);
+  u32x4_t wreg[PD][DS];
+  auto issue = [&](int slot, int j) {
+    const int n0t = (blockIdx.x + j * G) * rpt;
+#pragma unroll
+    for (int i = 0; i < DS; ++i) {
+      const int row = (i < nload) ? lr + RPI * i : lr;  // (8-row tiles: the upper half re-reads row lr, an L1 hit)
+      const unsigned off = (j < cnt && kok) ? (unsigned)((int64_t)min(n0t + row, p.N - 1) * p.w_stride) + koff : 0xFFFFFFF0u;
+      wreg[slot][i] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off, 0, 0));
+    }
+  };
+#pragma unroll
+  for (int j = 0; j < PD; ++j) issue(j, j);
+
+  // ---- X fragments of this wave's K slice, once: coalesced rows -> swizzled image -> A-fragment registers ----
+  u32x4_t xf[MT][DS];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    u32x4_t xr[DS];
+#pragma unroll
+    for (int i = 0; i < DS; ++i) {
+      const int m = mt * 16 + lr + RPI * i;
+      const u32x4_t v = *(const u32x4_t*)(p.x + (int64_t)min(m, p.M - 1) * p.x_stride + (kok ? koff : 0));
+      xr[i] = (m < p.M && kok) ? v : zero4;
+    }
+#pragma unroll
+    for (int i = 0; i < DS; ++i) {
+      const int row = lr + RPI * i;
+      *(u32x4_t*)(wl + row * kw + (((lc ^ row) & (LPR - 1)) << 4)) = xr[i];
+    }
+#pragma unroll
+    for (int sI = 0; sI < DS; ++sI) xf[mt][sI] = *(const u32x4_t*)(wl + a * kw + ((((4 * sI + g) ^ a) & (LPR - 1)) << 4));
+  }
+  const int arow = (rpt == 16) ? a : (a & 7);
+
+  for (int j0 = 0; j0 < cnt; j0 += TPP) {
+    // epilogue operands of this phase's tiles (fetched now, consumed after the phase's MFMAs)
+    float swv[TPP];
+    uint16_t braw[TPP];
+    if (slabs == nullptr) {
+#pragma unroll
+      for (int jj = 0; jj < TPP; ++jj) {
+        const int ne = min((int)(blockIdx.x + min(j0 + jj, cnt - 1) * G) * rpt + en, p.N - 1);
+        swv[jj] = 1.0f;
+        if constexpr (SCALED) swv[jj] = p.sw[ne];
+        braw[jj] = *(const uint16_t*)(biasp + (has_bias ? ne : 0));
+      }
+    }
+#pragma unroll
+    for (int jj = 0; jj < TPP; ++jj) {
+      const int j = j0 + jj;
+      const int slot = (TPP == 1) ? 0 : (jj % PD);
+      // staged registers -> swizzled image (wave private: same-wave LDS ops are ordered, no barrier needed)
+#pragma unroll
+      for (int i = 0; i < DS; ++i) {
+        const int row = lr + RPI * i;
+        *(u32x4_t*)(wl + row * kw + (((lc ^ row) & (LPR - 1)) << 4)) = wreg[slot][i];
+      }
+      if constexpr (TPP > 1) issue(slot, j + PD);
+      f32x4_t acc[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int sI = 0; sI < DS; ++sI) {
+        const u32x4_t wf = *(const u32x4_t*)(wl + arow * kw + ((((4 * sI + g) ^ arow) & (LPR - 1)) << 4));
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) MfmaOp<ES>::run(xf[mt][sI], wf, acc[mt]);
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[jj][w][mt * 16 + 4 * g + r][a] = acc[mt][r];
+    }
+    __syncthreads();
+    if (em < MT * 16) {
+#pragma unroll
+      for (int jj = 0; jj < TPP; ++jj) {
+        const int j = j0 + jj;
+        const int n0 = (blockIdx.x + j * G) * rpt;
+        float v = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < kV2Waves; ++ww) v += red[jj][ww][em][en];
+        const bool live = j < cnt && em < p.M && en < rpt && n0 + en < p.N;
+        if (slabs != nullptr) {
+          if (live) slabs[((int64_t)kr * p.M + em) * p.N + n0 + en] = v;
+        } else {
+          const float bv = has_bias ? (float)__builtin_bit_cast(OutT, braw[jj]) : 0.0f;
+          v = v * sxv * swv[jj] + bv;
+          if (live) ((OutT*)p.y)[(int64_t)em * p.y_stride + n0 + en] = (OutT)v;
+        }
+      }
+    }
+    if (TPP > 1) __syncthreads();  // the next phase overwrites red
+  }
+}
+
+// out[m][n] = (sum_kr slabs[kr][m][n]) * sx[m] * sw[n] + bias[n]: the combine step of a split-K launch when no
+// consumer kernel fuses it.
+template <typename OutT>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, int S, const float* sx,
+                                                            const float* sw, const OutT* bias, OutT* out,
+                                                            int64_t out_stride, int M, int N) {
+  const int64_t total = (int64_t)M * (N / 4);
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int m = (int)(idx / (N / 4)), n = (int)(idx - (int64_t)m * (N / 4)) * 4;
+    f32x4_t v = *(const f32x4_t*)(slabs + (int64_t)m * N + n);
+    for (int sI = 1; sI < S; ++sI) v += *(const f32x4_t*)(slabs + ((int64_t)sI * M + m) * N + n);
+    const float sm = sx ? sx[m] : 1.0f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float r = v[c] * sm * (sw ? sw[n + c] : 1.0f);
+      if (bias) r += (float)bias[n + c];
+      out[(int64_t)m * out_stride + n + c] = (OutT)r;
+    }
+  }
+}
+
+inline int v2_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) cus = 256;
+    else cus = prop.multiProcessorCount;
+  }
+  return cus;
+}
+
+// number of k-ranges the v2 kernel needs for this problem, 0 if it cannot take it
+template <int ES>
+inline int v2_kranges(const SkinnyParams& p, int* ds_out) {
+  if (p.M > 32 || g_skinny_force_v1 || (int64_t)p.N * p.w_stride >= 0xFFFFFFF0ll) return 0;
+  if ((ES == ES_FP8) != (p.sx != nullptr) || (!p.sx != !p.sw)) return 0;
+  int ds;
+  if (p.kbytes <= 1024) ds = 2;
+  else if (p.kbytes <= 2048) ds = 4;
+  else ds = (p.kbytes <= 4096) ? 8 : 16;
+  if (p.kbytes % 64 != 0) return 0;
+  *ds_out = ds;
+  const int range = kV2Waves * ds * 64;
+  return (p.kbytes + range - 1) / range;
+}
+
+template <int ES, int MT, int DS, typename OutT>
+int launch_v2(const SkinnyParams& p, int kranges, float* slabs, hipStream_t st) {
+  const int cus = v2_cus();
+  // 8-row tiles when 16-row tiles would leave the last round of workgroups mostly idle
+  const int per_range_wgs = cus / kranges > 0 ? cus / kranges : 1;
+  const int t16 = (p.N + 15) / 16;
+  const int rounds16 = (t16 + per_range_wgs - 1) / per_range_wgs;
+  const bool use8 = rounds16 < 4 && (t16 % per_range_wgs) != 0 && (t16 % per_range_wgs) < (3 * per_range_wgs) / 4;
+  const int rpt = use8 ? 8 : 16;
+  const int ntiles = (p.N + rpt - 1) / rpt;
+  const int gx = ntiles < per_range_wgs ? ntiles : per_range_wgs;
+  const dim3 grid(gx, kranges);
+  constexpr int PD = DS >= 16 ? 1 : 2;
+  constexpr int TPP = DS >= 16 ? 2 : 4;
+  if (ntiles <= gx)
+    hipLaunchKernelGGL((skinny_gemm_v2_kernel<ES, MT, DS, PD, 1, OutT>), grid, dim3(kV2Waves * 64), 0, st, p, rpt, ntiles, slabs);
+  else
+    hipLaunchKernelGGL((skinny_gemm_v2_kernel<ES, MT, DS, PD, TPP, OutT>), grid, dim3(kV2Waves * 64), 0, st, p, rpt, ntiles, slabs);
+  SGL_HIP_LAUNCH_CHECK();
+  return SGL_MI355_OK;
+}
+
+template <int ES, int MT, typename OutT>
+int launch_v2_ds(const SkinnyParams& p, int ds, int kranges, float* slabs, hipStream_t st) {
+  switch (ds) {
+    case 16: return launch_v2<ES, MT, 16, OutT>(p, kranges, slabs, st);
+    case 8: return launch_v2<ES, MT, 8, OutT>(p, kranges, slabs, st);
+    case 4: return launch_v2<ES, MT, 4, OutT>(p, kranges, slabs, st);
+    default: return launch_v2<ES, MT, 2, OutT>(p, kranges, slabs, st);
+  }
+}
+
 template <int ES, typename OutT>
-int launch_mt(const SkinnyParams& p, hipStream_t st) {
+int launch_mt(const SkinnyParams& p, float* workspace, int64_t workspace_floats, hipStream_t st) {
+  int ds = 0;
+  const int kranges = (sizeof(OutT) == 2) ? v2_kranges<ES>(p, &ds) : 0;
+  if (kranges == 1) return p.M <= 16 ? launch_v2_ds<ES, 1, OutT>(p, ds, 1, nullptr, st) : launch_v2_ds<ES, 2, OutT>(p, ds, 1, nullptr, st);
+  if (kranges > 1 && workspace != nullptr && workspace_floats >= (int64_t)kranges * p.M * p.N && p.N % 4 == 0) {
+    const int rc = p.M <= 16 ? launch_v2_ds<ES, 1, OutT>(p, ds, kranges, workspace, st)
+                             : launch_v2_ds<ES, 2, OutT>(p, ds, kranges, workspace, st);
+    if (rc != SGL_MI355_OK) return rc;
+    const int64_t items = (int64_t)p.M * (p.N / 4);
+    const unsigned blocks = (unsigned)((items + 255) / 256 > 2048 ? 2048 : (items + 255) / 256);
+    hipLaunchKernelGGL((splitk_reduce_kernel<OutT>), dim3(blocks), dim3(256), 0, st, workspace, kranges, p.sx, p.sw,
+                       (const OutT*)p.bias, (OutT*)p.y, p.y_stride, p.M, p.N);
+    SGL_HIP_LAUNCH_CHECK();
+    return SGL_MI355_OK;
+  }
   if (p.M <= 16) return launch<ES, 1, OutT>(p, st);
   if (p.M <= 32) return launch<ES, 2, OutT>(p, st);
   return launch<ES, 4, OutT>(p, st);
@@ -166,10 +416,24 @@ int launch_mt(const SkinnyParams& p, hipStream_t st) {
 
 }  // namespace
 
+extern "C" int sgl_mi355_skinny_gemm_force_generic(int on) {
+  g_skinny_force_v1 = on != 0;
+  return SGL_MI355_OK;
+}
+
 // in_dtype: SGL_FP8_E4M3 / SGL_BF16 / SGL_F16 (X and W share it); out_dtype: SGL_BF16 / SGL_F16.
+extern "C" int sgl_mi355_skinny_gemm_num_kranges(int M, int N, int K, int in_dtype) {
+  // how many f32 [M, N] slabs of workspace sgl_mi355_skinny_gemm wants for this shape (0 or 1: none needed)
+  if (M > 32 || g_skinny_force_v1) return 0;
+  const int kbytes = K * (in_dtype == SGL_FP8_E4M3 ? 1 : 2);
+  if (kbytes % 64 != 0 || kbytes <= 4096) return kbytes % 64 == 0 ? 1 : 0;
+  return (kbytes + 8191) / 8192;
+}
+
 extern "C" int sgl_mi355_skinny_gemm(const void* x, int64_t x_stride_elems, const void* w, int64_t w_stride_elems, void* y,
                                      int64_t y_stride_elems, const float* scales_x, const float* scales_w,
-                                     const void* bias, int M, int N, int K, int in_dtype, int out_dtype, void* stream) {
+                                     const void* bias, int M, int N, int K, int in_dtype, int out_dtype,
+                                     float* workspace, int64_t workspace_floats, void* stream) {
   SGL_CHECK(M >= 0 && N >= 0 && K >= 0, "skinny_gemm: negative shape");
   if (M == 0 || N == 0) return SGL_MI355_OK;
   SGL_CHECK(M <= 64, "skinny_gemm: M=%d exceeds 64 (use the tiled GEMM)", M);
@@ -188,8 +452,11 @@ extern "C" int sgl_mi355_skinny_gemm(const void* x, int64_t x_stride_elems, cons
   p.M = M; p.N = N; p.K = K; p.kbytes = K * es;
   hipStream_t st = (hipStream_t)stream;
   if (in_dtype == SGL_FP8_E4M3)
-    return out_dtype == SGL_BF16 ? launch_mt<ES_FP8, __bf16>(p, st) : launch_mt<ES_FP8, _Float16>(p, st);
+    return out_dtype == SGL_BF16 ? launch_mt<ES_FP8, __bf16>(p, workspace, workspace_floats, st)
+                                 : launch_mt<ES_FP8, _Float16>(p, workspace, workspace_floats, st);
   if (in_dtype == SGL_BF16)
-    return out_dtype == SGL_BF16 ? launch_mt<ES_BF16, __bf16>(p, st) : launch_mt<ES_BF16, _Float16>(p, st);
-  return out_dtype == SGL_BF16 ? launch_mt<ES_F16, __bf16>(p, st) : launch_mt<ES_F16, _Float16>(p, st);
+    return out_dtype == SGL_BF16 ? launch_mt<ES_BF16, __bf16>(p, workspace, workspace_floats, st)
+                                 : launch_mt<ES_BF16, _Float16>(p, workspace, workspace_floats, st);
+  return out_dtype == SGL_BF16 ? launch_mt<ES_F16, __bf16>(p, workspace, workspace_floats, st)
+                               : launch_mt<ES_F16, _Float16>(p, workspace, workspace_floats, st);
 }

@@ -6,6 +6,22 @@ import torch
 
 from .._cabi import check, current_stream, dtype_code, lib, ptr
 
+_WORKSPACES = {}
+
+
+def _splitk_workspace(m, n, k, dtype, device):
+    """f32 slab workspace for the split-K form of the weight-streaming GEMM (one cached buffer per device: the
+    launcher must not allocate inside a captured graph)."""
+    kr = lib.sgl_mi355_skinny_gemm_num_kranges(m, n, k, dtype_code(dtype))
+    if kr <= 1:
+        return None, 0
+    need = kr * m * n
+    buf = _WORKSPACES.get(device)
+    if buf is None or buf.numel() < need:
+        buf = torch.empty(max(need, 1 << 22), dtype=torch.float32, device=device)
+        _WORKSPACES[device] = buf
+    return buf, buf.numel()
+
 
 def _cuda(*ts):
     for t in ts:
@@ -85,9 +101,10 @@ def fp8_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype, bias=None):
         raise RuntimeError("out must be multiple of 16 bytes for memory alignment")
     w_stride = mat_b.stride(1)  # W[n, :] = mat_b[:, n]
     if m <= 64:
+        ws, ws_n = _splitk_workspace(m, n, k, mat_a.dtype, mat_a.device)
         check(lib.sgl_mi355_skinny_gemm(ptr(mat_a), mat_a.stride(0), ptr(mat_b), w_stride, ptr(out), out.stride(0),
                                         ptr(scales_a), ptr(scales_b), ptr(bias), m, n, k, dtype_code(mat_a.dtype),
-                                        dtype_code(out_dtype), current_stream()))
+                                        dtype_code(out_dtype), ptr(ws), ws_n, current_stream()))
     else:
         check(lib.sgl_mi355_fp8_gemm(ptr(mat_a), mat_a.stride(0), ptr(mat_b), w_stride, ptr(out), out.stride(0),
                                      ptr(scales_a), ptr(scales_b), ptr(bias), m, n, k, dtype_code(out_dtype),
@@ -105,8 +122,9 @@ def dense_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
     out_dtype = out_dtype or x.dtype
     out = torch.empty((m, n), dtype=out_dtype, device=x.device)
     if m <= 64:
+        ws, ws_n = _splitk_workspace(m, n, k, x.dtype, x.device)
         check(lib.sgl_mi355_skinny_gemm(ptr(x), x.stride(0), ptr(weight), weight.stride(0), ptr(out), out.stride(0), None,
-                                        None, ptr(bias), m, n, k, dtype_code(x.dtype), dtype_code(out_dtype),
+                                        None, ptr(bias), m, n, k, dtype_code(x.dtype), dtype_code(out_dtype), ptr(ws), ws_n,
                                         current_stream()))
     else:
         check(lib.sgl_mi355_dense_gemm(ptr(x), x.stride(0), ptr(weight), weight.stride(0), ptr(out), out.stride(0),

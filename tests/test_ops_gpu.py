@@ -150,6 +150,22 @@ def test_fp8_scaled_mm_vs_golden(case, sk, golden):
     torch.testing.assert_close(o.cpu().float(), want.float(), rtol=1.6e-2, atol=0.3)
 
 
+@pytest.mark.parametrize("m,n,k", [(32, 272, 14336), (7, 64, 8256), (32, 4096, 4096), (16, 6144, 4096), (32, 1000, 3072)])
+@pytest.mark.parametrize("generic", [False, True])
+def test_fp8_skinny_paths_vs_oracle(m, n, k, generic, sk, pkg):
+    """X-stationary kernel (single k-range and split-K slabs + reduce, 8/16-row tiles) and the any-K kernel."""
+    from ltp_sglang_amd._cabi import lib
+
+    c = _cases.build_gemm_case(dict(m=m, n=n, k=k, bias=True, out="bf16"), seed=k + m)
+    lib.sgl_mi355_skinny_gemm_force_generic(int(generic))
+    try:
+        o = sk.fp8_scaled_mm(c["a"].to(DEV), c["w"].to(DEV).t(), c["sa"].to(DEV), c["sb"].to(DEV), c["out_dtype"], c["bias"].to(DEV))
+    finally:
+        lib.sgl_mi355_skinny_gemm_force_generic(0)
+    ref = oq.scaled_mm(c["a"], c["w"].t(), c["sa"], c["sb"], c["out_dtype"], c["bias"])
+    torch.testing.assert_close(o.cpu().float(), ref.float(), rtol=1.6e-2, atol=0.3)
+
+
 def test_fp8_scaled_mm_checks(sk):
     a = torch.zeros(4, 64, dtype=torch.float8_e4m3fn, device=DEV)
     b = torch.zeros(32, 64, dtype=torch.float8_e4m3fn, device=DEV)
@@ -162,7 +178,8 @@ def test_fp8_scaled_mm_checks(sk):
         sk.fp8_scaled_mm(a, b.t(), sa, sb[:5], torch.bfloat16)
 
 
-@pytest.mark.parametrize("m,n,k,dtype", [(32, 1000, 4096, torch.bfloat16), (5, 64, 768, torch.float16), (64, 48, 1024, torch.bfloat16)])
+@pytest.mark.parametrize("m,n,k,dtype", [(32, 1000, 4096, torch.bfloat16), (5, 64, 768, torch.float16), (64, 48, 1024, torch.bfloat16),
+                                         (32, 520, 8192, torch.bfloat16), (9, 128, 2048, torch.float16)])
 def test_dense_skinny_linear(m, n, k, dtype, sk):
     g = torch.Generator().manual_seed(k)
     x = torch.randn(m, k, generator=g).to(dtype)
