@@ -125,6 +125,10 @@ int sgl_mi355_skinny_gemm(const void* x, int64_t x_stride_elems, const void* w, 
                           int N, int K, int in_dtype, int out_dtype, float* workspace, int64_t workspace_floats,
                           void* stream);
 int sgl_mi355_skinny_gemm_num_kranges(int M, int N, int K, int in_dtype);
+/* Producer half of the launch-boundary split-K reduce: raw f32 partial sums [kranges, M, N], scales left to the consumer
+ * (sgl_mi355_fused_add_rmsnorm_quant_fp8 with slabs != NULL). fp8, M <= 32. */
+int sgl_mi355_skinny_gemm_slabs(const void* x, int64_t x_stride_elems, const void* w, int64_t w_stride_elems, float* slabs,
+                                int M, int N, int K, int in_dtype, void* stream);
 
 /* Test hook: route every skinny GEMM through the generic (any-K) kernel instead of the X-stationary one. */
 int sgl_mi355_skinny_gemm_force_generic(int on);
@@ -160,6 +164,29 @@ int sgl_mi355_embedding(void* out, const int64_t* ids, const void* table, int64_
 /* greedy sampling: torch.argmax(logits, -1), layers/sampler.py */
 int sgl_mi355_argmax(int64_t* out, const void* logits, int64_t rows, int64_t vocab, int64_t row_stride, int dtype,
                      void* stream);
+
+/* ---- fused decode-step kernels: bit-identical to the op sequences they replace ------------------------------ */
+/* [split-K combine ->] fused_add_rmsnorm (layernorm.py:135-171) -> sgl_per_token_quant_fp8.  Exactly one of x / slabs. */
+int sgl_mi355_fused_add_rmsnorm_quant_fp8(const void* x, const float* slabs, int nslabs, const float* slab_sx,
+                                          const float* slab_sw, void* residual, const void* weight, float eps,
+                                          void* out_norm, void* out_q, float* out_s, int tokens, int hidden, int dtype,
+                                          void* stream);
+/* silu_and_mul (activation.py:60-63) -> sgl_per_token_quant_fp8 */
+int sgl_mi355_silu_and_mul_quant_fp8(const void* x, void* out_q, float* out_s, int tokens, int d, int dtype, void* stream);
+/* rotary_embedding (rotary_embedding.py:138-165) on q, k in place -> set_kv_buffer (memory_pool.py:369-407) of (k, v) */
+int sgl_mi355_rope_set_kv(const int64_t* positions, void* query, void* key, const void* value, const float* cos_sin_cache,
+                          void* k_buffer, void* v_buffer, const int64_t* loc, int64_t tokens, int num_q_heads,
+                          int num_k_heads, int head_size, int rot_dim, int64_t q_stride, int64_t k_stride,
+                          int64_t v_stride, int64_t k_slot_stride, int64_t v_slot_stride, int is_neox, int dtype,
+                          void* stream);
+/* decode stage-2 LSE merge (decode_attention.py:492-552) -> sgl_per_token_quant_fp8 of the [batch, Hq*Dv] output */
+int sgl_mi355_decode_merge_quant_fp8(const float* attn_logits, const float* attn_lse, const int32_t* kv_indptr,
+                                     const int64_t* seq_lens, const int32_t* num_kv_splits, int max_kv_splits, int batch,
+                                     int num_q_heads, int v_head_dim, void* out_o, void* out_q, float* out_s, int dtype,
+                                     void* stream);
+/* torch.argmax(logits, -1) with 16-byte loads (bf16/f16 rows) */
+int sgl_mi355_argmax_vec(int64_t* out, const void* logits, int64_t rows, int64_t vocab, int64_t row_stride, int dtype,
+                         void* stream);
 
 /* out[cols, rows] = in[rows, cols]^T for 16-bit elements (weight re-layout between awq_dequantize's [K, N] and
  * the [N, K] the GEMMs stream; AWQLinearMethod.apply, layers/quantization/awq.py:401-418) */

@@ -93,4 +93,20 @@ __device__ __forceinline__ float wave_reduce_sum(float v) {
   return v;
 }
 
+// One step of the LSE-weighted merge of split-KV partials (decode_attention.py:492-552), written with explicit fmaf so
+// that every kernel that merges (stand-alone stage 2, fused merge+quant) rounds identically: left to the compiler,
+// a*b + c*d contracts differently from kernel to kernel and flips the last f32 bit now and then.
+struct LseMerge {
+  float M = -INFINITY, L = 0.f, so = 0.f, sn = 0.f;
+  __device__ __forceinline__ void begin(float lse) {
+    const float nM = fmaxf(M, lse);
+    so = __expf(M - nM);
+    sn = __expf(lse - nM);
+    L = fmaf(L, so, sn);
+    M = nM;
+  }
+  __device__ __forceinline__ float acc(float a, float v) const { return fmaf(a, so, v * sn); }
+  __device__ __forceinline__ float finish(float a) const { return L > 0.f ? a / L : 0.f; }
+};
+
 static inline int cdiv_i(int a, int b) { return (a + b - 1) / b; }

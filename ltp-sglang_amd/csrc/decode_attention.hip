@@ -374,19 +374,15 @@ __global__ __launch_bounds__(128) void decode_attn_stage2(const DecodeParams p) 
   const int dv = p.dv;
   const int64_t slot0 = ((int64_t)b * p.hq + h) * p.max_kv_splits;
   for (int d = threadIdx.x; d < dv; d += blockDim.x) {
-    float M = -INFINITY, L = 0.f, accv = 0.f;
+    LseMerge mg;
+    float accv = 0.f;
     for (int s = 0; s < nsplit; ++s) {
       if (s * per < seq_len) {
-        const float lse = p.attn_lse[slot0 + s];
-        const float v = p.attn_logits[(slot0 + s) * dv + d];
-        const float nM = fmaxf(M, lse);
-        const float so = __expf(M - nM), sn = __expf(lse - nM);
-        accv = accv * so + v * sn;
-        L = L * so + sn;
-        M = nM;
+        mg.begin(p.attn_lse[slot0 + s]);
+        accv = mg.acc(accv, p.attn_logits[(slot0 + s) * dv + d]);
       }
     }
-    const float r = (L > 0.f) ? accv / L : 0.f;
+    const float r = mg.finish(accv);
     ((T*)p.o)[(int64_t)b * p.o_stride_t + (int64_t)h * dv + d] = ElemTraits<T>::from_f32(r);
   }
 }
@@ -421,6 +417,7 @@ int launch_all(const DecodeParams& p, int d_qk, hipStream_t st) {
     rc = SGL_MI355_OK;
   }
   if (rc != SGL_MI355_OK) return rc;
+  if (p.o == nullptr) return SGL_MI355_OK;  // partials only: the caller merges (sgl_mi355_decode_merge_quant_fp8)
   hipLaunchKernelGGL((decode_attn_stage2<T>), dim3(p.bs, p.hq), dim3(128), 0, st, p);
   SGL_HIP_LAUNCH_CHECK();
   return SGL_MI355_OK;
@@ -437,7 +434,7 @@ extern "C" int sgl_mi355_decode_attention(
     int dtype, void* stream) {
   SGL_CHECK(batch >= 0, "decode_attention: negative batch %d", batch);
   if (batch == 0) return SGL_MI355_OK;
-  SGL_CHECK(q && k_buffer && v_buffer && o, "decode_attention: null tensor pointer");
+  SGL_CHECK(q && k_buffer && v_buffer, "decode_attention: null tensor pointer");  // o == NULL: split partials only
   SGL_CHECK(attn_logits && attn_lse && num_kv_splits, "decode_attention: null split scratch pointer");
   SGL_CHECK(kv_indptr || (req_to_token && req_pool_indices && seq_lens),
             "decode_attention: need either (kv_indptr, kv_indices) or (req_to_token, req_pool_indices, seq_lens)");

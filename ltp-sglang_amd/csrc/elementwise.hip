@@ -34,6 +34,7 @@ __device__ __forceinline__ void st8(T* p, const V8<T>& x) {
 // T -> float -> T round trip); these are the reference's rounding points and must really happen.
 template <typename T>
 __device__ __forceinline__ float round_via(float x) {
+  asm volatile("" : "+v"(x));  // x must exist as an f32 first: no v_fma_mix* single-rounding shortcut (the reference rounds twice)
   const T t = (T)x;
   const uint16_t u = __builtin_bit_cast(uint16_t, t);
   uint16_t v;
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(T* out, const T* x, T* res
       const V8<T> w = ld8(weight + i * 8);
       V8<T> o;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) o.v[j] = (T)((vals[it][j] * rs) * (float)w.v[j]);
+      for (int j = 0; j < 8; ++j) o.v[j] = (T)round_via<T>((vals[it][j] * rs) * (float)w.v[j]);
       st8(orow + i * 8, o);
     }
   }

@@ -1,0 +1,421 @@
+// Fused elementwise kernels of the decode step: each one is bit-identical to the sequence of stand-alone kernels it
+// replaces (same rounding points), it only removes launches and HBM round trips.  At batch 32 every one of these
+// ops is a ~2-5 us launch, 17 of them per layer; fused they are 4.
+//
+//   fused_add_rmsnorm_quant_fp8 = [splitk_reduce ->] fused_add_rmsnorm -> sgl_per_token_quant_fp8
+//       (layernorm.py:135-171 + per_token_quant_fp8.cu:15-228)
+//   silu_and_mul_quant_fp8      = silu_and_mul -> sgl_per_token_quant_fp8      (activation.py:60-63)
+//   rope_set_kv                 = rotary_embedding -> set_kv_buffer             (rotary_embedding.py:138-165,
+//                                                                                memory_pool.py:369-407)
+//   decode_merge_quant_fp8      = decode stage-2 LSE merge -> sgl_per_token_quant_fp8
+//       (decode_attention.py:492-552)
+// All HBM/L2-bound byte work: one 256-thread workgroup per token, 16-byte accesses.
+#include "common.h"
+
+namespace {
+
+constexpr float kFp8Max = 448.0f;
+
+template <typename T>
+struct V8 {
+  T v[8];
+};
+template <typename T>
+__device__ __forceinline__ V8<T> ld8(const T* p) {
+  return __builtin_bit_cast(V8<T>, *(const u32x4_t*)p);
+}
+template <typename T>
+__device__ __forceinline__ void st8(T* p, const V8<T>& x) {
+  *(u32x4_t*)p = __builtin_bit_cast(u32x4_t, x);
+}
+
+// f32 -> T -> f32 through the bit pattern (see elementwise.hip: the rounding point must really happen)
+template <typename T>
+__device__ __forceinline__ float round_via(float x) {
+  asm volatile("" : "+v"(x));  // x must exist as an f32 first: no v_fma_mix* single-rounding shortcut (the reference rounds twice)
+  const T t = (T)x;
+  const uint16_t u = __builtin_bit_cast(uint16_t, t);
+  uint16_t v;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "v"(u));
+  return (float)__builtin_bit_cast(T, v);
+}
+
+__device__ __forceinline__ u32x2_t pack8_fp8(const float (&f)[8]) {
+  int lo = 0, hi = 0;
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+  return u32x2_t{(uint32_t)lo, (uint32_t)hi};
+}
+
+__device__ __forceinline__ float clamp448(float v) { return fmaxf(fminf(v, kFp8Max), -kFp8Max); }
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_reduce_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+  v = wave_reduce_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// per-token fp8 quantisation of the row held in vals (already rounded to T), exactly per_token_quant_fp8.cu
+template <int MAXV>
+__device__ __forceinline__ void quant_row(const float (&vals)[MAXV][8], int nvec, uint8_t* qrow, float* srow, float* red) {
+  float amax = 0.f;
+#pragma unroll
+  for (int it = 0; it < MAXV; ++it)
+    if ((int)threadIdx.x + it * 256 < nvec)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(vals[it][j]));
+  amax = block_max(amax, red);
+  const float scale = amax / kFp8Max;
+  if (threadIdx.x == 0) *srow = scale;
+  const float inv = (scale == 0.f) ? 0.f : 1.0f / scale;
+#pragma unroll
+  for (int it = 0; it < MAXV; ++it) {
+    const int i = threadIdx.x + it * 256;
+    if (i < nvec) {
+      float f[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = clamp448(vals[it][j] * inv);
+      *(u32x2_t*)(qrow + i * 8) = pack8_fp8(f);
+    }
+  }
+}
+
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256) void add_rmsnorm_quant_kernel(const T* x, const float* slabs, int nslabs,
+                                                                const float* slab_sx, const float* slab_sw, T* residual,
+                                                                const T* weight, float eps, T* out_norm, uint8_t* out_q,
+                                                                float* out_s, int tokens, int hidden) {
+  __shared__ float red[4];
+  const int64_t row = blockIdx.x;
+  const int nvec = hidden / 8;
+  float vals[MAXV][8];
+  float ss = 0.f;
+  const float sxm = (slabs && slab_sx) ? slab_sx[row] : 1.0f;
+#pragma unroll
+  for (int it = 0; it < MAXV; ++it) {
+    const int i = threadIdx.x + it * 256;
+    if (i < nvec) {
+      float f[8];
+      if (slabs) {  // x = T((sum of the split-K partial sums) * sx[m] * sw[n]): the GEMM epilogue, fused
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = 0.f;
+        for (int sI = 0; sI < nslabs; ++sI) {
+          const float* sp = slabs + ((int64_t)sI * tokens + row) * hidden + i * 8;
+          const f32x4_t a0 = *(const f32x4_t*)sp, a1 = *(const f32x4_t*)(sp + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { f[j] += a0[j]; f[4 + j] += a1[j]; }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = round_via<T>(f[j] * sxm * (slab_sw ? slab_sw[i * 8 + j] : 1.0f));
+      } else {
+        const V8<T> a = ld8(x + row * hidden + i * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = (float)a.v[j];
+      }
+      if (residual) {
+        const V8<T> r = ld8(residual + row * hidden + i * 8);
+        V8<T> ro;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          f[j] += (float)r.v[j];
+          ro.v[j] = (T)f[j];
+        }
+        st8(residual + row * hidden + i * 8, ro);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        vals[it][j] = f[j];
+        ss += f[j] * f[j];
+      }
+    }
+  }
+  const float var = block_sum(ss, red) / (float)hidden;
+  const float rs = 1.0f / sqrtf(var + eps);
+#pragma unroll
+  for (int it = 0; it < MAXV; ++it) {
+    const int i = threadIdx.x + it * 256;
+    if (i < nvec) {
+      const V8<T> w = ld8(weight + i * 8);
+      V8<T> o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        vals[it][j] = round_via<T>((vals[it][j] * rs) * (float)w.v[j]);
+        o.v[j] = (T)vals[it][j];
+      }
+      if (out_norm) st8(out_norm + row * hidden + i * 8, o);
+    }
+  }
+  if (out_q) quant_row<MAXV>(vals, nvec, out_q + row * hidden, out_s + row, red);
+}
+
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256) void silu_mul_quant_kernel(const T* x, uint8_t* out_q, float* out_s, int d) {
+  __shared__ float red[4];
+  const int64_t row = blockIdx.x;
+  const int nvec = d / 8;
+  float vals[MAXV][8];
+#pragma unroll
+  for (int it = 0; it < MAXV; ++it) {
+    const int i = threadIdx.x + it * 256;
+    if (i < nvec) {
+      const V8<T> a = ld8(x + row * 2 * d + i * 8), b = ld8(x + row * 2 * d + d + i * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float af = (float)a.v[j];
+        const float sI = round_via<T>(af / (1.0f + expf(-af)));
+        vals[it][j] = round_via<T>(sI * (float)b.v[j]);
+      }
+    }
+  }
+  quant_row<MAXV>(vals, nvec, out_q + row * d, out_s + row, red);
+}
+
+// one workgroup per token: rotate q (in place) and k (in place + into the pool), copy v into the pool
+template <typename T>
+__global__ __launch_bounds__(256) void rope_set_kv_kernel(const int64_t* positions, T* q, T* k, const T* v, const float* cache,
+                                                          T* k_buf, T* v_buf, const int64_t* loc, int hq, int hk,
+                                                          int head_size, int rot_dim, int64_t q_stride, int64_t k_stride,
+                                                          int64_t v_stride, int64_t kb_stride, int64_t vb_stride, int is_neox) {
+  const int64_t t = blockIdx.x;
+  const int half = rot_dim / 2;
+  const float* cs = cache + positions[t] * rot_dim;
+  const int64_t slot = loc[t];
+  T* kdst = k_buf + slot * kb_stride;
+  const int npairs = (hq + hk) * half;
+  for (int idx = threadIdx.x; idx < npairs; idx += 256) {
+    const int h = idx / half, i = idx - h * half;
+    const bool isq = h < hq;
+    T* base = isq ? q + t * q_stride + (int64_t)h * head_size : k + t * k_stride + (int64_t)(h - hq) * head_size;
+    const float c = round_via<T>(cs[i]), s = round_via<T>(cs[half + i]);
+    const int i1 = is_neox ? i : 2 * i, i2 = is_neox ? half + i : 2 * i + 1;
+    const float x1 = (float)base[i1], x2 = (float)base[i2];
+    const T o1 = (T)(round_via<T>(x1 * c) - round_via<T>(x2 * s));
+    const T o2 = (T)(round_via<T>(x2 * c) + round_via<T>(x1 * s));
+    base[i1] = o1;
+    base[i2] = o2;
+    if (!isq) {
+      kdst[(h - hq) * head_size + i1] = o1;
+      kdst[(h - hq) * head_size + i2] = o2;
+    }
+  }
+  // un-rotated tail of each k head (rot_dim < head_size) and the whole v row
+  if (rot_dim < head_size)
+    for (int idx = threadIdx.x; idx < hk * (head_size - rot_dim); idx += 256) {
+      const int h = idx / (head_size - rot_dim), i = rot_dim + idx % (head_size - rot_dim);
+      kdst[h * head_size + i] = k[t * k_stride + (int64_t)h * head_size + i];
+    }
+  const int vvec = hk * head_size / 8;
+  for (int i = threadIdx.x; i < vvec; i += 256)
+    *(u32x4_t*)(v_buf + slot * vb_stride + i * 8) = *(const u32x4_t*)(v + t * v_stride + i * 8);
+}
+
+// one workgroup per token: merge the split partials of every head (decode stage 2), round to T, per-token fp8 quant
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256) void decode_merge_quant_kernel(const float* attn_logits, const float* attn_lse,
+                                                                 const int32_t* kv_indptr, const int64_t* seq_lens,
+                                                                 const int32_t* num_kv_splits, int max_kv_splits, int hq,
+                                                                 int dv, T* out_o, uint8_t* out_q, float* out_s) {
+  __shared__ float red[4];
+  const int b = blockIdx.x;
+  const int seq_len = kv_indptr ? kv_indptr[b + 1] - kv_indptr[b] : (int)seq_lens[b];
+  const int nsplit = max(1, min(num_kv_splits[b], max_kv_splits));
+  const int per0 = (seq_len + nsplit - 1) / nsplit;
+  const int per = (per0 + 31) / 32 * 32;
+  const int row_elems = hq * dv, nvec = row_elems / 8;
+  float vals[MAXV][8];
+#pragma unroll
+  for (int it = 0; it < MAXV; ++it) {
+    const int i = threadIdx.x + it * 256;
+    if (i < nvec) {
+      const int e0 = i * 8, h = e0 / dv, d0 = e0 - h * dv;
+      const int64_t slot0 = ((int64_t)b * hq + h) * max_kv_splits;
+      LseMerge mg;
+      float acc[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+      for (int sI = 0; sI < nsplit; ++sI) {
+        if (sI * per < seq_len) {
+          mg.begin(attn_lse[slot0 + sI]);
+          const float* lp = attn_logits + (slot0 + sI) * dv + d0;
+          const f32x4_t a0 = *(const f32x4_t*)lp, a1 = *(const f32x4_t*)(lp + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            acc[j] = mg.acc(acc[j], a0[j]);
+            acc[4 + j] = mg.acc(acc[4 + j], a1[j]);
+          }
+        }
+      }
+      V8<T> o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        vals[it][j] = round_via<T>(mg.finish(acc[j]));
+        o.v[j] = (T)vals[it][j];
+      }
+      if (out_o) st8(out_o + (int64_t)b * row_elems + e0, o);
+    }
+  }
+  if (out_q) quant_row<MAXV>(vals, nvec, out_q + (int64_t)b * row_elems, out_s + b, red);
+}
+
+// vectorised greedy argmax: first index of the row maximum
+template <typename T>
+__global__ __launch_bounds__(1024) void argmax_vec_kernel(int64_t* out, const T* logits, int64_t vocab, int64_t stride) {
+  __shared__ float rv[16];
+  __shared__ int64_t ri[16];
+  const T* row = logits + (int64_t)blockIdx.x * stride;
+  float best = -INFINITY;
+  int64_t bi = 0x7fffffffffffffffLL;
+  const int64_t nvec = vocab / 8;
+  for (int64_t i = threadIdx.x; i < nvec; i += 1024) {
+    const V8<T> a = ld8(row + i * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float v = (float)a.v[j];
+      if (v > best) { best = v; bi = i * 8 + j; }  // ascending index within the thread: strict > keeps the first
+    }
+  }
+  for (int64_t i = nvec * 8 + threadIdx.x; i < vocab; i += 1024) {
+    const float v = (float)row[i];
+    if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    const float ov = __shfl_xor(best, m, WAVE);
+    const int64_t oi = __shfl_xor(bi, m, WAVE);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  if ((threadIdx.x & 63) == 0) { rv[threadIdx.x >> 6] = best; ri[threadIdx.x >> 6] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 16; ++w)
+      if (rv[w] > best || (rv[w] == best && ri[w] < bi)) { best = rv[w]; bi = ri[w]; }
+    out[blockIdx.x] = bi;
+  }
+}
+
+#define DISPATCH_HALF(dtype, ...) \
+  if ((dtype) == SGL_BF16) {      \
+    using T = __bf16;             \
+    __VA_ARGS__                   \
+  } else {                        \
+    using T = _Float16;           \
+    __VA_ARGS__                   \
+  }
+
+}  // namespace
+
+// x (bf16/f16 [tokens, hidden]) XOR slabs (f32 [nslabs, tokens, hidden] raw split-K sums with their sx[m] / sw[n]);
+// residual (in/out) may be NULL (first layer); out_norm and out_q/out_s are each optional.
+extern "C" int sgl_mi355_fused_add_rmsnorm_quant_fp8(const void* x, const float* slabs, int nslabs, const float* slab_sx,
+                                                     const float* slab_sw, void* residual, const void* weight, float eps,
+                                                     void* out_norm, void* out_q, float* out_s, int tokens, int hidden,
+                                                     int dtype, void* stream) {
+  SGL_CHECK(tokens >= 0 && hidden > 0, "fused_add_rmsnorm_quant_fp8: bad shape");
+  if (tokens == 0) return SGL_MI355_OK;
+  SGL_CHECK((x != nullptr) != (slabs != nullptr), "fused_add_rmsnorm_quant_fp8: exactly one of x / slabs must be given");
+  SGL_CHECK(weight && (out_norm || out_q), "fused_add_rmsnorm_quant_fp8: null pointer");
+  SGL_CHECK(!out_q || out_s, "fused_add_rmsnorm_quant_fp8: out_q needs out_s");
+  SGL_CHECK(hidden % 8 == 0 && hidden <= 8192, "fused_add_rmsnorm_quant_fp8: hidden=%d must be a multiple of 8 and <= 8192", hidden);
+  SGL_CHECK(dtype == SGL_BF16 || dtype == SGL_F16, "fused_add_rmsnorm_quant_fp8: dtype must be bf16 or f16");
+  SGL_CHECK(!slabs || nslabs >= 1, "fused_add_rmsnorm_quant_fp8: nslabs must be >= 1");
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_HALF(dtype, {
+    hipLaunchKernelGGL((add_rmsnorm_quant_kernel<T, 4>), dim3(tokens), dim3(256), 0, st, (const T*)x, slabs, nslabs, slab_sx,
+                       slab_sw, (T*)residual, (const T*)weight, eps, (T*)out_norm, (uint8_t*)out_q, out_s, tokens, hidden);
+  })
+  SGL_HIP_LAUNCH_CHECK();
+  return SGL_MI355_OK;
+}
+
+extern "C" int sgl_mi355_silu_and_mul_quant_fp8(const void* x, void* out_q, float* out_s, int tokens, int d, int dtype,
+                                                void* stream) {
+  SGL_CHECK(tokens >= 0 && d > 0, "silu_and_mul_quant_fp8: bad shape");
+  if (tokens == 0) return SGL_MI355_OK;
+  SGL_CHECK(x && out_q && out_s, "silu_and_mul_quant_fp8: null pointer");
+  SGL_CHECK(d % 8 == 0 && d <= 32768, "silu_and_mul_quant_fp8: d=%d must be a multiple of 8 and <= 32768", d);
+  SGL_CHECK(dtype == SGL_BF16 || dtype == SGL_F16, "silu_and_mul_quant_fp8: dtype must be bf16 or f16");
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_HALF(dtype, {
+    if (d <= 16384)
+      hipLaunchKernelGGL((silu_mul_quant_kernel<T, 8>), dim3(tokens), dim3(256), 0, st, (const T*)x, (uint8_t*)out_q, out_s, d);
+    else
+      hipLaunchKernelGGL((silu_mul_quant_kernel<T, 16>), dim3(tokens), dim3(256), 0, st, (const T*)x, (uint8_t*)out_q, out_s, d);
+  })
+  SGL_HIP_LAUNCH_CHECK();
+  return SGL_MI355_OK;
+}
+
+extern "C" int sgl_mi355_rope_set_kv(const int64_t* positions, void* query, void* key, const void* value,
+                                     const float* cos_sin_cache, void* k_buffer, void* v_buffer, const int64_t* loc,
+                                     int64_t tokens, int num_q_heads, int num_k_heads, int head_size, int rot_dim,
+                                     int64_t q_stride, int64_t k_stride, int64_t v_stride, int64_t k_slot_stride,
+                                     int64_t v_slot_stride, int is_neox, int dtype, void* stream) {
+  SGL_CHECK(tokens >= 0, "rope_set_kv: negative token count");
+  if (tokens == 0) return SGL_MI355_OK;
+  SGL_CHECK(positions && query && key && value && cos_sin_cache && k_buffer && v_buffer && loc, "rope_set_kv: null pointer");
+  SGL_CHECK(rot_dim > 0 && rot_dim % 2 == 0 && rot_dim <= head_size, "rope_set_kv: rot_dim=%d invalid for head_size=%d", rot_dim, head_size);
+  SGL_CHECK((num_k_heads * head_size) % 8 == 0 && v_stride % 8 == 0 && v_slot_stride % 8 == 0 &&
+                ((uintptr_t)value % 16) == 0 && ((uintptr_t)v_buffer % 16) == 0,
+            "rope_set_kv: v rows must be 16-byte aligned");
+  SGL_CHECK(dtype == SGL_BF16 || dtype == SGL_F16, "rope_set_kv: dtype must be bf16 or f16");
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_HALF(dtype, {
+    hipLaunchKernelGGL((rope_set_kv_kernel<T>), dim3((unsigned)tokens), dim3(256), 0, st, positions, (T*)query, (T*)key,
+                       (const T*)value, cos_sin_cache, (T*)k_buffer, (T*)v_buffer, loc, num_q_heads, num_k_heads, head_size,
+                       rot_dim, q_stride, k_stride, v_stride, k_slot_stride, v_slot_stride, is_neox);
+  })
+  SGL_HIP_LAUNCH_CHECK();
+  return SGL_MI355_OK;
+}
+
+// kv_indptr (int32 [batch+1]) or seq_lens (int64 [batch]) gives each request's length (needed to skip empty splits)
+extern "C" int sgl_mi355_decode_merge_quant_fp8(const float* attn_logits, const float* attn_lse, const int32_t* kv_indptr,
+                                                const int64_t* seq_lens, const int32_t* num_kv_splits, int max_kv_splits,
+                                                int batch, int num_q_heads, int v_head_dim, void* out_o, void* out_q,
+                                                float* out_s, int dtype, void* stream) {
+  SGL_CHECK(batch >= 0, "decode_merge_quant_fp8: negative batch");
+  if (batch == 0) return SGL_MI355_OK;
+  SGL_CHECK(attn_logits && attn_lse && num_kv_splits && (kv_indptr || seq_lens) && (out_o || out_q),
+            "decode_merge_quant_fp8: null pointer");
+  SGL_CHECK(!out_q || out_s, "decode_merge_quant_fp8: out_q needs out_s");
+  const int row = num_q_heads * v_head_dim;
+  SGL_CHECK(v_head_dim % 8 == 0 && row <= 16384, "decode_merge_quant_fp8: Hq*Dv=%d must be <= 16384 and Dv a multiple of 8", row);
+  SGL_CHECK(dtype == SGL_BF16 || dtype == SGL_F16, "decode_merge_quant_fp8: dtype must be bf16 or f16");
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_HALF(dtype, {
+    if (row <= 8192)
+      hipLaunchKernelGGL((decode_merge_quant_kernel<T, 4>), dim3(batch), dim3(256), 0, st, attn_logits, attn_lse, kv_indptr,
+                         seq_lens, num_kv_splits, max_kv_splits, num_q_heads, v_head_dim, (T*)out_o, (uint8_t*)out_q, out_s);
+    else
+      hipLaunchKernelGGL((decode_merge_quant_kernel<T, 8>), dim3(batch), dim3(256), 0, st, attn_logits, attn_lse, kv_indptr,
+                         seq_lens, num_kv_splits, max_kv_splits, num_q_heads, v_head_dim, (T*)out_o, (uint8_t*)out_q, out_s);
+  })
+  SGL_HIP_LAUNCH_CHECK();
+  return SGL_MI355_OK;
+}
+
+extern "C" int sgl_mi355_argmax_vec(int64_t* out, const void* logits, int64_t rows, int64_t vocab, int64_t row_stride,
+                                    int dtype, void* stream) {
+  SGL_CHECK(rows >= 0 && vocab > 0, "argmax: bad shape");
+  if (rows == 0) return SGL_MI355_OK;
+  SGL_CHECK(out && logits, "argmax: null pointer");
+  SGL_CHECK(dtype == SGL_BF16 || dtype == SGL_F16, "argmax_vec: dtype must be bf16 or f16");
+  SGL_CHECK(row_stride % 8 == 0 && ((uintptr_t)logits % 16) == 0, "argmax_vec: rows must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_HALF(dtype, {
+    hipLaunchKernelGGL((argmax_vec_kernel<T>), dim3((unsigned)rows), dim3(1024), 0, st, out, (const T*)logits, vocab, row_stride);
+  })
+  SGL_HIP_LAUNCH_CHECK();
+  return SGL_MI355_OK;
+}

@@ -215,7 +215,9 @@ __global__ __launch_bounds__(kV2Waves * 64, 2) void skinny_gemm_v2_kernel(const 
   const bool has_bias = p.bias != nullptr;
   const OutT* biasp = has_bias ? (const OutT*)p.bias : (const OutT*)p.w;  // any readable address when absent
   float sxv = 1.0f;
-  if constexpr (SCALED) sxv = p.sx[min(em, p.M - 1)];
+  if constexpr (SCALED) {
+    if (slabs == nullptr) sxv = p.sx[min(em, p.M - 1)];  // slab mode leaves the scales to the consumer kernel
+  }
 
   const unsigned wbytes = (unsigned)min((int64_t)p.N * p.w_stride, (int64_t)0xFFFFFFF0ll);
   const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, wbytes, 0x00020000);
@@ -459,4 +461,27 @@ extern "C" int sgl_mi355_skinny_gemm(const void* x, int64_t x_stride_elems, cons
                                  : launch_mt<ES_BF16, _Float16>(p, workspace, workspace_floats, st);
   return out_dtype == SGL_BF16 ? launch_mt<ES_F16, __bf16>(p, workspace, workspace_floats, st)
                                : launch_mt<ES_F16, _Float16>(p, workspace, workspace_floats, st);
+}
+
+// Raw split-K partial sums only: slabs f32 [kranges, M, N] (kranges = sgl_mi355_skinny_gemm_num_kranges), no scales;
+// the consumer kernel (sgl_mi355_fused_add_rmsnorm_quant_fp8 with slabs) combines them at its own launch boundary.
+extern "C" int sgl_mi355_skinny_gemm_slabs(const void* x, int64_t x_stride_elems, const void* w, int64_t w_stride_elems,
+                                           float* slabs, int M, int N, int K, int in_dtype, void* stream) {
+  SGL_CHECK(M > 0 && M <= 32 && N > 0 && K > 0, "skinny_gemm_slabs: needs 0 < M <= 32");
+  SGL_CHECK(x && w && slabs, "skinny_gemm_slabs: null pointer");
+  SGL_CHECK(in_dtype == SGL_FP8_E4M3, "skinny_gemm_slabs: fp8 only");
+  SGL_CHECK(K % 64 == 0 && x_stride_elems % 16 == 0 && w_stride_elems % 16 == 0 && ((uintptr_t)x % 16) == 0 &&
+                ((uintptr_t)w % 16) == 0 && (int64_t)N * w_stride_elems < 0xFFFFFFF0ll,
+            "skinny_gemm_slabs: unsupported shape/alignment (K=%d)", K);
+  SkinnyParams p;
+  p.x = (const char*)x; p.x_stride = x_stride_elems;
+  p.w = (const char*)w; p.w_stride = w_stride_elems;
+  p.y = nullptr; p.y_stride = 0;
+  p.sx = nullptr; p.sw = nullptr; p.bias = nullptr;  // slab mode never reads scales or bias
+  p.M = M; p.N = N; p.K = K; p.kbytes = K;
+  const int ds = K <= 1024 ? 2 : (K <= 2048 ? 4 : (K <= 4096 ? 8 : 16));
+  const int range = kV2Waves * ds * 64;
+  const int kranges = (K + range - 1) / range;
+  hipStream_t st = (hipStream_t)stream;
+  return M <= 16 ? launch_v2_ds<ES_FP8, 1, __bf16>(p, ds, kranges, slabs, st) : launch_v2_ds<ES_FP8, 2, __bf16>(p, ds, kranges, slabs, st);
 }

@@ -13,9 +13,11 @@ from .elementwise import (
     rmsnorm,
     silu_and_mul,
 )
+from .fused import decode_merge_quant_fp8, fused_add_rmsnorm_quant_fp8, rope_set_kv, silu_and_mul_quant_fp8
 from .gemm import (
     awq_dequantize,
     dense_linear,
+    fp8_linear_slabs,
     fp8_scaled_mm,
     sgl_per_tensor_quant_fp8,
     sgl_per_token_group_quant_fp8,

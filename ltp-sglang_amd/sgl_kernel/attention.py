@@ -53,6 +53,7 @@ def decode_attention_fwd(
     o [bs, Hq, Dv]; attn_logits f32 [bs, Hq, max_kv_splits, Dv]; attn_lse f32 [bs, Hq, max_kv_splits].
     """
     _require_cuda(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, attn_logits, attn_lse, num_kv_splits)
+    # o may be None: only the split partials (attn_logits / attn_lse) are produced and the caller merges them
     assert max_kv_splits == attn_logits.shape[2]
     assert q.shape[0] <= kv_indptr.shape[0] - 1
     assert q.shape[0] <= attn_logits.shape[0]
@@ -62,13 +63,13 @@ def decode_attention_fwd(
     bs, hq, d = q.shape
     hkv, dv = v_buffer.shape[1], v_buffer.shape[2]
     assert q.stride(2) == 1 and q.stride(1) == d, "q must be [bs, Hq, D] with contiguous heads"
-    assert o.stride(2) == 1 and o.stride(1) == dv
-    assert q.dtype == k_buffer.dtype == v_buffer.dtype == o.dtype
+    assert o is None or (o.stride(2) == 1 and o.stride(1) == dv and o.dtype == q.dtype)
+    assert q.dtype == k_buffer.dtype == v_buffer.dtype
     kst, ksh = _row_strides(k_buffer)
     vst, vsh = _row_strides(v_buffer)
     check(
         lib.sgl_mi355_decode_attention(
-            ptr(q), q.stride(0), ptr(k_buffer), ptr(v_buffer), kst, ksh, vst, vsh, ptr(o), o.stride(0),
+            ptr(q), q.stride(0), ptr(k_buffer), ptr(v_buffer), kst, ksh, vst, vsh, ptr(o), 0 if o is None else o.stride(0),
             ptr(kv_indptr), ptr(kv_indices), None, 0, None, None,
             ptr(attn_logits), ptr(attn_lse), ptr(num_kv_splits), int(max_kv_splits),
             bs, hq, hkv, d, dv, float(sm_scale), float(logit_cap), dtype_code(q.dtype), current_stream(),

@@ -63,6 +63,10 @@ def argmax(logits: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Te
     assert logits.dim() == 2 and logits.stride(1) == 1
     if out is None:
         out = torch.empty((logits.shape[0],), dtype=torch.int64, device=logits.device)
-    check(lib.sgl_mi355_argmax(ptr(out), ptr(logits), logits.shape[0], logits.shape[1], logits.stride(0),
-                               dtype_code(logits.dtype), current_stream()))
+    if logits.dtype in (torch.bfloat16, torch.float16) and logits.stride(0) % 8 == 0 and logits.data_ptr() % 16 == 0:
+        check(lib.sgl_mi355_argmax_vec(ptr(out), ptr(logits), logits.shape[0], logits.shape[1], logits.stride(0),
+                                       dtype_code(logits.dtype), current_stream()))
+    else:
+        check(lib.sgl_mi355_argmax(ptr(out), ptr(logits), logits.shape[0], logits.shape[1], logits.stride(0),
+                                   dtype_code(logits.dtype), current_stream()))
     return out

@@ -1,0 +1,64 @@
+"""Fused decode-step ops (no counterpart in the reference's op list: each equals a sequence of reference ops and is
+bit-identical to running this build's stand-alone kernels in that sequence)."""
+from typing import Optional, Tuple
+
+import torch
+
+from .._cabi import check, current_stream, dtype_code, lib, ptr
+
+
+def fused_add_rmsnorm_quant_fp8(x: Optional[torch.Tensor], residual: Optional[torch.Tensor], weight: torch.Tensor, eps: float,
+                                slabs: Optional[torch.Tensor] = None, slab_sx: Optional[torch.Tensor] = None,
+                                slab_sw: Optional[torch.Tensor] = None, want_norm: bool = False,
+                                want_quant: bool = True, dtype=None):
+    """residual += x (in place, if given); y = rmsnorm(sum) * weight; returns (y or None, y_q fp8, y_scale [M,1]).
+    ``slabs`` [S, M, H] f32 replaces x by the fused split-K combine ((sum_s slabs) * slab_sx[m] * slab_sw[n])."""
+    if slabs is not None:
+        _, m, h = slabs.shape
+        dt = dtype or weight.dtype
+        dev = slabs.device
+    else:
+        m, h = x.shape
+        dt, dev = x.dtype, x.device
+        assert x.is_contiguous()
+    out_norm = torch.empty((m, h), dtype=dt, device=dev) if want_norm else None
+    out_q = torch.empty((m, h), dtype=torch.float8_e4m3fn, device=dev) if want_quant else None
+    out_s = torch.empty((m, 1), dtype=torch.float32, device=dev) if want_quant else None
+    check(lib.sgl_mi355_fused_add_rmsnorm_quant_fp8(ptr(x), ptr(slabs), 0 if slabs is None else slabs.shape[0], ptr(slab_sx),
+                                                    ptr(slab_sw), ptr(residual), ptr(weight), float(eps), ptr(out_norm),
+                                                    ptr(out_q), ptr(out_s), m, h, dtype_code(dt), current_stream()))
+    return out_norm, out_q, out_s
+
+
+def silu_and_mul_quant_fp8(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    m, d2 = x.shape
+    d = d2 // 2
+    assert x.is_contiguous()
+    out_q = torch.empty((m, d), dtype=torch.float8_e4m3fn, device=x.device)
+    out_s = torch.empty((m, 1), dtype=torch.float32, device=x.device)
+    check(lib.sgl_mi355_silu_and_mul_quant_fp8(ptr(x), ptr(out_q), ptr(out_s), m, d, dtype_code(x.dtype), current_stream()))
+    return out_q, out_s
+
+
+def rope_set_kv(positions, query, key, value, head_size, cos_sin_cache, is_neox, k_buffer, v_buffer, loc) -> None:
+    """query [T, Hq*hs], key [T, Hk*hs] rotated in place; (rotated key, value) written to the pool rows ``loc``."""
+    t = positions.numel()
+    q2, k2, v2 = query.view(t, -1), key.view(t, -1), value.view(t, -1)
+    assert q2.stride(1) == 1 and k2.stride(1) == 1 and v2.stride(1) == 1 and loc.dtype == torch.int64
+    assert k_buffer[0].is_contiguous() and v_buffer[0].is_contiguous() and cos_sin_cache.dtype == torch.float32
+    check(lib.sgl_mi355_rope_set_kv(ptr(positions), ptr(q2), ptr(k2), ptr(v2), ptr(cos_sin_cache), ptr(k_buffer), ptr(v_buffer),
+                                    ptr(loc), t, q2.shape[1] // head_size, k2.shape[1] // head_size, head_size,
+                                    cos_sin_cache.shape[1], q2.stride(0), k2.stride(0), v2.stride(0), k_buffer.stride(0),
+                                    v_buffer.stride(0), int(bool(is_neox)), dtype_code(query.dtype), current_stream()))
+
+
+def decode_merge_quant_fp8(attn_logits, attn_lse, kv_indptr, num_kv_splits, max_kv_splits, dtype, want_o=False):
+    bs, hq, _, dv = attn_logits.shape
+    dev = attn_logits.device
+    out_o = torch.empty((bs, hq * dv), dtype=dtype, device=dev) if want_o else None
+    out_q = torch.empty((bs, hq * dv), dtype=torch.float8_e4m3fn, device=dev)
+    out_s = torch.empty((bs, 1), dtype=torch.float32, device=dev)
+    check(lib.sgl_mi355_decode_merge_quant_fp8(ptr(attn_logits), ptr(attn_lse), ptr(kv_indptr), None, ptr(num_kv_splits),
+                                               int(max_kv_splits), bs, hq, dv, ptr(out_o), ptr(out_q), ptr(out_s),
+                                               dtype_code(dtype), current_stream()))
+    return out_o, out_q, out_s

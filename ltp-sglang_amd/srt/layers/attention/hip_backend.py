@@ -179,5 +179,19 @@ class HipAttnBackend(AttentionBackend):
         )
         return o
 
+    def forward_decode_partial(self, q, layer, forward_batch):
+        """Stage 1 only (the caller has already written K/V and will merge the split partials itself, e.g. fused with
+        the next op's quantisation): returns the ForwardMetadata holding attn_logits / attn_lse / num_kv_splits."""
+        self._check_layer(layer)
+        md = self.forward_metadata
+        K.decode_attention_fwd(
+            q.reshape(-1, layer.tp_q_head_num, layer.qk_head_dim),
+            forward_batch.token_to_kv_pool.get_key_buffer(layer.layer_id),
+            forward_batch.token_to_kv_pool.get_value_buffer(layer.layer_id),
+            None, md.kv_indptr, md.kv_indices, md.attn_logits, md.attn_lse, md.num_kv_splits, self.max_kv_splits,
+            layer.scaling, layer.logit_cap,
+        )
+        return md
+
     def support_triton(self):
         return False  # the host helpers use this build's HIP index kernels, never Triton

@@ -131,6 +131,7 @@ class LlamaForCausalLM(nn.Module):
     def __init__(self, cfg: LlamaShape, quantization: Optional[str], dtype=torch.bfloat16):
         super().__init__()
         self.cfg, self.dtype = cfg, dtype
+        self.fused_decode = True
         qc = None
         if quantization is not None:
             cls = get_quantization_config(quantization)
@@ -181,7 +182,54 @@ class LlamaForCausalLM(nn.Module):
                     mod.bias.copy_(randn(mod.bias.shape))
             qm.process_weights_after_loading(mod)
 
+    def _fused_decode_ok(self, forward_batch) -> bool:
+        return (self.fused_decode and forward_batch.forward_mode.is_decode() and self.tp_size == 1
+                and self.quant_config is not None and self.quant_config.get_name() == "w8a8_fp8"
+                and forward_batch.batch_size <= 32 and self.cfg.hidden_size <= 8192)
+
+    def forward_decode_fused(self, input_ids, positions, forward_batch: ForwardBatch):
+        """The same decode step with the elementwise work fused into 4 kernels per layer (sgl_kernel/fused.py) and the
+        down_proj split-K combine folded into the next layer's RMSNorm.  Every fused kernel is bit-identical to the op
+        sequence it replaces, so this path and forward() give the same logits."""
+        pool = forward_batch.token_to_kv_pool
+        backend = forward_batch.attn_backend
+        m = input_ids.numel()
+        hidden = K.embedding(input_ids, self.embed_tokens)
+        residual, slabs, slab_sx, slab_sw = None, None, None, None
+        for layer in self.layers:
+            attn, mlp = layer.self_attn, layer.mlp
+            ln1 = layer.input_layernorm
+            if slabs is None:
+                _, xq, xs = K.fused_add_rmsnorm_quant_fp8(hidden, None, ln1.weight.data, ln1.variance_epsilon)
+                residual = hidden
+            else:
+                _, xq, xs = K.fused_add_rmsnorm_quant_fp8(None, residual, ln1.weight.data, ln1.variance_epsilon, slabs=slabs,
+                                                          slab_sx=slab_sx, slab_sw=slab_sw, dtype=self.dtype)
+            qkv = K.fp8_scaled_mm(xq, attn.qkv_proj.weight, xs.view(-1), attn.qkv_proj.weight_scale.view(-1), self.dtype,
+                                  attn.qkv_proj.bias)
+            q, k, v = qkv.split([attn.q_size, attn.kv_size, attn.kv_size], dim=-1)
+            lid = attn.attn.layer_id
+            K.rope_set_kv(positions, q, k, v, attn.head_dim, attn.rotary_emb.cos_sin_cache, True, pool.get_key_buffer(lid),
+                          pool.get_value_buffer(lid), forward_batch.out_cache_loc)
+            md = backend.forward_decode_partial(q, attn.attn, forward_batch)
+            _, oq, osc = K.decode_merge_quant_fp8(md.attn_logits, md.attn_lse, md.kv_indptr, md.num_kv_splits,
+                                                  backend.max_kv_splits, self.dtype)
+            attn_out = K.fp8_scaled_mm(oq, attn.o_proj.weight, osc.view(-1), attn.o_proj.weight_scale.view(-1), self.dtype)
+            ln2 = layer.post_attention_layernorm
+            _, hq2, hs2 = K.fused_add_rmsnorm_quant_fp8(attn_out, residual, ln2.weight.data, ln2.variance_epsilon)
+            gate_up = K.fp8_scaled_mm(hq2, mlp.gate_up_proj.weight, hs2.view(-1), mlp.gate_up_proj.weight_scale.view(-1), self.dtype)
+            aq, asc = K.silu_and_mul_quant_fp8(gate_up)
+            wd = mlp.down_proj.weight  # [K, N] column-major view of the [N, K] parameter
+            slabs = K.fp8_linear_slabs(aq, wd.t(), m, wd.shape[1], wd.shape[0])
+            slab_sx, slab_sw = asc.view(-1), mlp.down_proj.weight_scale.view(-1)
+        hidden, _, _ = K.fused_add_rmsnorm_quant_fp8(None, residual, self.norm.weight.data, self.norm.variance_epsilon, slabs=slabs,
+                                                     slab_sx=slab_sx, slab_sw=slab_sw, want_norm=True, want_quant=False,
+                                                     dtype=self.dtype)
+        return K.dense_linear(hidden, self.lm_head, None, out_dtype=self.dtype)
+
     def forward(self, input_ids, positions, forward_batch: ForwardBatch, last_index: Optional[torch.Tensor] = None):
+        if self._fused_decode_ok(forward_batch):
+            return self.forward_decode_fused(input_ids, positions, forward_batch)
         hidden_states = K.embedding(input_ids, self.embed_tokens)
         residual = None
         for layer in self.layers:

@@ -281,3 +281,109 @@ def test_dense_gemm_large_m(dtype, sk):
     ref = x.float() @ w.float().t()
     tol = 3e-2 if dtype == torch.bfloat16 else 4e-3
     assert (o.cpu().float() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+
+
+# ---------------------------------------------------------------- fused decode kernels == their unfused op sequences
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("with_res", [True, False])
+def test_fused_add_rmsnorm_quant_bit_exact(dtype, with_res, sk):
+    g = torch.Generator().manual_seed(17)
+    m, h = 9, 4096
+    x = torch.randn(m, h, generator=g).to(dtype).to(DEV)
+    res = torch.randn(m, h, generator=g).to(dtype).to(DEV)
+    w = (1 + 0.1 * torch.randn(h, generator=g)).to(dtype).to(DEV)
+    # unfused reference sequence on this build's own kernels
+    x1, r1 = x.clone(), res.clone()
+    if with_res:
+        sk.fused_add_rmsnorm(x1, r1, w, 1e-5)
+    else:
+        x1 = sk.rmsnorm(x1, w, 1e-5)
+    q1 = torch.empty(m, h, dtype=torch.float8_e4m3fn, device=DEV)
+    s1 = torch.empty(m, 1, dtype=torch.float32, device=DEV)
+    sk.sgl_per_token_quant_fp8(x1, q1, s1)
+    r2 = res.clone()
+    y2, q2, s2 = sk.fused_add_rmsnorm_quant_fp8(x.clone(), r2 if with_res else None, w, 1e-5, want_norm=True)
+    assert torch.equal(y2, x1) and torch.equal(s1, s2) and torch.equal(q1.view(torch.uint8), q2.view(torch.uint8))
+    if with_res:
+        assert torch.equal(r1, r2)
+    # and the oracle
+    yo = oe.rmsnorm(x.cpu(), w.cpu(), 1e-5, res.cpu() if with_res else None)
+    yo = yo[0] if with_res else yo
+    ulp = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+    torch.testing.assert_close(y2.cpu().float(), yo.float(), rtol=ulp, atol=ulp)
+
+
+def test_fused_rmsnorm_from_splitk_slabs_bit_exact(sk, pkg):
+    """down_proj (K = 14336: two k-ranges) -> next layer's fused_add_rmsnorm_quant reading the f32 slabs directly
+    == fp8_scaled_mm (slabs + reduce kernel) -> fused_add_rmsnorm -> per-token quant."""
+    from ltp_sglang_amd._cabi import check, current_stream, dtype_code, lib, ptr
+
+    c = _cases.build_gemm_case(dict(m=32, n=512, k=14336, bias=False, out="bf16"), seed=5)
+    a, wt, sa, sb = c["a"].to(DEV), c["w"].to(DEV), c["sa"].to(DEV).abs() + 1e-4, c["sb"].to(DEV).abs() + 1e-4
+    g = torch.Generator().manual_seed(3)
+    res = torch.randn(32, 512, generator=g).bfloat16().to(DEV)
+    nw = (1 + 0.1 * torch.randn(512, generator=g)).bfloat16().to(DEV)
+    y = sk.fp8_scaled_mm(a, wt.t(), sa, sb, torch.bfloat16)
+    r1 = res.clone()
+    sk.fused_add_rmsnorm(y, r1, nw, 1e-5)
+    q1 = torch.empty(32, 512, dtype=torch.float8_e4m3fn, device=DEV)
+    s1 = torch.empty(32, 1, dtype=torch.float32, device=DEV)
+    sk.sgl_per_token_quant_fp8(y, q1, s1)
+    slabs = sk.fp8_linear_slabs(a, wt, 32, 512, 14336)
+    assert slabs.shape[0] == 2
+    r2 = res.clone()
+    y2, q2, s2 = sk.fused_add_rmsnorm_quant_fp8(None, r2, nw, 1e-5, slabs=slabs, slab_sx=sa, slab_sw=sb, want_norm=True)
+    assert torch.equal(r1, r2) and torch.equal(y, y2) and torch.equal(s1, s2) and torch.equal(q1.view(torch.uint8), q2.view(torch.uint8))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_silu_and_mul_quant_bit_exact(dtype, sk):
+    x = (torch.randn(5, 2 * 14336, generator=torch.Generator().manual_seed(2)) * 2).to(dtype).to(DEV)
+    act = sk.silu_and_mul(x)
+    q1 = torch.empty(5, 14336, dtype=torch.float8_e4m3fn, device=DEV)
+    s1 = torch.empty(5, 1, dtype=torch.float32, device=DEV)
+    sk.sgl_per_token_quant_fp8(act, q1, s1)
+    q2, s2 = sk.silu_and_mul_quant_fp8(x)
+    assert torch.equal(s1, s2) and torch.equal(q1.view(torch.uint8), q2.view(torch.uint8))
+
+
+@pytest.mark.parametrize("case", _cases.ROPE_CASES, ids=lambda c: c["name"])
+def test_rope_set_kv_bit_exact(case, sk, golden):
+    g = golden("elementwise")
+    c = _cases.build_rope_case(case)
+    t, hk, hs = case["t"], case["hk"], case["hs"]
+    cache = torch.zeros(4096, case["rot"], dtype=torch.float32)
+    cache[c["positions"]] = torch.from_numpy(g[case["name"] + ".cache_rows"])
+    q, k = c["q"].to(DEV), c["k"].to(DEV)
+    v = torch.randn(t, hk * hs, generator=torch.Generator().manual_seed(1)).to(q.dtype).to(DEV)
+    kb = torch.zeros(50, hk, hs, dtype=q.dtype, device=DEV)
+    vb = torch.zeros(50, hk, hs, dtype=q.dtype, device=DEV)
+    loc = (torch.randperm(49, generator=torch.Generator().manual_seed(2))[:t] + 1).to(DEV)
+    sk.rope_set_kv(c["positions"].to(DEV), q, k, v, hs, cache.to(DEV), case["neox"], kb, vb, loc)
+    assert np.array_equal(_cases.bits16(q.cpu()), g[case["name"] + ".q"])
+    assert np.array_equal(_cases.bits16(k.cpu()), g[case["name"] + ".k"])
+    assert torch.equal(kb[loc].reshape(t, -1), k) and torch.equal(vb[loc].reshape(t, -1), v)
+    untouched = torch.ones(50, dtype=torch.bool)
+    untouched[loc.cpu()] = False
+    assert not kb[untouched.to(DEV)].any() and not vb[untouched.to(DEV)].any()
+
+
+def test_decode_merge_quant_bit_exact(sk):
+    case = dict(name="mq", kind="decode", dtype="bf16", hq=32, hkv=8, d=128, seq=[1, 33, 300, 129])
+    c = _cases.build_attn_case(case, seed=9)
+    bs, hq, d = c["bs"], c["hq"], c["d"]
+    seq = c["seq_lens"]
+    kv_indptr = torch.zeros(bs + 1, dtype=torch.int32)
+    kv_indptr[1:] = torch.cumsum(seq, 0)
+    kv_indices = torch.cat([c["req_to_token"][c["req_pool_indices"][i], : int(seq[i])] for i in range(bs)]).int()
+    o = torch.empty(bs, hq, d, dtype=c["dtype"], device=DEV)
+    logits = torch.zeros(bs, hq, 8, d, dtype=torch.float32, device=DEV)
+    lse = torch.zeros(bs, hq, 8, dtype=torch.float32, device=DEV)
+    splits = torch.tensor([1, 2, 8, 3], dtype=torch.int32, device=DEV)
+    sk.decode_attention_fwd(c["q"].to(DEV), c["k_buffer"].to(DEV), c["v_buffer"].to(DEV), o, kv_indptr.to(DEV),
+                            kv_indices.to(DEV), logits, lse, splits, 8, c["scaling"])
+    q1 = torch.empty(bs, hq * d, dtype=torch.float8_e4m3fn, device=DEV)
+    s1 = torch.empty(bs, 1, dtype=torch.float32, device=DEV)
+    sk.sgl_per_token_quant_fp8(o.view(bs, -1), q1, s1)
+    o2, q2, s2 = sk.decode_merge_quant_fp8(logits, lse, kv_indptr.to(DEV), splits, 8, c["dtype"], want_o=True)
+    assert torch.equal(o2, o.view(bs, -1)) and torch.equal(s1, s2) and torch.equal(q1.view(torch.uint8), q2.view(torch.uint8))
