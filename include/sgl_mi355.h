@@ -188,6 +188,27 @@ int sgl_mi355_decode_merge_quant_fp8(const float* attn_logits, const float* attn
 int sgl_mi355_argmax_vec(int64_t* out, const void* logits, int64_t rows, int64_t vocab, int64_t row_stride, int dtype,
                          void* stream);
 
+/* ---- native radix tree for RadixAttention prefix sharing (host side, bit-exact slot indices) ------------------ */
+/* python/sglang/srt/mem_cache/radix_cache.py:43-555 (TreeNode, RadixCache._match_prefix_helper / _split_node /
+ * _insert_helper / evict / inc_lock_ref / dec_lock_ref); keys are token ids, values KV slot indices, both int64.
+ * page_size > 1 matches whole pages (:111-120).  Node handles are int64 ids. */
+void* sgl_mi355_radix_create(int page_size);
+int sgl_mi355_radix_destroy(void* tree);
+int sgl_mi355_radix_reset(void* tree);
+int64_t sgl_mi355_radix_root(void* tree);
+int64_t sgl_mi355_radix_match_prefix(void* tree, const int64_t* key, int64_t key_len, int64_t* out_values, int64_t out_cap,
+                                     int64_t* last_node);
+int64_t sgl_mi355_radix_insert(void* tree, const int64_t* key, const int64_t* values, int64_t len);
+int64_t sgl_mi355_radix_evict(void* tree, int64_t num_tokens, int64_t* out_values, int64_t out_cap, int64_t* out_node_lens,
+                              int64_t lens_cap, int64_t* n_nodes);
+int64_t sgl_mi355_radix_inc_lock_ref(void* tree, int64_t node);
+int64_t sgl_mi355_radix_dec_lock_ref(void* tree, int64_t node);
+int64_t sgl_mi355_radix_evictable_size(void* tree);
+int64_t sgl_mi355_radix_protected_size(void* tree);
+int64_t sgl_mi355_radix_total_size(void* tree);
+int64_t sgl_mi355_radix_num_nodes(void* tree);
+int64_t sgl_mi355_radix_node_info(void* tree, int64_t node, int64_t* parent, int64_t* lock_ref, int64_t* num_children);
+
 /* out[cols, rows] = in[rows, cols]^T for 16-bit elements (weight re-layout between awq_dequantize's [K, N] and
  * the [N, K] the GEMMs stream; AWQLinearMethod.apply, layers/quantization/awq.py:401-418) */
 int sgl_mi355_transpose_2d(void* out, const void* in, int rows, int cols, void* stream);

@@ -23,7 +23,7 @@ def parse_header(path=HEADER_PATH):
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     text = re.sub(r"//[^\n]*", "", text)
     protos = []
-    for m in re.finditer(r"\n\s*(const char\*|int)\s+(sgl_mi355_\w+)\s*\(([^)]*)\)\s*;", text):
+    for m in re.finditer(r"\n\s*(const char\*|void\*|int64_t|int)\s+(sgl_mi355_\w+)\s*\(([^)]*)\)\s*;", text):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
         argtypes = []
         if args and args != "void":
@@ -39,7 +39,8 @@ def parse_header(path=HEADER_PATH):
                     argtypes.append(c_float)
                 else:
                     raise RuntimeError(f"{name}: cannot map C parameter '{a}'")
-        protos.append((name, c_char_p if ret.startswith("const char") else c_int, argtypes))
+        restype = {"const char*": c_char_p, "void*": c_void_p, "int64_t": c_int64, "int": c_int}[ret]
+        protos.append((name, restype, argtypes))
     return protos
 
 

@@ -247,3 +247,104 @@ def build_rope_case(case, seed=0):
     k = _randn(rng, (case["t"], case["hk"] * case["hs"]), dt)
     positions = torch.from_numpy(rng.randint(0, 4096, size=case["t"]).astype(np.int64))
     return dict(q=q, k=k, positions=positions)
+
+
+# ----------------------------------------------------------------------------------------------
+# radix-cache / allocator scripts: the SAME seeded script is run against the reference classes (golden generator),
+# the oracle and the product classes; every observable (indices, lengths, freed slots, counters) is recorded.
+# ----------------------------------------------------------------------------------------------
+def radix_primitive_script(make_cache, free_log, seed=0, n_ops=120, page_size=1):
+    """Random match / insert / lock / evict sequence over keys with heavy prefix sharing.
+    make_cache() -> cache object exposing match_prefix(key)->(indices, node), insert(key, values)->int,
+    inc_lock_ref(node), dec_lock_ref(node), evict(n), evictable_size(), protected_size(), total_size().
+    free_log: list that the cache's allocator appends freed index lists to."""
+    rng = np.random.RandomState(seed)
+    cache = make_cache()
+    stems = [list(rng.randint(0, 50, size=rng.randint(4, 24) * page_size)) for _ in range(4)]
+    next_slot = [1]
+    locked, trace = [], []
+
+    def new_key():
+        stem = stems[rng.randint(len(stems))]
+        cut = rng.randint(1, len(stem) // page_size + 1) * page_size
+        tail = list(rng.randint(0, 50, size=rng.randint(0, 6) * page_size))
+        return [int(x) for x in stem[:cut] + tail]
+
+    for _ in range(n_ops):
+        op = rng.choice(["match", "insert", "insert", "lock", "unlock", "evict"])
+        if op == "match":
+            key = new_key()
+            idx, node = cache.match_prefix(key)
+            trace.append(("match", [int(x) for x in idx]))
+        elif op == "insert":
+            key = new_key()
+            vals = list(range(next_slot[0], next_slot[0] + len(key)))
+            next_slot[0] += len(key)
+            trace.append(("insert", int(cache.insert(key, vals))))
+        elif op == "lock":
+            key = new_key()
+            idx, node = cache.match_prefix(key)
+            trace.append(("lock", [int(x) for x in idx], int(cache.inc_lock_ref(node))))
+            locked.append(node)
+        elif op == "unlock" and locked:
+            node = locked.pop(rng.randint(len(locked)))
+            trace.append(("unlock", int(cache.dec_lock_ref(node))))
+        elif op == "evict":
+            before = len(free_log)
+            cache.evict(int(rng.randint(1, 30)))
+            trace.append(("evict", [list(map(int, f)) for f in free_log[before:]]))
+        trace.append(("sizes", int(cache.evictable_size()), int(cache.protected_size()), int(cache.total_size())))
+    return trace
+
+
+def radix_request_script(make_env, seed=0, n_reqs=12, shared_prefix=40, page_size=1):
+    """Shared-prefix serving scenario (BASELINE configs[2] in miniature) through the request-level API:
+    match_prefix -> alloc -> write req_to_token -> lock -> cache_unfinished_req (chunk) -> decode tokens ->
+    cache_finished_req, with an eviction in the middle.  make_env() -> (cache, req_to_token_pool, allocator, SimpleReq)."""
+    from types import SimpleNamespace
+
+    rng = np.random.RandomState(seed + 7)
+    cache, r2t_pool, alloc = make_env()
+    prefix = [int(x) for x in rng.randint(0, 1000, size=shared_prefix)]
+    trace = []
+    live = []
+    for i in range(n_reqs):
+        uniq = [int(x) for x in rng.randint(0, 1000, size=int(rng.randint(3, 20)))]
+        ids = prefix + uniq
+        res = cache.match_prefix(ids[:-1] if len(ids) > 1 else ids)
+        prefix_indices, last_node = res[0], res[1]
+        req = SimpleNamespace(origin_input_ids=ids, output_ids=[], fill_ids=list(ids), prefix_indices=prefix_indices,
+                              last_node=last_node, req_pool_idx=r2t_pool.alloc(1)[0])
+        cache.inc_lock_ref(last_node)
+        n_new = len(ids) - len(prefix_indices)
+        loc = alloc.alloc(n_new)
+        if loc is None:
+            cache.evict(n_new)
+            loc = alloc.alloc(n_new)
+        r2t_pool.write((req.req_pool_idx, slice(0, len(prefix_indices))), prefix_indices.to(torch.int32))
+        r2t_pool.write((req.req_pool_idx, slice(len(prefix_indices), len(ids))), loc.to(torch.int32))
+        trace.append(("extend", i, [int(x) for x in prefix_indices], [int(x) for x in loc]))
+        cache.cache_unfinished_req(req)
+        trace.append(("unfinished", i, [int(x) for x in req.prefix_indices]))
+        live.append(req)
+        if i % 4 == 3:  # finish the two oldest after a few decode steps
+            for req in live[:2]:
+                for _ in range(int(rng.randint(1, 5))):
+                    tok = int(rng.randint(0, 1000))
+                    slot = alloc.alloc(1)
+                    seq = len(req.origin_input_ids) + len(req.output_ids)
+                    r2t_pool.write((req.req_pool_idx, seq), slot.to(torch.int32))
+                    req.output_ids.append(tok)
+                    trace.append(("decode", int(slot[0])))
+                cache.cache_finished_req(req)
+            live = live[2:]
+            cache.evict(int(rng.randint(5, 25)))
+        trace.append(("sizes", int(cache.evictable_size()), int(cache.protected_size()), int(cache.total_size()),
+                      int(alloc.available_size())))
+    for req in live:
+        req.output_ids.append(0)
+        cache.cache_finished_req(req)
+    cache.evict(10 ** 6)
+    alloc.merge_and_sort_free()
+    trace.append(("final_free", [int(x) for x in alloc.free_pages]))
+    return trace

@@ -239,6 +239,47 @@ def gen_elementwise():
     print("elementwise.npz", len(out), "arrays")
 
 
+def gen_radix():
+    import json
+
+    from sglang.srt.mem_cache.allocator import TokenToKVPoolAllocator
+    from sglang.srt.mem_cache.memory_pool import ReqToTokenPool
+    from sglang.srt.mem_cache.radix_cache import RadixCache
+
+    out = {}
+    for page_size in (1, 4):
+        for seed in (0, 1, 2):
+            free_log = []
+            fake_alloc = type("A", (), {"device": "cpu", "free": lambda self, idx: free_log.append([int(x) for x in idx])})()
+
+            class Adapter:
+                def __init__(self):
+                    self.c = RadixCache(None, fake_alloc, page_size=page_size)
+
+                def match_prefix(self, key):
+                    r = self.c.match_prefix(key)
+                    return (torch.cat([torch.as_tensor(v) for v in [r.device_indices]]).tolist(), r.last_device_node)
+
+                def insert(self, key, vals):
+                    return self.c.insert(key, torch.tensor(vals, dtype=torch.int64))
+
+                def __getattr__(self, n):
+                    return getattr(self.c, n)
+
+            out[f"prim_p{page_size}_s{seed}"] = _cases.radix_primitive_script(Adapter, free_log, seed=seed, page_size=page_size)
+
+    def env():
+        pool = ReqToTokenPool(32, 256, "cpu", False)
+        alloc = TokenToKVPoolAllocator(600, torch.bfloat16, "cpu", None)
+        return RadixCache(pool, alloc, page_size=1), pool, alloc
+
+    for seed in (0, 1):
+        out[f"req_s{seed}"] = _cases.radix_request_script(env, seed=seed)
+    with open(os.path.join(HERE, "radix.json"), "w") as f:
+        json.dump(out, f, separators=(",", ":"))
+    print("radix.json", {k: len(v) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     torch.manual_seed(0)
