@@ -99,6 +99,15 @@ int sgl_mi355_decode_metadata(int32_t* kv_indptr, int32_t* num_kv_splits, const 
                               int num_seq, int num_group, int num_head, int num_kv_head, int max_kv_splits,
                               int device_core_count, int static_splits, void* stream);
 
+/* alloc_extend_kernel / alloc_decode_kernel of PagedTokenToKVPoolAllocator, mem_cache/allocator.py:275-395:
+ * page-aligned slot assignment; ret_values[0] = (new pages << 32 | extend tokens) resp. new pages. */
+int sgl_mi355_alloc_extend(const void* prefix_lens, int prefix_is64, const void* seq_lens, int seq_is64,
+                           const void* last_loc, int last_loc_is64, const int64_t* free_pages, int64_t* out_indices,
+                           int64_t* ret_values, int page_size, int batch, void* stream);
+int sgl_mi355_alloc_decode(const void* seq_lens, int seq_is64, const void* last_loc, int last_loc_is64,
+                           const int64_t* free_pages, int64_t* out_indices, int64_t* ret_values, int page_size, int batch,
+                           void* stream);
+
 /* ---- fp8 activation quantisation (bit-exact with the reference's torch restatements) -------- */
 /* sgl_per_token_quant_fp8, sgl-kernel/csrc/gemm/per_token_quant_fp8.cu:15-228; python gemm.py:140-145 */
 int sgl_mi355_per_token_quant_fp8(const void* input, int64_t input_stride, void* output_q, float* output_s,

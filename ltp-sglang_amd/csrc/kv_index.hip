@@ -274,3 +274,107 @@ extern "C" int sgl_mi355_decode_metadata(int32_t* kv_indptr, int32_t* num_kv_spl
   SGL_HIP_LAUNCH_CHECK();
   return SGL_MI355_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Paged allocator index kernels (page_size > 1): bit-exact with alloc_extend_kernel / alloc_decode_kernel of
+// python/sglang/srt/mem_cache/allocator.py:275-395.  A request first fills the tail of its last partial page
+// (last_loc + 1 ...), then takes whole new pages from the free list, then a new partial page; the per-request offsets
+// into out_indices / free_pages are prefix sums over the batch (a workgroup reduction here, a serial walk there).
+// ret_values[0] = (sum of new pages << 32) | sum of extend tokens   (extend)   /   sum of new pages   (decode)
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+
+__device__ __forceinline__ int64_t cdivp(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+__global__ __launch_bounds__(256) void alloc_extend_kernel(const void* pre_lens, int pl64, const void* seq_lens, int sl64,
+                                                           const void* last_loc, int ll64, const int64_t* free_pages,
+                                                           int64_t* out_indices, int64_t* ret_values, int page_size, int bs) {
+  __shared__ int64_t red[4];
+  const int pid = blockIdx.x;
+  // prefix sums over requests before pid (extend tokens and new pages) and, for the last request, the batch totals
+  int64_t ext_before = 0, pages_before = 0;
+  for (int i = threadIdx.x; i < pid; i += 256) {
+    const int64_t s = ld_idx(seq_lens, i, sl64), p = ld_idx(pre_lens, i, pl64);
+    ext_before += s - p;
+    pages_before += cdivp(s, page_size) - cdivp(p, page_size);
+  }
+  for (int m = 32; m >= 1; m >>= 1) {
+    ext_before += __shfl_xor(ext_before, m, WAVE);
+    pages_before += __shfl_xor(pages_before, m, WAVE);
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ext_before;
+  __syncthreads();
+  ext_before = red[0] + red[1] + red[2] + red[3];
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = pages_before;
+  __syncthreads();
+  pages_before = red[0] + red[1] + red[2] + red[3];
+
+  const int64_t seq = ld_idx(seq_lens, pid, sl64), pre = ld_idx(pre_lens, pid, pl64);
+  const int64_t ext = seq - pre;
+  const int64_t pages_self = cdivp(seq, page_size) - cdivp(pre, page_size);
+  if (pid == bs - 1 && threadIdx.x == 0) ret_values[0] = ((pages_before + pages_self) << 32) | (ext_before + ext);
+
+  int64_t* out = out_indices + ext_before;
+  const int64_t last = ld_idx(last_loc, pid, ll64);
+  const int64_t pre_up = cdivp(pre, page_size) * page_size;
+  const int64_t part1 = (seq < pre_up ? seq : pre_up) - pre;  // tail of the old partial page
+  for (int64_t k = threadIdx.x; k < part1; k += 256) out[k] = last + 1 + k;
+  if (pre + part1 == seq) return;
+  const int64_t part2 = seq / page_size * page_size - pre_up;  // whole new pages
+  for (int64_t k = threadIdx.x; k < part2; k += 256)
+    out[part1 + k] = free_pages[pages_before + k / page_size] * page_size + k % page_size;
+  if (pre + part1 + part2 == seq) return;
+  const int64_t part3 = seq - seq / page_size * page_size;     // new partial page
+  const int64_t start_page = free_pages[pages_before + pages_self - 1];
+  for (int64_t k = threadIdx.x; k < part3; k += 256) out[part1 + part2 + k] = start_page * page_size + k;
+}
+
+__global__ __launch_bounds__(256) void alloc_decode_kernel(const void* seq_lens, int sl64, const void* last_loc, int ll64,
+                                                           const int64_t* free_pages, int64_t* out_indices,
+                                                           int64_t* ret_values, int page_size, int bs) {
+  __shared__ int64_t red[4];
+  const int pid = blockIdx.x;
+  int64_t pages_before = 0;
+  for (int i = threadIdx.x; i < pid; i += 256) {
+    const int64_t s = ld_idx(seq_lens, i, sl64);
+    pages_before += cdivp(s, page_size) - cdivp(s - 1, page_size);
+  }
+  for (int m = 32; m >= 1; m >>= 1) pages_before += __shfl_xor(pages_before, m, WAVE);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = pages_before;
+  __syncthreads();
+  pages_before = red[0] + red[1] + red[2] + red[3];
+  if (threadIdx.x != 0) return;
+  const int64_t seq = ld_idx(seq_lens, pid, sl64);
+  const int64_t pages_self = cdivp(seq, page_size) - cdivp(seq - 1, page_size);
+  if (pid == bs - 1) ret_values[0] = pages_before + pages_self;
+  out_indices[pid] = pages_self == 0 ? ld_idx(last_loc, pid, ll64) + 1 : free_pages[pages_before] * page_size;
+}
+
+}  // namespace
+
+extern "C" int sgl_mi355_alloc_extend(const void* prefix_lens, int prefix_is64, const void* seq_lens, int seq_is64,
+                                      const void* last_loc, int last_loc_is64, const int64_t* free_pages,
+                                      int64_t* out_indices, int64_t* ret_values, int page_size, int batch, void* stream) {
+  SGL_CHECK(batch >= 0 && page_size >= 1, "alloc_extend: bad batch/page_size");
+  if (batch == 0) return SGL_MI355_OK;
+  SGL_CHECK(prefix_lens && seq_lens && last_loc && free_pages && out_indices && ret_values, "alloc_extend: null pointer");
+  hipLaunchKernelGGL(alloc_extend_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, prefix_lens, prefix_is64, seq_lens,
+                     seq_is64, last_loc, last_loc_is64, free_pages, out_indices, ret_values, page_size, batch);
+  SGL_HIP_LAUNCH_CHECK();
+  return SGL_MI355_OK;
+}
+
+extern "C" int sgl_mi355_alloc_decode(const void* seq_lens, int seq_is64, const void* last_loc, int last_loc_is64,
+                                      const int64_t* free_pages, int64_t* out_indices, int64_t* ret_values, int page_size,
+                                      int batch, void* stream) {
+  SGL_CHECK(batch >= 0 && page_size >= 1, "alloc_decode: bad batch/page_size");
+  if (batch == 0) return SGL_MI355_OK;
+  SGL_CHECK(seq_lens && last_loc && free_pages && out_indices && ret_values, "alloc_decode: null pointer");
+  hipLaunchKernelGGL(alloc_decode_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, seq_lens, seq_is64, last_loc,
+                     last_loc_is64, free_pages, out_indices, ret_values, page_size, batch);
+  SGL_HIP_LAUNCH_CHECK();
+  return SGL_MI355_OK;
+}

@@ -71,3 +71,35 @@ def num_kv_splits(seq_lens, num_group, num_head, num_kv_head, max_kv_splits, dev
     c2 = cdiv(mx, s2)
     per = [max(cdiv(s, c1), cdiv(s, c2)) for s in seq_lens]
     return np.repeat(np.asarray(per, dtype=np.int32), num_group)
+
+
+def alloc_extend(prefix_lens, seq_lens, last_loc, free_pages, page_size):
+    """-> (out_indices int64, num_new_pages); allocator.py:275-365 (alloc_extend_kernel)."""
+    out, used = [], 0
+    for pre, seq, last in zip(prefix_lens, seq_lens, last_loc):
+        pre, seq, last = int(pre), int(seq), int(last)
+        pre_up = -(-pre // page_size) * page_size
+        part1 = min(seq, pre_up) - pre
+        out += [last + 1 + k for k in range(part1)]
+        n_new = -(-seq // page_size) - (-(-pre // page_size))
+        pos = pre + part1
+        for j in range(n_new):
+            page = int(free_pages[used + j])
+            take = min(page_size, seq - pos)
+            out += [page * page_size + k for k in range(take)]
+            pos += take
+        used += n_new
+    return np.asarray(out, dtype=np.int64), used
+
+
+def alloc_decode(seq_lens, last_loc, free_pages, page_size):
+    """-> (out_indices int64, num_new_pages); allocator.py:368-394 (alloc_decode_kernel)."""
+    out, used = [], 0
+    for seq, last in zip(seq_lens, last_loc):
+        seq = int(seq)
+        if -(-seq // page_size) - (-(-(seq - 1) // page_size)) == 0:
+            out.append(int(last) + 1)
+        else:
+            out.append(int(free_pages[used]) * page_size)
+            used += 1
+    return np.asarray(out, dtype=np.int64), used

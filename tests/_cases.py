@@ -348,3 +348,50 @@ def radix_request_script(make_env, seed=0, n_reqs=12, shared_prefix=40, page_siz
     alloc.merge_and_sort_free()
     trace.append(("final_free", [int(x) for x in alloc.free_pages]))
     return trace
+
+
+def paged_alloc_script(make_alloc, page_size, seed=0, device="cpu"):
+    """Extend / decode / free / chunked-extend sequence against a paged allocator; records every index tensor."""
+    rng = np.random.RandomState(seed + 31)
+    alloc = make_alloc(64 * page_size, page_size)
+    bs = 5
+    slots = [[] for _ in range(bs)]
+    trace = []
+
+    def t(x, dt=torch.int64):
+        return torch.tensor(x, dtype=dt, device=device)
+
+    def extend(new_lens):
+        pre = [len(s) for s in slots]
+        seq = [p + n for p, n in zip(pre, new_lens)]
+        last = [s[-1] if s else -1 for s in slots]
+        out = alloc.alloc_extend(t(pre), t(seq), t(last), int(sum(new_lens)))
+        out = [int(x) for x in out.cpu()]
+        pos = 0
+        for i, n in enumerate(new_lens):
+            slots[i] += out[pos : pos + n]
+            pos += n
+        trace.append(("extend", out, [int(x) for x in alloc.free_pages.cpu()][:8]))
+
+    extend([int(x) for x in rng.randint(1, 3 * page_size + 2, size=bs)])
+    for _ in range(page_size + 2):
+        seq = [len(s) + 1 for s in slots]
+        out = alloc.alloc_decode(t(seq), t([s[-1] for s in slots]))
+        out = [int(x) for x in out.cpu()]
+        for i in range(bs):
+            slots[i].append(out[i])
+        trace.append(("decode", out))
+    alloc.free(t(slots[1]))
+    slots[1] = []
+    trace.append(("avail", int(alloc.available_size())))
+    extend([int(x) for x in rng.randint(1, 2 * page_size + 3, size=bs)])
+    extend([int(x) for x in rng.randint(1, page_size + 1, size=bs)])
+    for i in (0, 3):
+        alloc.free(t(slots[i]))
+        slots[i] = []
+    alloc.merge_and_sort_free()
+    trace.append(("final_free", [int(x) for x in alloc.free_pages.cpu()]))
+    # every live slot is unique and every request's pages are its own
+    live = [x for s in slots for x in s]
+    assert len(set(live)) == len(live)
+    return trace

@@ -275,6 +275,12 @@ def gen_radix():
 
     for seed in (0, 1):
         out[f"req_s{seed}"] = _cases.radix_request_script(env, seed=seed)
+    from sglang.srt.mem_cache.allocator import PagedTokenToKVPoolAllocator
+
+    for ps in (4, 16):
+        for seed in (0, 1):
+            out[f"paged_p{ps}_s{seed}"] = _cases.paged_alloc_script(
+                lambda size, page: PagedTokenToKVPoolAllocator(size, page, torch.bfloat16, "cpu", None), ps, seed=seed)
     with open(os.path.join(HERE, "radix.json"), "w") as f:
         json.dump(out, f, separators=(",", ":"))
     print("radix.json", {k: len(v) for k, v in out.items()})

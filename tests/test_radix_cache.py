@@ -131,3 +131,63 @@ def test_allocator_order_and_lazy_merge(pkg):
     a.free_group_end()
     assert sorted(a.alloc(4).tolist()) == x.tolist()
     assert a.alloc(1) is None
+
+
+class _OraclePagedAlloc:
+    """numpy restatement of PagedTokenToKVPoolAllocator (oracle/kv_index.py alloc_extend / alloc_decode + the host logic)."""
+
+    def __init__(self, size, page_size):
+        self.ps = page_size
+        self.free_pages = torch.arange(1, size // page_size + 1)
+        self.release = torch.empty(0, dtype=torch.int64)
+
+    def merge_and_sort_free(self):
+        if len(self.release):
+            self.free_pages = torch.sort(torch.cat((self.free_pages, self.release))).values
+            self.release = torch.empty(0, dtype=torch.int64)
+
+    def available_size(self):
+        return (len(self.free_pages) + len(self.release)) * self.ps
+
+    def _need(self, before, after):
+        return int((-(-after // self.ps) - (-(-before // self.ps))).sum())
+
+    def alloc_extend(self, pre, seq, last, n):
+        from oracle import kv_index as oi
+
+        if self._need(pre, seq) > len(self.free_pages):
+            self.merge_and_sort_free()
+        out, used = oi.alloc_extend(pre.numpy(), seq.numpy(), last.numpy(), self.free_pages.numpy(), self.ps)
+        self.free_pages = self.free_pages[used:]
+        return torch.from_numpy(out)
+
+    def alloc_decode(self, seq, last):
+        from oracle import kv_index as oi
+
+        if self._need(seq - 1, seq) > len(self.free_pages):
+            self.merge_and_sort_free()
+        out, used = oi.alloc_decode(seq.numpy(), last.numpy(), self.free_pages.numpy(), self.ps)
+        self.free_pages = self.free_pages[used:]
+        return torch.from_numpy(out)
+
+    def free(self, idx):
+        self.release = torch.cat((torch.unique(idx // self.ps), self.release))
+
+
+@pytest.mark.parametrize("page_size", [4, 16])
+@pytest.mark.parametrize("seed", [0, 1])
+def test_oracle_paged_allocator_matches_reference(page_size, seed):
+    trace = _cases.paged_alloc_script(_OraclePagedAlloc, page_size, seed=seed)
+    assert _norm(trace) == GOLD[f"paged_p{page_size}_s{seed}"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("page_size", [4, 16])
+@pytest.mark.parametrize("seed", [0, 1])
+def test_hip_paged_allocator_matches_reference(page_size, seed, pkg):
+    from ltp_sglang_amd.srt.mem_cache.allocator import PagedTokenToKVPoolAllocator
+
+    trace = _cases.paged_alloc_script(
+        lambda size, page: PagedTokenToKVPoolAllocator(size, page, torch.bfloat16, "cuda:0", None), page_size, seed=seed,
+        device="cuda:0")
+    assert _norm(trace) == GOLD[f"paged_p{page_size}_s{seed}"]
