@@ -54,6 +54,10 @@ int sgl_mi355_decode_attention(const void* q, int64_t q_stride_t, const void* k_
                                int max_kv_splits, int batch, int num_q_heads, int num_kv_heads, int head_dim,
                                int v_head_dim, float sm_scale, float logit_cap, int dtype, void* stream);
 
+/* Measurement hook: 1 (default) = every wave owns one (request, kv head, split) unit; 0 = the first design, a
+ * 4-wave workgroup sharing one split with an LDS merge. */
+int sgl_mi355_decode_attention_set_mode(int mode);
+
 /* Extend (prefill / chunked prefill / prefix-cache hit) attention: cached prefix from the paged pool + causal
  * triangle over the contiguous new K/V.  Replaces extend_attention_fwd
  * (python/sglang/srt/layers/attention/triton_ops/extend_attention.py:306-438) with (qo_indptr, kv_indptr,
@@ -94,7 +98,8 @@ int sgl_mi355_set_kv_buffer(void* k_buffer, void* v_buffer, int64_t k_slot_bytes
                             const int64_t* loc, const void* cache_k, const void* cache_v, int64_t cache_k_stride_bytes,
                             int64_t cache_v_stride_bytes, int k_row_bytes, int v_row_bytes, int64_t tokens, void* stream);
 /* kv_indptr[1:bs+1] = cumsum(seq_lens) (triton_backend.py:172) and get_num_kv_splits_triton
- * (triton_backend.py:876-924); either output may be NULL. */
+ * (triton_backend.py:876-924); either output may be NULL.  static_splits: 0 = reference heuristic, 1 = max everywhere,
+ * 2 = MI355X balance rule (about two rounds of resident workgroups). */
 int sgl_mi355_decode_metadata(int32_t* kv_indptr, int32_t* num_kv_splits, const void* seq_lens, int seq_is64,
                               int num_seq, int num_group, int num_head, int num_kv_head, int max_kv_splits,
                               int device_core_count, int static_splits, void* stream);

@@ -10,6 +10,10 @@ import os
 import re
 from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 
+import torch  # noqa: F401  -- must be loaded BEFORE the library: torch brings its own libamdhip64 and the process
+#                  must end up with that single HIP runtime (loading ours first makes torch fail with
+#                  "no ROCm-capable device is detected")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libsgl_mi355.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "sgl_mi355.h")

@@ -80,7 +80,12 @@ __device__ __forceinline__ float softcap_log2(float s_scaled, float cap) {
   return cap * t * kLog2e;
 }
 
-template <typename T, int D, int NW>
+// MODE 0: the NW waves of a workgroup share one (request, kv head, split) and interleave its tiles; LDS merge.
+// MODE 1: every wave is its own (request, kv head, split) unit; the NW waves of a workgroup are NW consecutive
+//         units of one request with the kv head fastest, so they read ADJACENT 256-byte pieces of the same token rows
+//         at about the same time (whole 2-KiB token rows per workgroup instead of scattered 256-byte pieces) and no
+//         barrier or cross-wave merge exists at all.
+template <typename T, int D, int NW, int MODE>
 __global__ __launch_bounds__(NW * 64, 2) void decode_attn_stage1(const DecodeParams p) {
   using Tr = ElemTraits<T>;
   using vec8 = typename Tr::vec8;
@@ -98,10 +103,21 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attn_stage1(const DecodePar
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hchunks = (p.group + 15) >> 4;
-  const int kh = blockIdx.x / hchunks;
-  const int hc = blockIdx.x - kh * hchunks;
-  const int split = blockIdx.y;
+  int khc, split;
+  if constexpr (MODE == 0) {
+    khc = blockIdx.x;
+    split = blockIdx.y;
+  } else {
+    const int unit = blockIdx.x * NW + w;  // wave-uniform
+    khc = unit % (p.hkv * hchunks);
+    split = unit / (p.hkv * hchunks);
+  }
+  const int kh = khc / hchunks;
+  const int hc = khc - kh * hchunks;
   const int b = blockIdx.z;
   const int h0 = kh * p.group + hc * 16;
   const int nh = min(16, p.group - hc * 16);
@@ -111,15 +127,12 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attn_stage1(const DecodePar
   request_range(p, b, idx_row, seq_len);
   int nsplit = p.num_kv_splits[b];
   nsplit = max(1, min(nsplit, p.max_kv_splits));
-  if (split >= nsplit) return;
+  if (split >= nsplit) return;  // MODE 1: a whole-wave exit; the kernel has no barrier in that mode
   const int per = split_len(seq_len, nsplit);
   const int start = split * per;
   const int end = min(start + per, seq_len);
   if (start >= end) return;
 
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int a = lane & 15;  // MFMA n index: q head within the chunk
   const int g = lane >> 4;  // MFMA k/m group
   const int c16 = lane % LPR;
@@ -171,14 +184,15 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attn_stage1(const DecodePar
     }
   };
 
-  int tile = w;
+  constexpr int TS = (MODE == 0) ? NW : 1;  // tile stride of this wave
+  int tile = (MODE == 0) ? w : 0;
   int idx_next = 0;
   if (tile < ntiles) {
     issue(load_idx(tile));
-    idx_next = load_idx(tile + NW);
+    idx_next = load_idx(tile + TS);
   }
 
-  for (; tile < ntiles; tile += NW) {
+  for (; tile < ntiles; tile += TS) {
     const int tok0 = start + tile * kTile;
     // ---- staged registers -> swizzled LDS images (wave private, no barrier) ----
 #pragma unroll
@@ -192,8 +206,8 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attn_stage1(const DecodePar
       *(u32x4_t*)(vl + row * ROWB + ((((c16 >> 1) ^ fv) << 5) | ((c16 & 1) << 4))) = vv;
     }
     // ---- issue the gather of this wave's next tile, prefetch indices two tiles ahead ----
-    if (tile + NW < ntiles) issue(idx_next);
-    idx_next = load_idx(tile + 2 * NW);
+    if (tile + TS < ntiles) issue(idx_next);
+    idx_next = load_idx(tile + 2 * TS);
 
     // ---- S^T = K Q^T for two 16-token halves ----
     f32x4_t s[2];
@@ -265,6 +279,22 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attn_stage1(const DecodePar
   // ---- merge the NW wave-private states, write the split partial ----
   l_i += __shfl_xor(l_i, 16, WAVE);
   l_i += __shfl_xor(l_i, 32, WAVE);
+  if constexpr (MODE == 1) {
+    // the wave IS the split: write acc / l and m + log(l) straight from the accumulator layout
+    if (a < nh) {
+      const int64_t slot = ((int64_t)b * p.hq + (h0 + a)) * p.max_kv_splits + split;
+      const float inv = 1.0f / l_i;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        f32x4_t o = acc[n];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] *= inv;
+        *(f32x4_t*)(p.attn_logits + slot * D + 16 * n + 4 * g) = o;
+      }
+      if (g == 0) p.attn_lse[slot] = m_i * kLn2 + __logf(l_i);
+    }
+    return;
+  }
   __syncthreads();
   float* red_m = (float*)smem;       // [NW][16]
   float* red_l = red_m + NW * 16;    // [NW][16]
@@ -387,18 +417,33 @@ __global__ __launch_bounds__(128) void decode_attn_stage2(const DecodeParams p) 
   }
 }
 
+int g_decode_mode = 0;  // 0 = workgroup-shared split (default: faster at batch 32), 1 = wave-per-unit (faster for 1 kv head per rank)
+
 template <typename T, int D>
 int launch_mfma(const DecodeParams& p, hipStream_t st) {
-  constexpr int NW = 4;
-  constexpr int smem = NW * 2 * kTile * D * 2;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)decode_attn_stage1<T, D, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_set = true;
-  }
   const int hchunks = (p.group + 15) / 16;
-  dim3 grid(p.hkv * hchunks, p.max_kv_splits, p.bs);
-  hipLaunchKernelGGL((decode_attn_stage1<T, D, NW>), grid, dim3(NW * 64), smem, st, p);
+  if (g_decode_mode == 0) {
+    constexpr int NW = 4;
+    constexpr int smem = NW * 2 * kTile * D * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)decode_attn_stage1<T, D, NW, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+      attr_set = true;
+    }
+    dim3 grid(p.hkv * hchunks, p.max_kv_splits, p.bs);
+    hipLaunchKernelGGL((decode_attn_stage1<T, D, NW, 0>), grid, dim3(NW * 64), smem, st, p);
+  } else {
+    constexpr int NW = 8;
+    constexpr int smem = NW * 2 * kTile * D * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)decode_attn_stage1<T, D, NW, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+      attr_set = true;
+    }
+    const int units = p.hkv * hchunks * p.max_kv_splits;
+    dim3 grid((units + NW - 1) / NW, 1, p.bs);
+    hipLaunchKernelGGL((decode_attn_stage1<T, D, NW, 1>), grid, dim3(NW * 64), smem, st, p);
+  }
   SGL_HIP_LAUNCH_CHECK();
   return SGL_MI355_OK;
 }
@@ -424,6 +469,11 @@ int launch_all(const DecodeParams& p, int d_qk, hipStream_t st) {
 }
 
 }  // namespace
+
+extern "C" int sgl_mi355_decode_attention_set_mode(int mode) {
+  g_decode_mode = mode ? 1 : 0;
+  return SGL_MI355_OK;
+}
 
 extern "C" int sgl_mi355_decode_attention(
     const void* q, int64_t q_stride_t, const void* k_buffer, const void* v_buffer, int64_t k_stride_t,

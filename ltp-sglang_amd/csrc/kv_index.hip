@@ -136,7 +136,35 @@ __global__ __launch_bounds__(1024) void decode_meta_kernel(int32_t* kv_indptr, i
     }
   }
   if (!num_kv_splits) return;
-  if (static_splits || device_core_count <= 0) {
+  if (static_splits == 2 && device_core_count > 0) {
+    // MI355X balance rule (measured, tools/bench_decode_attn.py): about TWO rounds of resident workgroups
+    // (2 x 256-thread workgroups per CU) stream fastest -- one round starts and drains in lock step, more rounds pay
+    // the per-workgroup prologue again.  Split length T = total key rows x (kv heads x head chunks) / (2 x resident),
+    // rounded up to whole 32-token tiles; each request gets ceil(len / T) splits.
+    int64_t tot = 0;
+    for (int i = tid; i < num_seq; i += 1024) tot += ld_idx(seq_lens, i, sl64);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) tot += __shfl_xor(tot, m, WAVE);
+    __syncthreads();
+    if ((tid & 63) == 0) scan[tid >> 6] = tot;
+    __syncthreads();
+    tot = 0;
+    for (int w = 0; w < 16; ++w) tot += scan[w];
+    const int kv_group = num_head / num_kv_head;
+    const int64_t units = (int64_t)num_kv_head * ((kv_group + 15) / 16) * num_group;
+    const int64_t target_wgs = 2ll * 2 * device_core_count;
+    int64_t T = (tot * units + target_wgs - 1) / target_wgs;
+    T = (T + 31) / 32 * 32;
+    if (T < 64) T = 64;
+    for (int i = tid; i < num_seq; i += 1024) {
+      const int64_t len = ld_idx(seq_lens, i, sl64);
+      int ns = (int)((len + T - 1) / T);
+      ns = ns < 1 ? 1 : (ns > max_kv_splits ? max_kv_splits : ns);
+      for (int gI = 0; gI < num_group; ++gI) num_kv_splits[i * num_group + gI] = ns;
+    }
+    return;
+  }
+  if (static_splits == 1 || device_core_count <= 0) {
     for (int i = tid; i < num_seq * num_group; i += 1024) num_kv_splits[i] = max_kv_splits;
     return;
   }
@@ -261,7 +289,9 @@ extern "C" int sgl_mi355_set_kv_buffer(void* k_buffer, void* v_buffer, int64_t k
   return SGL_MI355_OK;
 }
 
-// kv_indptr and/or num_kv_splits may be NULL to skip that part.
+// kv_indptr and/or num_kv_splits may be NULL to skip that part.  static_splits: 0 = the reference's heuristic
+// (get_num_kv_splits_triton), 1 = max_kv_splits for every request (SGLANG_TRITON_DECODE_ATTN_STATIC_KV_SPLITS),
+// 2 = the MI355X balance rule (any split count gives the same attention up to fp association: SURVEY.md a12).
 extern "C" int sgl_mi355_decode_metadata(int32_t* kv_indptr, int32_t* num_kv_splits, const void* seq_lens, int seq_is64,
                                          int num_seq, int num_group, int num_head, int num_kv_head, int max_kv_splits,
                                          int device_core_count, int static_splits, void* stream) {

@@ -61,8 +61,9 @@ def set_kv_buffer(k_buffer, v_buffer, loc, cache_k, cache_v) -> None:
 
 def decode_metadata(kv_indptr, num_kv_splits, seq_lens, num_group, num_head, num_kv_head, max_kv_splits,
                     device_core_count, static_splits=False) -> None:
-    """kv_indptr[1:bs+1] = cumsum(seq_lens) and the reference's num_kv_splits heuristic, one launch."""
+    """kv_indptr[1:bs+1] = cumsum(seq_lens) and num_kv_splits, one launch.  static_splits: 0/False = the reference's
+    heuristic, 1/True = max_kv_splits everywhere, 2 = the MI355X balance rule."""
     check(lib.sgl_mi355_decode_metadata(ptr(kv_indptr), ptr(num_kv_splits), ptr(seq_lens), is64(seq_lens),
                                         seq_lens.numel(), int(num_group), int(num_head), int(num_kv_head),
-                                        int(max_kv_splits), int(device_core_count), int(bool(static_splits)),
+                                        int(max_kv_splits), int(device_core_count), int(static_splits),
                                         current_stream()))

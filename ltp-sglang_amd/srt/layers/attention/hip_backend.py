@@ -61,7 +61,8 @@ class HipAttnBackend(AttentionBackend):
         self.num_kv_head = cfg.get_num_kv_heads(tp)
         args = getattr(model_runner, "server_args", None)
         self.max_kv_splits = getattr(args, "triton_attention_num_kv_splits", None) or default_max_kv_splits()
-        self.static_kv_splits = bool(getattr(args, "static_kv_splits", False))
+        # 0 = reference heuristic, 1 = static, 2 = MI355X balance rule (default; split counts are not parity-critical)
+        self.static_kv_splits = 1 if getattr(args, "static_kv_splits", False) else int(getattr(args, "kv_split_rule", 2))
         self.v_head_dim = model_runner.token_to_kv_pool.get_value_buffer(0).shape[-1]
         self.max_context_len = cfg.context_len
         gpu_id = getattr(model_runner, "gpu_id", 0)

@@ -36,7 +36,11 @@ def run(bs=32, hq=32, hkv=8, d=128, seq=2048, nsplit=2, max_splits=16, iters=20,
     print(f"bs={bs} seq={seq} hq={hq} hkv={hkv} nsplit={nsplit}: {ms*1e3:.1f} us/layer  {byts/ms/1e6:.0f} GB/s algorithmic")
 
 if __name__ == "__main__":
-    for ns in (1, 2, 4, 8, 16):
-        run(nsplit=ns)
-    run(bs=128, hq=8, hkv=1, seq=2048, nsplit=4)
-    run(bs=128, hq=8, hkv=1, seq=2048, nsplit=8)
+    from ltp_sglang_amd._cabi import lib
+    for mode in (0, 1):
+        lib.sgl_mi355_decode_attention_set_mode(mode)
+        print("mode", mode)
+        for ns in (1, 2, 4, 5, 8, 16):
+            run(nsplit=ns)
+        run(bs=128, hq=8, hkv=1, seq=2048, nsplit=4)
+        run(bs=128, hq=8, hkv=1, seq=2048, nsplit=8)
