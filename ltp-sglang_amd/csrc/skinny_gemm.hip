@@ -184,9 +184,39 @@ int launch(const SkinnyParams& p, hipStream_t st) {
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kV2Waves = 8;
 
-template <int ES, int MT, int DS, int PD, int TPP, typename OutT>
+// Fused epilogues (single k-range only).  Both rely on an INTERLEAVED weight row order so that the two values an output
+// needs sit in one 16-row tile, 8 columns apart (thread en and en ^ 8 of the same row m exchange them with one shuffle):
+//   EPI_SILU: tile t = [gate rows 8t..8t+7 | up rows 8t..8t+7]  -> act[m][8t+j] = T(T(silu(gate)) * up)
+//             (gate_up_proj + SiluAndMul, models/llama.py:94-98, activation.py:60-63)
+//   EPI_ROPE: inside every q/k head, tile u = [rows 8u..8u+7 | rows 64+8u..64+8u+7] (the neox rotation pairs); q is
+//             written rotated to q_out, k rotated and v straight into the KV pool rows loc[m]
+//             (qkv_proj -> rotary_emb -> set_kv_buffer, models/llama.py:180-191, rotary_embedding.py:49-72,
+//             memory_pool.py:401-407).  head_dim = rot_dim = 128.
+// Every rounding point of the unfused op sequence is kept (GEMM output -> T, each product -> T), so results are
+// bit-identical to running the separate kernels.
+enum { EPI_NONE = 0, EPI_SILU = 1, EPI_ROPE = 2 };
+struct EpiParams {
+  const int64_t* positions;
+  const float* cos_sin;  // [max_pos, 128]: cos | sin
+  const int64_t* loc;
+  void* k_buf;
+  void* v_buf;
+  int64_t k_slot_stride, v_slot_stride;  // elements
+  int hq, hkv;
+};
+
+template <typename T>
+__device__ __forceinline__ float rnd_to(float x) {
+  asm volatile("" : "+v"(x));  // materialise the f32 first: no single-rounding v_fma_mix shortcut
+  const T t = (T)x;
+  uint16_t u = __builtin_bit_cast(uint16_t, t), v;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "v"(u));
+  return (float)__builtin_bit_cast(T, v);
+}
+
+template <int ES, int MT, int DS, int PD, int TPP, typename OutT, int EPI = EPI_NONE>
 __global__ __launch_bounds__(kV2Waves * 64, 2) void skinny_gemm_v2_kernel(const SkinnyParams p, int rpt, int ntiles,
-                                                                          float* slabs) {
+                                                                          float* slabs, const EpiParams ep = EpiParams{}) {
   constexpr int kw = DS * 64;             // bytes of K per wave
   constexpr int LPR = kw / 16;            // lanes per weight row in one load instruction
   constexpr int RPI = 64 / LPR;           // rows per load instruction
@@ -217,6 +247,11 @@ __global__ __launch_bounds__(kV2Waves * 64, 2) void skinny_gemm_v2_kernel(const 
   float sxv = 1.0f;
   if constexpr (SCALED) {
     if (slabs == nullptr) sxv = p.sx[min(em, p.M - 1)];  // slab mode leaves the scales to the consumer kernel
+  }
+  int64_t ep_pos = 0, ep_loc = 0;
+  if constexpr (EPI == EPI_ROPE) {
+    ep_pos = ep.positions[min(em, p.M - 1)];
+    ep_loc = ep.loc[min(em, p.M - 1)];
   }
 
   const unsigned wbytes = (unsigned)min((int64_t)p.N * p.w_stride, (int64_t)0xFFFFFFF0ll);
@@ -308,7 +343,36 @@ __global__ __launch_bounds__(kV2Waves * 64, 2) void skinny_gemm_v2_kernel(const 
         } else {
           const float bv = has_bias ? (float)__builtin_bit_cast(OutT, braw[jj]) : 0.0f;
           v = v * sxv * swv[jj] + bv;
-          if (live) ((OutT*)p.y)[(int64_t)em * p.y_stride + n0 + en] = (OutT)v;
+          if constexpr (EPI == EPI_NONE) {
+            if (live) ((OutT*)p.y)[(int64_t)em * p.y_stride + n0 + en] = (OutT)v;
+          } else {
+            const float vr = rnd_to<OutT>(v);             // the GEMM's own output rounding
+            const float pr = __shfl_xor(vr, 8, WAVE);     // the partner column of the same row m
+            if constexpr (EPI == EPI_SILU) {
+              if (live && en < 8) {
+                const float sg = rnd_to<OutT>(vr / (1.0f + expf(-vr)));
+                ((OutT*)p.y)[(int64_t)em * p.y_stride + (n0 >> 1) + en] = (OutT)rnd_to<OutT>(sg * pr);
+              }
+            } else {
+              const int head = n0 >> 7, u = (n0 & 127) >> 4;
+              if (live) {
+                if (head < ep.hq + ep.hkv) {
+                  const int i = 8 * u + (en & 7);
+                  const float* cs = ep.cos_sin + ep_pos * 128;
+                  const float c = rnd_to<OutT>(cs[i]), sn = rnd_to<OutT>(cs[64 + i]);
+                  const float x1 = en < 8 ? vr : pr, x2 = en < 8 ? pr : vr;
+                  const float o = en < 8 ? rnd_to<OutT>(x1 * c) - rnd_to<OutT>(x2 * sn) : rnd_to<OutT>(x2 * c) + rnd_to<OutT>(x1 * sn);
+                  const int col = i + (en < 8 ? 0 : 64);
+                  if (head < ep.hq)
+                    ((OutT*)p.y)[(int64_t)em * p.y_stride + head * 128 + col] = (OutT)o;
+                  else
+                    ((OutT*)ep.k_buf)[ep_loc * ep.k_slot_stride + (head - ep.hq) * 128 + col] = (OutT)o;
+                } else {
+                  ((OutT*)ep.v_buf)[ep_loc * ep.v_slot_stride + (head - ep.hq - ep.hkv) * 128 + (n0 & 127) + en] = (OutT)vr;
+                }
+              }
+            }
+          }
         }
       }
     }
@@ -484,4 +548,82 @@ extern "C" int sgl_mi355_skinny_gemm_slabs(const void* x, int64_t x_stride_elems
   const int kranges = (K + range - 1) / range;
   hipStream_t st = (hipStream_t)stream;
   return M <= 16 ? launch_v2_ds<ES_FP8, 1, __bf16>(p, ds, kranges, slabs, st) : launch_v2_ds<ES_FP8, 2, __bf16>(p, ds, kranges, slabs, st);
+}
+
+namespace {
+template <int MT, int DS, typename OutT, int EPI>
+int launch_v2_epi(const SkinnyParams& p, const EpiParams& ep, hipStream_t st) {
+  const int cus = v2_cus();
+  const int ntiles = p.N / 16;
+  const int gx = ntiles < cus ? ntiles : cus;
+  if (ntiles <= gx)
+    hipLaunchKernelGGL((skinny_gemm_v2_kernel<ES_FP8, MT, DS, 2, 1, OutT, EPI>), dim3(gx, 1), dim3(kV2Waves * 64), 0, st, p, 16,
+                       ntiles, (float*)nullptr, ep);
+  else
+    hipLaunchKernelGGL((skinny_gemm_v2_kernel<ES_FP8, MT, DS, 2, 4, OutT, EPI>), dim3(gx, 1), dim3(kV2Waves * 64), 0, st, p, 16,
+                       ntiles, (float*)nullptr, ep);
+  SGL_HIP_LAUNCH_CHECK();
+  return SGL_MI355_OK;
+}
+
+template <int EPI>
+int run_epi(SkinnyParams& p, const EpiParams& ep, int out_dtype, hipStream_t st, const char* who) {
+  SGL_CHECK(p.M > 0 && p.M <= 32, "%s: needs 0 < M <= 32 (got %d)", who, p.M);
+  SGL_CHECK(p.kbytes % 64 == 0 && p.kbytes <= 4096, "%s: K=%d must be a multiple of 64 and <= 4096 (single k-range)", who, p.kbytes);
+  SGL_CHECK(p.N % 16 == 0 && (int64_t)p.N * p.w_stride < 0xFFFFFFF0ll, "%s: N=%d must be a multiple of 16", who, p.N);
+  SGL_CHECK(out_dtype == SGL_BF16 || out_dtype == SGL_F16, "%s: out_dtype must be bf16 or f16", who);
+  const int ds = p.kbytes <= 1024 ? 2 : (p.kbytes <= 2048 ? 4 : 8);
+#define SGL_EPI_CASE(MTv, DSv)                                                                                          \
+  return out_dtype == SGL_BF16 ? launch_v2_epi<MTv, DSv, __bf16, EPI>(p, ep, st) : launch_v2_epi<MTv, DSv, _Float16, EPI>(p, ep, st)
+  if (p.M <= 16) {
+    if (ds == 8) { SGL_EPI_CASE(1, 8); }
+    if (ds == 4) { SGL_EPI_CASE(1, 4); }
+    SGL_EPI_CASE(1, 2);
+  }
+  if (ds == 8) { SGL_EPI_CASE(2, 8); }
+  if (ds == 4) { SGL_EPI_CASE(2, 4); }
+  SGL_EPI_CASE(2, 2);
+#undef SGL_EPI_CASE
+}
+}  // namespace
+
+// act[M, N/2] = T(T(silu(g)) * u) with [g | u] = fp8_scaled_mm(x, w_interleaved) -- gate_up_proj + SiluAndMul in one launch.
+// w_interleaved [N, K] / scales_w [N]: tile t of 16 rows = gate rows 8t..8t+7 then up rows 8t..8t+7.
+extern "C" int sgl_mi355_fp8_gemm_silu_mul(const void* x, int64_t x_stride_elems, const void* w_interleaved,
+                                           int64_t w_stride_elems, void* act, int64_t act_stride_elems,
+                                           const float* scales_x, const float* scales_w_interleaved, int M, int N, int K,
+                                           int out_dtype, void* stream) {
+  SGL_CHECK(x && w_interleaved && act && scales_x && scales_w_interleaved, "fp8_gemm_silu_mul: null pointer");
+  SGL_CHECK(((uintptr_t)x % 16) == 0 && ((uintptr_t)w_interleaved % 16) == 0 && x_stride_elems % 16 == 0 && w_stride_elems % 16 == 0,
+            "fp8_gemm_silu_mul: rows must be 16-byte aligned");
+  SkinnyParams p;
+  p.x = (const char*)x; p.x_stride = x_stride_elems; p.w = (const char*)w_interleaved; p.w_stride = w_stride_elems;
+  p.y = act; p.y_stride = act_stride_elems; p.sx = scales_x; p.sw = scales_w_interleaved; p.bias = nullptr;
+  p.M = M; p.N = N; p.K = K; p.kbytes = K;
+  return run_epi<EPI_SILU>(p, EpiParams{}, out_dtype, (hipStream_t)stream, "fp8_gemm_silu_mul");
+}
+
+// qkv_proj + neox rotary embedding + set_kv_buffer in one launch.  w_interleaved / scales / bias rows: inside every q and k
+// head (128 rows) tile u = rows 8u..8u+7 then rows 64+8u..64+8u+7; v heads in natural order.  q (rotated) -> q_out
+// [M, Hq*128]; k (rotated) and v -> pool rows loc[m] of k_buffer / v_buffer ([slots, Hkv, 128], strides in elements).
+extern "C" int sgl_mi355_fp8_qkv_rope_set_kv(const void* x, int64_t x_stride_elems, const void* w_interleaved,
+                                             int64_t w_stride_elems, void* q_out, int64_t q_stride_elems,
+                                             const float* scales_x, const float* scales_w_interleaved,
+                                             const void* bias_interleaved, const int64_t* positions,
+                                             const float* cos_sin_cache, const int64_t* loc, void* k_buffer, void* v_buffer,
+                                             int64_t k_slot_stride, int64_t v_slot_stride, int M, int num_q_heads,
+                                             int num_kv_heads, int head_dim, int K, int out_dtype, void* stream) {
+  SGL_CHECK(x && w_interleaved && q_out && scales_x && scales_w_interleaved && positions && cos_sin_cache && loc && k_buffer && v_buffer,
+            "fp8_qkv_rope_set_kv: null pointer");
+  SGL_CHECK(head_dim == 128, "fp8_qkv_rope_set_kv: head_dim (= rotary_dim) must be 128, got %d", head_dim);
+  SGL_CHECK(((uintptr_t)x % 16) == 0 && ((uintptr_t)w_interleaved % 16) == 0 && x_stride_elems % 16 == 0 && w_stride_elems % 16 == 0,
+            "fp8_qkv_rope_set_kv: rows must be 16-byte aligned");
+  SkinnyParams p;
+  p.x = (const char*)x; p.x_stride = x_stride_elems; p.w = (const char*)w_interleaved; p.w_stride = w_stride_elems;
+  p.y = q_out; p.y_stride = q_stride_elems; p.sx = scales_x; p.sw = scales_w_interleaved; p.bias = bias_interleaved;
+  p.M = M; p.N = (num_q_heads + 2 * num_kv_heads) * 128; p.K = K; p.kbytes = K;
+  EpiParams ep;
+  ep.positions = positions; ep.cos_sin = cos_sin_cache; ep.loc = loc; ep.k_buf = k_buffer; ep.v_buf = v_buffer;
+  ep.k_slot_stride = k_slot_stride; ep.v_slot_stride = v_slot_stride; ep.hq = num_q_heads; ep.hkv = num_kv_heads;
+  return run_epi<EPI_ROPE>(p, ep, out_dtype, (hipStream_t)stream, "fp8_qkv_rope_set_kv");
 }

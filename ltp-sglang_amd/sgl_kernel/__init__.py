@@ -13,7 +13,16 @@ from .elementwise import (
     rmsnorm,
     silu_and_mul,
 )
-from .fused import decode_merge_quant_fp8, fused_add_rmsnorm_quant_fp8, rope_set_kv, silu_and_mul_quant_fp8
+from .fused import (
+    decode_merge_quant_fp8,
+    fp8_gemm_silu_mul,
+    fp8_qkv_rope_set_kv,
+    fused_add_rmsnorm_quant_fp8,
+    interleave_gate_up_rows,
+    interleave_rope_rows,
+    rope_set_kv,
+    silu_and_mul_quant_fp8,
+)
 from .gemm import (
     awq_dequantize,
     dense_linear,
@@ -31,3 +40,13 @@ from .kvcache import (
     set_kv_buffer,
     write_req_to_token,
 )
+
+
+def sglang_per_token_quant_fp8(x):
+    """x [M, K] -> (x_q e4m3fn, x_s f32 [M, 1]); fp8_kernel.py:375-391."""
+    import torch
+
+    x_q = torch.empty_like(x, dtype=torch.float8_e4m3fn)
+    x_s = torch.empty(x.shape[0], 1, device=x.device, dtype=torch.float32)
+    sgl_per_token_quant_fp8(x, x_q, x_s)
+    return x_q, x_s

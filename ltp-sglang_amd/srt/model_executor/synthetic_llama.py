@@ -132,6 +132,7 @@ class LlamaForCausalLM(nn.Module):
         super().__init__()
         self.cfg, self.dtype = cfg, dtype
         self.fused_decode = True
+        self.fused_epilogues = True
         qc = None
         if quantization is not None:
             cls = get_quantization_config(quantization)
@@ -187,6 +188,32 @@ class LlamaForCausalLM(nn.Module):
                 and self.quant_config is not None and self.quant_config.get_name() == "w8a8_fp8"
                 and forward_batch.batch_size <= 32 and self.cfg.hidden_size <= 8192)
 
+    def _fused_weights(self, layer):
+        """Row-interleaved copies of the qkv / gate_up weights for the fused GEMM epilogues (built once; K <= 4096,
+        head_dim 128).  They replace the plain copies on the decode path; memory cost = one extra copy of those two."""
+        if not self.fused_epilogues:
+            return None
+        cached = getattr(layer, "_fused_w", None)
+        if cached is not None:
+            return cached or None
+        attn, mlp = layer.self_attn, layer.mlp
+        kdim = attn.qkv_proj.weight.shape[0]
+        if attn.head_dim != 128 or kdim > 4096 or kdim % 64 != 0:
+            layer._fused_w = {}
+            return None
+        hq, hkv = attn.num_heads, attn.num_kv_heads
+        qw = attn.qkv_proj.weight.t()        # [N, K] fp8 (the parameter is the [K, N] view)
+        gw = mlp.gate_up_proj.weight.t()
+        as_u8 = lambda w: w.contiguous().view(torch.uint8)
+        layer._fused_w = dict(
+            qkv_w=K.interleave_rope_rows(as_u8(qw), hq, hkv).view(torch.float8_e4m3fn),
+            qkv_s=K.interleave_rope_rows(attn.qkv_proj.weight_scale.view(-1), hq, hkv),
+            qkv_b=None if attn.qkv_proj.bias is None else K.interleave_rope_rows(attn.qkv_proj.bias.data, hq, hkv),
+            gu_w=K.interleave_gate_up_rows(as_u8(gw)).view(torch.float8_e4m3fn),
+            gu_s=K.interleave_gate_up_rows(mlp.gate_up_proj.weight_scale.view(-1)),
+        )
+        return layer._fused_w
+
     def forward_decode_fused(self, input_ids, positions, forward_batch: ForwardBatch):
         """The same decode step with the elementwise work fused into 4 kernels per layer (sgl_kernel/fused.py) and the
         down_proj split-K combine folded into the next layer's RMSNorm.  Every fused kernel is bit-identical to the op
@@ -205,20 +232,30 @@ class LlamaForCausalLM(nn.Module):
             else:
                 _, xq, xs = K.fused_add_rmsnorm_quant_fp8(None, residual, ln1.weight.data, ln1.variance_epsilon, slabs=slabs,
                                                           slab_sx=slab_sx, slab_sw=slab_sw, dtype=self.dtype)
-            qkv = K.fp8_scaled_mm(xq, attn.qkv_proj.weight, xs.view(-1), attn.qkv_proj.weight_scale.view(-1), self.dtype,
-                                  attn.qkv_proj.bias)
-            q, k, v = qkv.split([attn.q_size, attn.kv_size, attn.kv_size], dim=-1)
             lid = attn.attn.layer_id
-            K.rope_set_kv(positions, q, k, v, attn.head_dim, attn.rotary_emb.cos_sin_cache, True, pool.get_key_buffer(lid),
-                          pool.get_value_buffer(lid), forward_batch.out_cache_loc)
+            fw = self._fused_weights(layer)
+            if fw is not None:   # qkv GEMM with the RoPE + KV-write epilogue
+                q = K.fp8_qkv_rope_set_kv(xq, xs.view(-1), fw["qkv_w"], fw["qkv_s"], fw["qkv_b"], positions,
+                                          attn.rotary_emb.cos_sin_cache, forward_batch.out_cache_loc, pool.get_key_buffer(lid),
+                                          pool.get_value_buffer(lid), attn.num_heads, attn.num_kv_heads, attn.head_dim, self.dtype)
+            else:
+                qkv = K.fp8_scaled_mm(xq, attn.qkv_proj.weight, xs.view(-1), attn.qkv_proj.weight_scale.view(-1), self.dtype,
+                                      attn.qkv_proj.bias)
+                q, k, v = qkv.split([attn.q_size, attn.kv_size, attn.kv_size], dim=-1)
+                K.rope_set_kv(positions, q, k, v, attn.head_dim, attn.rotary_emb.cos_sin_cache, True, pool.get_key_buffer(lid),
+                              pool.get_value_buffer(lid), forward_batch.out_cache_loc)
             md = backend.forward_decode_partial(q, attn.attn, forward_batch)
             _, oq, osc = K.decode_merge_quant_fp8(md.attn_logits, md.attn_lse, md.kv_indptr, md.num_kv_splits,
                                                   backend.max_kv_splits, self.dtype)
             attn_out = K.fp8_scaled_mm(oq, attn.o_proj.weight, osc.view(-1), attn.o_proj.weight_scale.view(-1), self.dtype)
             ln2 = layer.post_attention_layernorm
             _, hq2, hs2 = K.fused_add_rmsnorm_quant_fp8(attn_out, residual, ln2.weight.data, ln2.variance_epsilon)
-            gate_up = K.fp8_scaled_mm(hq2, mlp.gate_up_proj.weight, hs2.view(-1), mlp.gate_up_proj.weight_scale.view(-1), self.dtype)
-            aq, asc = K.silu_and_mul_quant_fp8(gate_up)
+            if fw is not None:   # gate_up GEMM with the SiluAndMul epilogue, then the per-token quantisation
+                act = K.fp8_gemm_silu_mul(hq2, hs2.view(-1), fw["gu_w"], fw["gu_s"], self.dtype)
+                aq, asc = K.sglang_per_token_quant_fp8(act)
+            else:
+                gate_up = K.fp8_scaled_mm(hq2, mlp.gate_up_proj.weight, hs2.view(-1), mlp.gate_up_proj.weight_scale.view(-1), self.dtype)
+                aq, asc = K.silu_and_mul_quant_fp8(gate_up)
             wd = mlp.down_proj.weight  # [K, N] column-major view of the [N, K] parameter
             slabs = K.fp8_linear_slabs(aq, wd.t(), m, wd.shape[1], wd.shape[0])
             slab_sx, slab_sw = asc.view(-1), mlp.down_proj.weight_scale.view(-1)

@@ -80,9 +80,10 @@ def test_fused_and_graph_decode_are_bit_identical(pkg):
     cfg = LlamaShape(hidden_size=1024, num_attention_heads=8, num_key_value_heads=2, head_dim=128, num_hidden_layers=3,
                      intermediate_size=3584, vocab_size=4096, max_position_embeddings=512)
     outs = {}
-    for mode in ("plain", "fused", "graph"):
+    for mode in ("plain", "fused_ops", "fused", "graph"):
         runner = SyntheticModelRunner(cfg, "w8a8_fp8", max_running_requests=8, context_len=256, max_total_tokens=2048, device=DEV, seed=5)
         runner.model.fused_decode = mode != "plain"
+        runner.model.fused_epilogues = mode in ("fused", "graph")
         g = torch.Generator().manual_seed(1)
         ids = [torch.randint(0, cfg.vocab_size, (n,), generator=g).to(DEV) for n in (50, 7, 33, 1)]
         logits, state = runner.extend(ids)
@@ -95,5 +96,6 @@ def test_fused_and_graph_decode_are_bit_identical(pkg):
             seq.append(logits.clone())
             nxt = torch.argmax(logits.float(), dim=-1)
         outs[mode] = torch.stack(seq)
+    assert torch.equal(outs["plain"], outs["fused_ops"])
     assert torch.equal(outs["plain"], outs["fused"])
     assert torch.equal(outs["plain"], outs["graph"])

@@ -387,3 +387,40 @@ def test_decode_merge_quant_bit_exact(sk):
     sk.sgl_per_token_quant_fp8(o.view(bs, -1), q1, s1)
     o2, q2, s2 = sk.decode_merge_quant_fp8(logits, lse, kv_indptr.to(DEV), splits, 8, c["dtype"], want_o=True)
     assert torch.equal(o2, o.view(bs, -1)) and torch.equal(s1, s2) and torch.equal(q1.view(torch.uint8), q2.view(torch.uint8))
+
+
+def test_fp8_gemm_silu_mul_bit_exact(sk):
+    """gate_up GEMM with the SiluAndMul epilogue (interleaved weight rows) == fp8_scaled_mm -> silu_and_mul."""
+    m, i_dim, k = 32, 1408, 4096
+    c = _cases.build_gemm_case(dict(m=m, n=2 * i_dim, k=k, bias=False, out="bf16"), seed=21)
+    a, wt, sa, sb = c["a"].to(DEV), c["w"].to(DEV), c["sa"].to(DEV) * 3, c["sb"].to(DEV) * 3
+    ref = sk.silu_and_mul(sk.fp8_scaled_mm(a, wt.t(), sa, sb, torch.bfloat16))
+    wi = sk.interleave_gate_up_rows(wt.view(torch.uint8)).view(torch.float8_e4m3fn)
+    got = sk.fp8_gemm_silu_mul(a, sa, wi, sk.interleave_gate_up_rows(sb), torch.bfloat16)
+    assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("m,hq,hkv,bias", [(32, 8, 2, False), (5, 4, 4, True), (17, 28, 4, True)])
+def test_fp8_qkv_rope_set_kv_bit_exact(m, hq, hkv, bias, sk):
+    """qkv GEMM with the RoPE + KV-write epilogue == fp8_scaled_mm -> rope -> set_kv_buffer (K = 3584 covers the K tail)."""
+    d, k = 128, 3584
+    n = (hq + 2 * hkv) * d
+    c = _cases.build_gemm_case(dict(m=m, n=n, k=k, bias=bias, out="bf16"), seed=m)
+    a, wt, sa, sb = c["a"].to(DEV), c["w"].to(DEV), c["sa"].to(DEV) * 3, c["sb"].to(DEV) * 3
+    bvec = None if not bias else c["bias"].to(DEV)
+    g = torch.Generator().manual_seed(m)
+    positions = torch.randint(0, 4096, (m,), generator=g).to(DEV)
+    cache = oe.rope_cache(d, d, 4096, 10000.0).to(DEV)
+    loc = (torch.randperm(99, generator=g)[:m] + 1).to(DEV)
+    # unfused sequence
+    qkv = sk.fp8_scaled_mm(a, wt.t(), sa, sb, torch.bfloat16, bvec)
+    q, kk, vv = qkv.split([hq * d, hkv * d, hkv * d], dim=-1)
+    kb1 = torch.zeros(100, hkv, d, dtype=torch.bfloat16, device=DEV)
+    vb1 = torch.zeros_like(kb1)
+    sk.rope_set_kv(positions, q, kk, vv, d, cache, True, kb1, vb1, loc)
+    # fused
+    wi = sk.interleave_rope_rows(wt.view(torch.uint8), hq, hkv).view(torch.float8_e4m3fn)
+    kb2, vb2 = torch.zeros_like(kb1), torch.zeros_like(kb1)
+    q2 = sk.fp8_qkv_rope_set_kv(a, sa, wi, sk.interleave_rope_rows(sb, hq, hkv), None if bvec is None else sk.interleave_rope_rows(bvec, hq, hkv),
+                                positions, cache, loc, kb2, vb2, hq, hkv, d, torch.bfloat16)
+    assert torch.equal(q2, q.contiguous()) and torch.equal(kb1, kb2) and torch.equal(vb1, vb2)
