@@ -99,9 +99,37 @@ __global__ __launch_bounds__(256) void add_rmsnorm_quant_kernel(const T* x, cons
   __shared__ float red[4];
   const int64_t row = blockIdx.x;
   const int nvec = hidden / 8;
+  // Every global load of the kernel is issued up front (inputs were just written by other CUs, so each dependent
+  // round trip costs ~2 us here): the norm weight travels with the inputs instead of after the first reduction.
+  V8<T> wreg[MAXV], rreg[MAXV], xreg[MAXV];
+  f32x4_t s0[MAXV][2], s1[MAXV][2], swr[MAXV][2];
+  const float sxm = (slabs && slab_sx) ? slab_sx[row] : 1.0f;
+  const int ns = slabs ? nslabs : 0;
+#pragma unroll
+  for (int it = 0; it < MAXV; ++it) {
+    const int i = threadIdx.x + it * 256;
+    const int ic = i < nvec ? i : 0;  // clamped: lanes past the row read column 0 (harmless) instead of branching
+    wreg[it] = ld8(weight + ic * 8);
+    if (residual) rreg[it] = ld8(residual + row * hidden + ic * 8);
+    if (slabs) {
+      const float* sp = slabs + row * hidden + ic * 8;
+      s0[it][0] = *(const f32x4_t*)sp;
+      s0[it][1] = *(const f32x4_t*)(sp + 4);
+      if (ns > 1) {
+        const float* sq = sp + (int64_t)tokens * hidden;
+        s1[it][0] = *(const f32x4_t*)sq;
+        s1[it][1] = *(const f32x4_t*)(sq + 4);
+      }
+      if (slab_sw) {
+        swr[it][0] = *(const f32x4_t*)(slab_sw + ic * 8);
+        swr[it][1] = *(const f32x4_t*)(slab_sw + ic * 8 + 4);
+      }
+    } else {
+      xreg[it] = ld8(x + row * hidden + ic * 8);
+    }
+  }
   float vals[MAXV][8];
   float ss = 0.f;
-  const float sxm = (slabs && slab_sx) ? slab_sx[row] : 1.0f;
 #pragma unroll
   for (int it = 0; it < MAXV; ++it) {
     const int i = threadIdx.x + it * 256;
@@ -109,26 +137,28 @@ __global__ __launch_bounds__(256) void add_rmsnorm_quant_kernel(const T* x, cons
       float f[8];
       if (slabs) {  // x = T((sum of the split-K partial sums) * sx[m] * sw[n]): the GEMM epilogue, fused
 #pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = 0.f;
-        for (int sI = 0; sI < nslabs; ++sI) {
-          const float* sp = slabs + ((int64_t)sI * tokens + row) * hidden + i * 8;
-          const f32x4_t a0 = *(const f32x4_t*)sp, a1 = *(const f32x4_t*)(sp + 4);
+        for (int j = 0; j < 8; ++j) f[j] = s0[it][j >> 2][j & 3];
+        if (ns > 1) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { f[j] += a0[j]; f[4 + j] += a1[j]; }
+          for (int j = 0; j < 8; ++j) f[j] += s1[it][j >> 2][j & 3];
+          for (int sI = 2; sI < ns; ++sI) {
+            const float* sp = slabs + ((int64_t)sI * tokens + row) * hidden + i * 8;
+            const f32x4_t a0 = *(const f32x4_t*)sp, a1 = *(const f32x4_t*)(sp + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { f[j] += a0[j]; f[4 + j] += a1[j]; }
+          }
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = round_via<T>(f[j] * sxm * (slab_sw ? slab_sw[i * 8 + j] : 1.0f));
+        for (int j = 0; j < 8; ++j) f[j] = round_via<T>(f[j] * sxm * (slab_sw ? swr[it][j >> 2][j & 3] : 1.0f));
       } else {
-        const V8<T> a = ld8(x + row * hidden + i * 8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = (float)a.v[j];
+        for (int j = 0; j < 8; ++j) f[j] = (float)xreg[it].v[j];
       }
       if (residual) {
-        const V8<T> r = ld8(residual + row * hidden + i * 8);
         V8<T> ro;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          f[j] += (float)r.v[j];
+          f[j] += (float)rreg[it].v[j];
           ro.v[j] = (T)f[j];
         }
         st8(residual + row * hidden + i * 8, ro);
@@ -146,11 +176,10 @@ __global__ __launch_bounds__(256) void add_rmsnorm_quant_kernel(const T* x, cons
   for (int it = 0; it < MAXV; ++it) {
     const int i = threadIdx.x + it * 256;
     if (i < nvec) {
-      const V8<T> w = ld8(weight + i * 8);
       V8<T> o;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        vals[it][j] = round_via<T>((vals[it][j] * rs) * (float)w.v[j]);
+        vals[it][j] = round_via<T>((vals[it][j] * rs) * (float)wreg[it].v[j]);
         o.v[j] = (T)vals[it][j];
       }
       if (out_norm) st8(out_norm + row * hidden + i * 8, o);

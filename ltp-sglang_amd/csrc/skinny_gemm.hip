@@ -439,7 +439,7 @@ int launch_v2(const SkinnyParams& p, int kranges, float* slabs, hipStream_t st) 
   const int ntiles = (p.N + rpt - 1) / rpt;
   const int gx = ntiles < per_range_wgs ? ntiles : per_range_wgs;
   const dim3 grid(gx, kranges);
-  constexpr int PD = DS >= 16 ? 1 : 2;
+  constexpr int PD = 1;
   constexpr int TPP = DS >= 16 ? 2 : 4;
   if (ntiles <= gx)
     hipLaunchKernelGGL((skinny_gemm_v2_kernel<ES, MT, DS, PD, 1, OutT>), grid, dim3(kV2Waves * 64), 0, st, p, rpt, ntiles, slabs);
@@ -557,10 +557,10 @@ int launch_v2_epi(const SkinnyParams& p, const EpiParams& ep, hipStream_t st) {
   const int ntiles = p.N / 16;
   const int gx = ntiles < cus ? ntiles : cus;
   if (ntiles <= gx)
-    hipLaunchKernelGGL((skinny_gemm_v2_kernel<ES_FP8, MT, DS, 2, 1, OutT, EPI>), dim3(gx, 1), dim3(kV2Waves * 64), 0, st, p, 16,
+    hipLaunchKernelGGL((skinny_gemm_v2_kernel<ES_FP8, MT, DS, 1, 1, OutT, EPI>), dim3(gx, 1), dim3(kV2Waves * 64), 0, st, p, 16,
                        ntiles, (float*)nullptr, ep);
   else
-    hipLaunchKernelGGL((skinny_gemm_v2_kernel<ES_FP8, MT, DS, 2, 4, OutT, EPI>), dim3(gx, 1), dim3(kV2Waves * 64), 0, st, p, 16,
+    hipLaunchKernelGGL((skinny_gemm_v2_kernel<ES_FP8, MT, DS, 1, 4, OutT, EPI>), dim3(gx, 1), dim3(kV2Waves * 64), 0, st, p, 16,
                        ntiles, (float*)nullptr, ep);
   SGL_HIP_LAUNCH_CHECK();
   return SGL_MI355_OK;
