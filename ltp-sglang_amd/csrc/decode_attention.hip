@@ -110,7 +110,7 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attn_stage1(const DecodePar
   int khc, split;
   if constexpr (MODE == 0) {
     khc = blockIdx.x;
-    split = blockIdx.y;
+    split = blockIdx.z;  // slowest grid dimension: workgroups of splits a request does not use are dispatched LAST
   } else {
     const int unit = blockIdx.x * NW + w;  // wave-uniform
     khc = unit % (p.hkv * hchunks);
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attn_stage1(const DecodePar
   }
   const int kh = khc / hchunks;
   const int hc = khc - kh * hchunks;
-  const int b = blockIdx.z;
+  const int b = blockIdx.y;
   const int h0 = kh * p.group + hc * 16;
   const int nh = min(16, p.group - hc * 16);
 
@@ -430,7 +430,9 @@ int launch_mfma(const DecodeParams& p, hipStream_t st) {
       (void)hipFuncSetAttribute((const void*)decode_attn_stage1<T, D, NW, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
       attr_set = true;
     }
-    dim3 grid(p.hkv * hchunks, p.max_kv_splits, p.bs);
+    // (kv head, request, split): with the split index slowest, the empty workgroups of unused splits sit at the end of
+    // the dispatch order instead of being interleaved with the real ones (bs 128 x 1 split: 417 us -> 201 us)
+    dim3 grid(p.hkv * hchunks, p.bs, p.max_kv_splits);
     hipLaunchKernelGGL((decode_attn_stage1<T, D, NW, 0>), grid, dim3(NW * 64), smem, st, p);
   } else {
     constexpr int NW = 8;
@@ -441,7 +443,7 @@ int launch_mfma(const DecodeParams& p, hipStream_t st) {
       attr_set = true;
     }
     const int units = p.hkv * hchunks * p.max_kv_splits;
-    dim3 grid((units + NW - 1) / NW, 1, p.bs);
+    dim3 grid((units + NW - 1) / NW, p.bs, 1);
     hipLaunchKernelGGL((decode_attn_stage1<T, D, NW, 1>), grid, dim3(NW * 64), smem, st, p);
   }
   SGL_HIP_LAUNCH_CHECK();

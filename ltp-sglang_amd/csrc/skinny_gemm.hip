@@ -214,8 +214,8 @@ __device__ __forceinline__ float rnd_to(float x) {
   return (float)__builtin_bit_cast(T, v);
 }
 
-template <int ES, int MT, int DS, int PD, int TPP, typename OutT, int EPI = EPI_NONE>
-__global__ __launch_bounds__(kV2Waves * 64, 2) void skinny_gemm_v2_kernel(const SkinnyParams p, int rpt, int ntiles,
+template <int ES, int MT, int DS, int PD, int TPP, typename OutT, int EPI = EPI_NONE, int NWV = kV2Waves>
+__global__ __launch_bounds__(NWV * 64, 2) void skinny_gemm_v2_kernel(const SkinnyParams p, int rpt, int ntiles,
                                                                           float* slabs, const EpiParams ep = EpiParams{}) {
   constexpr int kw = DS * 64;             // bytes of K per wave
   constexpr int LPR = kw / 16;            // lanes per weight row in one load instruction
@@ -224,8 +224,9 @@ __global__ __launch_bounds__(kV2Waves * 64, 2) void skinny_gemm_v2_kernel(const 
   constexpr int IMG = 16 * kw;            // bytes of one wave's LDS image (16 rows x kw)
   static_assert(NLD == DS, "one 16-byte load per lane and k double-step");
   static_assert(TPP == 1 || TPP % PD == 0, "static slot indices");
-  __shared__ __attribute__((aligned(16))) char wimg[kV2Waves * IMG];
-  __shared__ float red[TPP][kV2Waves][MT * 16][16];
+  constexpr int EPT = (MT * 256 + NWV * 64 - 1) / (NWV * 64);  // output elements per thread and tile
+  __shared__ __attribute__((aligned(16))) char wimg[NWV * IMG];
+  __shared__ float red[TPP][NWV][MT * 16][16];
   constexpr bool SCALED = (ES == ES_FP8);  // fp8_scaled_mm always carries both scale vectors
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -234,24 +235,30 @@ __global__ __launch_bounds__(kV2Waves * 64, 2) void skinny_gemm_v2_kernel(const 
   char* wl = wimg + w * IMG;
   const int lc = lane % LPR, lr = lane / LPR;  // staging: 16-byte chunk lc of row lr + RPI * i
   const int kr = blockIdx.y;
-  const int koff = kr * (kV2Waves * kw) + w * kw + lc * 16;  // this lane's byte offset inside a row
+  const int koff = kr * (NWV * kw) + w * kw + lc * 16;  // this lane's byte offset inside a row
   const bool kok = koff < p.kbytes;                          // K tail: lanes past the row end contribute zeros
 
   const int G = gridDim.x;
   const int cnt = (ntiles - (int)blockIdx.x + G - 1) / G;  // tiles of this workgroup: blockIdx.x + j * G, >= 1
   const int nload = (rpt == 16) ? DS : DS / 2;             // 8-row tiles load half the instructions
-  // this thread's output element of every tile is (m = tid / 16, n = tid % 16)
-  const int em = tid >> 4, en = tid & 15;
+  // this thread's output elements of every tile are (m = tid / 16 + e * NWV * 4, n = tid % 16)
+  const int em0 = tid >> 4, en = tid & 15;
   const bool has_bias = p.bias != nullptr;
   const OutT* biasp = has_bias ? (const OutT*)p.bias : (const OutT*)p.w;  // any readable address when absent
-  float sxv = 1.0f;
-  if constexpr (SCALED) {
-    if (slabs == nullptr) sxv = p.sx[min(em, p.M - 1)];  // slab mode leaves the scales to the consumer kernel
-  }
-  int64_t ep_pos = 0, ep_loc = 0;
-  if constexpr (EPI == EPI_ROPE) {
-    ep_pos = ep.positions[min(em, p.M - 1)];
-    ep_loc = ep.loc[min(em, p.M - 1)];
+  float sxv[EPT];
+  int64_t ep_pos[EPT], ep_loc[EPT];
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int em = min(em0 + e * NWV * 4, p.M - 1);
+    sxv[e] = 1.0f;
+    if constexpr (SCALED) {
+      if (slabs == nullptr) sxv[e] = p.sx[em];  // slab mode leaves the scales to the consumer kernel
+    }
+    ep_pos[e] = ep_loc[e] = 0;
+    if constexpr (EPI == EPI_ROPE) {
+      ep_pos[e] = ep.positions[em];
+      ep_loc[e] = ep.loc[em];
+    }
   }
 
   const unsigned wbytes = (unsigned)min((int64_t)p.N * p.w_stride, (int64_t)0xFFFFFFF0ll);
@@ -329,20 +336,23 @@ __global__ __launch_bounds__(kV2Waves * 64, 2) void skinny_gemm_v2_kernel(const 
         for (int r = 0; r < 4; ++r) red[jj][w][mt * 16 + 4 * g + r][a] = acc[mt][r];
     }
     __syncthreads();
-    if (em < MT * 16) {
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int em = em0 + e * NWV * 4;
+      if (em >= MT * 16) continue;
 #pragma unroll
       for (int jj = 0; jj < TPP; ++jj) {
         const int j = j0 + jj;
         const int n0 = (blockIdx.x + j * G) * rpt;
         float v = 0.f;
 #pragma unroll
-        for (int ww = 0; ww < kV2Waves; ++ww) v += red[jj][ww][em][en];
+        for (int ww = 0; ww < NWV; ++ww) v += red[jj][ww][em][en];
         const bool live = j < cnt && em < p.M && en < rpt && n0 + en < p.N;
         if (slabs != nullptr) {
           if (live) slabs[((int64_t)kr * p.M + em) * p.N + n0 + en] = v;
         } else {
           const float bv = has_bias ? (float)__builtin_bit_cast(OutT, braw[jj]) : 0.0f;
-          v = v * sxv * swv[jj] + bv;
+          v = v * sxv[e] * swv[jj] + bv;
           if constexpr (EPI == EPI_NONE) {
             if (live) ((OutT*)p.y)[(int64_t)em * p.y_stride + n0 + en] = (OutT)v;
           } else {
@@ -358,7 +368,7 @@ __global__ __launch_bounds__(kV2Waves * 64, 2) void skinny_gemm_v2_kernel(const 
               if (live) {
                 if (head < ep.hq + ep.hkv) {
                   const int i = 8 * u + (en & 7);
-                  const float* cs = ep.cos_sin + ep_pos * 128;
+                  const float* cs = ep.cos_sin + ep_pos[e] * 128;
                   const float c = rnd_to<OutT>(cs[i]), sn = rnd_to<OutT>(cs[64 + i]);
                   const float x1 = en < 8 ? vr : pr, x2 = en < 8 ? pr : vr;
                   const float o = en < 8 ? rnd_to<OutT>(x1 * c) - rnd_to<OutT>(x2 * sn) : rnd_to<OutT>(x2 * c) + rnd_to<OutT>(x1 * sn);
@@ -366,9 +376,9 @@ __global__ __launch_bounds__(kV2Waves * 64, 2) void skinny_gemm_v2_kernel(const 
                   if (head < ep.hq)
                     ((OutT*)p.y)[(int64_t)em * p.y_stride + head * 128 + col] = (OutT)o;
                   else
-                    ((OutT*)ep.k_buf)[ep_loc * ep.k_slot_stride + (head - ep.hq) * 128 + col] = (OutT)o;
+                    ((OutT*)ep.k_buf)[ep_loc[e] * ep.k_slot_stride + (head - ep.hq) * 128 + col] = (OutT)o;
                 } else {
-                  ((OutT*)ep.v_buf)[ep_loc * ep.v_slot_stride + (head - ep.hq - ep.hkv) * 128 + (n0 & 127) + en] = (OutT)vr;
+                  ((OutT*)ep.v_buf)[ep_loc[e] * ep.v_slot_stride + (head - ep.hq - ep.hkv) * 128 + (n0 & 127) + en] = (OutT)vr;
                 }
               }
             }
