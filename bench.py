@@ -207,6 +207,17 @@ def main():
 
     if rank != 0:
         return
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the process, so the per-launch figure
+    # comes from the committed summary of a `rocprofv3 --pmc` pass over this same command (tools/pmc_traffic.py)
+    traffic, traffic_src = None, None
+    pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_pmc_traffic.json")
+    if os.path.exists(pmc_path) and (args.model, args.quant, bs, seq, world) == ("llama3-8b", "w8a8_fp8", 32, 2048, 1):
+        with open(pmc_path) as f:
+            pmc = json.load(f)
+        k1 = pmc.get("kernels", {}).get("decode_attn_stage1", {})
+        if "fetch_bytes_per_launch" in k1:
+            traffic = k1["fetch_bytes_per_launch"] + k1.get("write_bytes_per_launch", 0.0)
+            traffic_src = "profiles/round1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; FETCH_SIZE x2 on gfx950)"
     tok_s = bs * args.steps / elapsed
     weights_bytes = lin_params * (1 if quant in ("w8a8_fp8", "fp8") else (0.5 if quant == "awq" else 2)) + V * hid * 2
     step_bytes = weights_bytes + bs * (seq + args.warmup + args.steps / 2) * L * 2 * hkv * d * 2
@@ -224,8 +235,8 @@ def main():
         "step_roofline": {"algorithmic_bytes_per_step": step_bytes, "hbm_peak_GBps": 8000.0,
                           "frac_of_hbm_roofline": step_bytes / (elapsed / args.steps) / (8e12 * world)},
         "roofline": {"kernel": "decode_attn_stage1", "bound": "hbm", "achieved": achieved, "peak": 8000.0,
-                     "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
-                     "launch_us": attn_ms * 1e3, "algorithmic_bytes_per_launch": kv_bytes},
+                     "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
+                     "traffic_source": traffic_src, "launch_us": attn_ms * 1e3, "algorithmic_bytes_per_launch": kv_bytes},
     }
     if not args.no_cpu_baseline and args.model != "tiny":
         out["cpu_baseline"] = cpu_baseline_sample(cfg, bs, seq, L)

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Round profile on the GPU box: kernel stats of the default bench command, then the two PMC passes (separately).
+#   tools/profile_round.sh <tag>     -> gpurun_out/<tag>_kernel_stats.csv, gpurun_out/<tag>_pmc_traffic.json
+set -e -o pipefail
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+TAG=${1:-round}
+OUT=$R/gpurun_out
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o bench -- \
+  python3 $R/bench.py --no-cpu-baseline > $OUT/${TAG}_bench_under_rocprof.log 2>&1
+cp $(find $OUT/prof_$TAG -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_kernel_stats.csv
+echo "[profile] kernel stats done"
+timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_$TAG -o pmc -- \
+  python3 $R/bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline > $OUT/${TAG}_pmc_fetch.log 2>&1
+echo "[profile] FETCH_SIZE pass done"
+timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_$TAG -o pmc -- \
+  python3 $R/bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline > $OUT/${TAG}_pmc_write.log 2>&1
+echo "[profile] WRITE_SIZE pass done"
+python3 $R/tools/pmc_traffic.py $OUT/pmc_fetch_$TAG $OUT/pmc_write_$TAG > $OUT/${TAG}_pmc_traffic.json
+# the raw per-dispatch CSVs are large: keep only the summaries in gpurun_out
+rm -rf $OUT/pmc_fetch_$TAG $OUT/pmc_write_$TAG
+find $OUT/prof_$TAG -name '*kernel_trace.csv' -delete
