@@ -42,6 +42,17 @@ __device__ __forceinline__ void mfma_chunk(const u32x4_t& a, const u32x4_t& b, f
   }
 }
 
+// fp8: the block-scaled form v_mfma_scale_f32_16x16x128_f8f6f4 with unit (E8M0 = 127) scales runs at twice the rate
+// of the non-scaled 16x16x32 fp8 MFMA; lane (row a, group g) supplies 32 K bytes (hardware order: 32 g .. 32 g + 31).
+// The sum over K does not care which 32 bytes a lane group takes as long as A and B agree, so group g takes the 16-byte
+// chunks g and 4 + g of the 128-byte slice: the same LDS read pattern as the 16x16x32 path, conflict free under lds_off.
+typedef int i32x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void mfma_mx(const u32x4_t& a0, const u32x4_t& a1, const u32x4_t& b0, const u32x4_t& b1, f32x4_t& acc) {
+  const i32x8_t av = {(int)a0[0], (int)a0[1], (int)a0[2], (int)a0[3], (int)a1[0], (int)a1[1], (int)a1[2], (int)a1[3]};
+  const i32x8_t bv = {(int)b0[0], (int)b0[1], (int)b0[2], (int)b0[3], (int)b1[0], (int)b1[1], (int)b1[2], (int)b1[3]};
+  acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bv, acc, 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+}
+
 constexpr int BM = 128, BN = 128, BKB = 128;  // BKB: bytes of K per slice
 constexpr int TILE_BYTES = BM * BKB;          // 16 KiB per operand per buffer
 
@@ -109,6 +120,20 @@ __global__ __launch_bounds__(256, 2) void tiled_gemm_kernel(const GemmParams p) 
     if (kt + 1 < nk) gload(kt + 1);
     const char* xa = smem + buf * 2 * TILE_BYTES;
     const char* wa = xa + TILE_BYTES;
+    if constexpr (ES == TG_FP8) {
+      u32x4_t af[4][2], bf[4][2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          af[i][h] = *(const u32x4_t*)(xa + lds_off(wm + 16 * i + a, 4 * h + g));
+          bf[i][h] = *(const u32x4_t*)(wa + lds_off(wn + 16 * i + a, 4 * h + g));
+        }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mfma_mx(af[i][0], af[i][1], bf[j][0], bf[j][1], acc[i][j]);
+    } else {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       u32x4_t af[4], bf[4];
@@ -121,6 +146,7 @@ __global__ __launch_bounds__(256, 2) void tiled_gemm_kernel(const GemmParams p) 
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) mfma_chunk<ES>(af[i], bf[j], acc[i][j]);
+    }
     }
     if (kt + 1 < nk) lstore(buf ^ 1);
     __syncthreads();
@@ -147,6 +173,153 @@ __global__ __launch_bounds__(256, 2) void tiled_gemm_kernel(const GemmParams p) 
       }
     }
   }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// fp8 256x256 tile: 8 waves (2 along M x 4 along N, 128 x 64 outputs each = 8 x 4 scaled MFMAs per 128-byte K slice),
+// both operands staged global -> LDS by the LDS-DMA form of the load (no VGPR staging, swizzle applied on the global
+// source address), two 64 KiB buffers, ONE barrier per K slice with the next slice's loads in flight across the whole
+// compute phase.  Computed transposed (A operand = W rows, B operand = X rows) so a lane ends up with 4 consecutive n of
+// one output row: 8-byte packed stores.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int T2 = 256;
+constexpr int OPB = T2 * BKB;  // 32 KiB per operand per buffer
+
+__device__ __forceinline__ void glds16(const char* g, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <typename OutT>
+__global__ __launch_bounds__(512, 1) void fp8_gemm256_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][W 32 KiB | X 32 KiB]
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int bid = blockIdx.x;
+  const int q = nwg / 8, r8 = nwg % 8, xcd = bid % 8;
+  const int wgid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + bid / 8;
+  const int tm = wgid / p.tiles_n, tn = wgid - tm * p.tiles_n;
+  const int m0 = tm * T2, n0 = tn * T2;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = (w >> 2) * 128, wn = (w & 3) * 64;
+  const int a = lane & 15, g = lane >> 4;
+
+  // LDS-DMA staging: wave w fills rows 32 w .. 32 w + 31 of both operands, 8 rows (1 KiB) per instruction; the lane
+  // that writes position (lane & 7) of row R loads the chunk the swizzle keeps there
+  const char* wsrc[4];
+  const char* xsrc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int row = 32 * w + 8 * t + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    wsrc[t] = p.w + (int64_t)min(n0 + row, p.N - 1) * p.w_stride + chunk * 16;
+    xsrc[t] = p.x + (int64_t)min(m0 + row, p.M - 1) * p.x_stride + chunk * 16;
+  }
+  const int nk = p.kbytes / BKB;
+  auto stage = [&](int kt, int buf) {
+    char* wb = smem + buf * 2 * OPB + (32 * w) * BKB;
+    const int off = kt * BKB;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      glds16(wsrc[t] + off, wb + t * 8 * BKB);
+      glds16(xsrc[t] + off, wb + OPB + t * 8 * BKB);
+    }
+  };
+
+  f32x4_t acc[4][8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  stage(0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    stage(min(kt + 1, nk - 1), buf ^ 1);  // (the last iteration re-stages its own slice into the idle buffer: branch free)
+    const char* wa = smem + buf * 2 * OPB;
+    const char* xa = wa + OPB;
+    u32x4_t wf[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) wf[j][h] = *(const u32x4_t*)(wa + lds_off(wn + 16 * j + a, 4 * h + g));
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      u32x4_t xf[4][2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) xf[i][h] = *(const u32x4_t*)(xa + lds_off(wm + 64 * half + 16 * i + a, 4 * h + g));
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mfma_mx(wf[j][0], wf[j][1], xf[i][0], xf[i][1], acc[j][4 * half + i]);
+    }
+    __syncthreads();  // drains this wave's LDS-DMA (vmcnt) and everybody's reads of buf before it is re-staged
+  }
+
+  // ---- epilogue: acc[j][i][r] -> row m0+wm+16i+a, col n0+wn+16j+4g+r ----
+  const bool vec_ok = (p.y_stride % 4 == 0) && (((uintptr_t)p.y & 7) == 0);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m = m0 + wm + 16 * i + a;
+    if (m >= p.M) continue;
+    const float sxv = p.sx ? p.sx[m] : 1.0f;
+    OutT* yrow = (OutT*)p.y + (int64_t)m * p.y_stride;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn + 16 * j + 4 * g;
+      if (n >= p.N) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int nn = min(n + r, p.N - 1);
+        const float swv = p.sw ? p.sw[nn] : 1.0f;
+        const float bv = p.bias ? (float)((const OutT*)p.bias)[nn] : 0.0f;
+        v[r] = acc[j][i][r];
+        if (p.sx) v[r] *= sxv;
+        v[r] = v[r] * swv + bv;
+      }
+      if (vec_ok && n + 3 < p.N) {
+        typedef OutT o4_t __attribute__((ext_vector_type(4)));
+        const o4_t o = {(OutT)v[0], (OutT)v[1], (OutT)v[2], (OutT)v[3]};
+        *(o4_t*)(yrow + n) = o;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n + r < p.N) yrow[n + r] = (OutT)v[r];
+      }
+    }
+  }
+}
+
+int tg_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+  }
+  return cus;
+}
+int g_tiled_force = 0;  // test hook: 1 = always the 128x128 kernel, 2 = the 256x256 kernel whenever its shape rules allow
+
+template <typename OutT>
+int launch256(GemmParams& p, hipStream_t st) {
+  constexpr int smem = 2 * 2 * OPB;  // 128 KiB
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)fp8_gemm256_kernel<OutT>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  p.tiles_m = (p.M + T2 - 1) / T2;
+  p.tiles_n = (p.N + T2 - 1) / T2;
+  hipLaunchKernelGGL((fp8_gemm256_kernel<OutT>), dim3(p.tiles_m * p.tiles_n), dim3(512), smem, st, p);
+  SGL_HIP_LAUNCH_CHECK();
+  return SGL_MI355_OK;
 }
 
 template <int ES, typename OutT>
@@ -182,12 +355,24 @@ int run(const void* x, int64_t xs, const void* w, int64_t ws, void* y, int64_t y
   p.sx = sx; p.sw = sw; p.bias = bias;
   p.M = M; p.N = N; p.kbytes = K * es;
   hipStream_t st = (hipStream_t)stream;
-  if (in_dtype == SGL_FP8_E4M3) return out_dtype == SGL_BF16 ? launch<TG_FP8, __bf16>(p, st) : launch<TG_FP8, _Float16>(p, st);
+  if (in_dtype == SGL_FP8_E4M3) {
+    // the 256x256 kernel wants whole 128-byte K slices and enough tiles to fill every CU at least once
+    const int64_t tiles256 = (int64_t)((M + T2 - 1) / T2) * ((N + T2 - 1) / T2);
+    const bool can256 = p.kbytes % BKB == 0 && p.kbytes >= BKB;
+    if (can256 && g_tiled_force != 1 && (g_tiled_force == 2 || tiles256 >= tg_cus()))
+      return out_dtype == SGL_BF16 ? launch256<__bf16>(p, st) : launch256<_Float16>(p, st);
+    return out_dtype == SGL_BF16 ? launch<TG_FP8, __bf16>(p, st) : launch<TG_FP8, _Float16>(p, st);
+  }
   if (in_dtype == SGL_BF16) return out_dtype == SGL_BF16 ? launch<TG_BF16, __bf16>(p, st) : launch<TG_BF16, _Float16>(p, st);
   return out_dtype == SGL_BF16 ? launch<TG_F16, __bf16>(p, st) : launch<TG_F16, _Float16>(p, st);
 }
 
 }  // namespace
+
+extern "C" int sgl_mi355_fp8_gemm_force_tile(int mode) {
+  g_tiled_force = mode;
+  return SGL_MI355_OK;
+}
 
 extern "C" int sgl_mi355_fp8_gemm(const void* x, int64_t x_stride_elems, const void* w, int64_t w_stride_elems, void* y,
                                   int64_t y_stride_elems, const float* scales_x, const float* scales_w, const void* bias,

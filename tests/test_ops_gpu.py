@@ -262,13 +262,40 @@ def test_awq_dequantize_qwen2_shapes_vs_oracle(k, nc, dtype, sk):
 
 
 # ---------------------------------------------------------------- tiled GEMM at prefill-sized M
-@pytest.mark.parametrize("m,n,k", [(256, 384, 4096), (1000, 136, 1024), (129, 6144, 512)])
-def test_fp8_scaled_mm_large_m_vs_oracle(m, n, k, sk):
-    case = dict(m=m, n=n, k=k, bias=True, out="bf16")
+@pytest.mark.parametrize("tile_mode", [1, 2])
+@pytest.mark.parametrize("m,n,k,out", [(256, 384, 4096, "bf16"), (1000, 136, 1024, "bf16"), (129, 6144, 512, "f16"),
+                                       (515, 776, 1152, "bf16"), (768, 136, 256, "f16")])
+def test_fp8_scaled_mm_large_m_vs_oracle(m, n, k, out, tile_mode, sk):
+    # tile_mode 1: 128x128 tiles; 2: the 256x256 LDS-DMA kernel (ragged M / N edges, odd K-slice counts)
+    from ltp_sglang_amd import _cabi
+    case = dict(m=m, n=n, k=k, bias=True, out=out)
     c = _cases.build_gemm_case(case, seed=m)
-    o = sk.fp8_scaled_mm(c["a"].to(DEV), c["w"].to(DEV).t(), c["sa"].to(DEV), c["sb"].to(DEV), c["out_dtype"], c["bias"].to(DEV))
+    _cabi.check(_cabi.lib.sgl_mi355_fp8_gemm_force_tile(tile_mode))
+    try:
+        o = sk.fp8_scaled_mm(c["a"].to(DEV), c["w"].to(DEV).t(), c["sa"].to(DEV), c["sb"].to(DEV), c["out_dtype"], c["bias"].to(DEV))
+    finally:
+        _cabi.lib.sgl_mi355_fp8_gemm_force_tile(0)
     ref = oq.scaled_mm(c["a"], c["w"].t(), c["sa"], c["sb"], c["out_dtype"], c["bias"])
     torch.testing.assert_close(o.cpu().float(), ref.float(), rtol=1.6e-2, atol=0.3)
+
+
+def test_fp8_gemm_tile_kernels_agree(sk):
+    # exact small-integer operands: every product and partial sum is exact in f32, so both kernels must match bit for bit
+    from ltp_sglang_amd import _cabi
+    g = torch.Generator().manual_seed(5)
+    m, n, k = 520, 776, 2048
+    a = torch.randint(-3, 4, (m, k), generator=g).float().to(torch.float8_e4m3fn).to(DEV)
+    w = torch.randint(-2, 3, (n, k), generator=g).float().to(torch.float8_e4m3fn).to(DEV)
+    sa, sb = torch.ones(m, device=DEV), torch.ones(n, device=DEV)
+    outs = []
+    for mode in (1, 2):
+        _cabi.check(_cabi.lib.sgl_mi355_fp8_gemm_force_tile(mode))
+        try:
+            outs.append(sk.fp8_scaled_mm(a, w.t(), sa, sb, torch.float16))
+        finally:
+            _cabi.lib.sgl_mi355_fp8_gemm_force_tile(0)
+    ref = (a.float() @ w.float().t()).to(torch.float16)
+    assert torch.equal(outs[0], ref) and torch.equal(outs[1], ref)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
