@@ -132,6 +132,7 @@ class LlamaForCausalLM(nn.Module):
         super().__init__()
         self.cfg, self.dtype = cfg, dtype
         self.fused_decode = True
+        self.fused_extend = True
         self.fused_epilogues = True
         qc = None
         if quantization is not None:
@@ -264,9 +265,52 @@ class LlamaForCausalLM(nn.Module):
                                                      dtype=self.dtype)
         return K.dense_linear(hidden, self.lm_head, None, out_dtype=self.dtype)
 
+    def _fused_extend_ok(self, forward_batch) -> bool:
+        return (self.fused_extend and forward_batch.forward_mode.is_extend() and self.tp_size == 1
+                and self.quant_config is not None and self.quant_config.get_name() == "w8a8_fp8"
+                and self.cfg.hidden_size <= 8192 and 2 * self.cfg.intermediate_size <= 65536)
+
+    def forward_extend_fused(self, input_ids, positions, forward_batch: ForwardBatch, last_index):
+        """Prefill with the same fused elementwise kernels as the decode step (add+RMSNorm+quant, RoPE+KV write,
+        SiluAndMul+quant); the linears are the tiled fp8 GEMM.  Bit-identical to the unfused op sequence of forward()."""
+        pool = forward_batch.token_to_kv_pool
+        backend = forward_batch.attn_backend
+        hidden = K.embedding(input_ids, self.embed_tokens)
+        residual = None
+        for layer in self.layers:
+            attn, mlp = layer.self_attn, layer.mlp
+            ln1, ln2 = layer.input_layernorm, layer.post_attention_layernorm
+            if residual is None:
+                _, xq, xs = K.fused_add_rmsnorm_quant_fp8(hidden, None, ln1.weight.data, ln1.variance_epsilon)
+                residual = hidden
+            else:
+                _, xq, xs = K.fused_add_rmsnorm_quant_fp8(hidden, residual, ln1.weight.data, ln1.variance_epsilon)
+            lid = attn.attn.layer_id
+            qkv = K.fp8_scaled_mm(xq, attn.qkv_proj.weight, xs.view(-1), attn.qkv_proj.weight_scale.view(-1), self.dtype,
+                                  attn.qkv_proj.bias)
+            q, k, v = qkv.split([attn.q_size, attn.kv_size, attn.kv_size], dim=-1)
+            K.rope_set_kv(positions, q, k, v, attn.head_dim, attn.rotary_emb.cos_sin_cache, True, pool.get_key_buffer(lid),
+                          pool.get_value_buffer(lid), forward_batch.out_cache_loc)
+            o = backend.forward_extend(q, k.view(-1, attn.num_kv_heads, attn.head_dim), v.view(-1, attn.num_kv_heads, attn.head_dim),
+                                       attn.attn, forward_batch, save_kv_cache=False)
+            oq, osc = K.sglang_per_token_quant_fp8(o)
+            hidden = K.fp8_scaled_mm(oq, attn.o_proj.weight, osc.view(-1), attn.o_proj.weight_scale.view(-1), self.dtype)
+            _, hq2, hs2 = K.fused_add_rmsnorm_quant_fp8(hidden, residual, ln2.weight.data, ln2.variance_epsilon)
+            gate_up = K.fp8_scaled_mm(hq2, mlp.gate_up_proj.weight, hs2.view(-1), mlp.gate_up_proj.weight_scale.view(-1), self.dtype)
+            aq, asc = K.silu_and_mul_quant_fp8(gate_up)
+            hidden = K.fp8_scaled_mm(aq, mlp.down_proj.weight, asc.view(-1), mlp.down_proj.weight_scale.view(-1), self.dtype)
+        if last_index is not None:  # only the last token of each request reaches the final norm and lm_head
+            hidden = hidden.index_select(0, last_index)
+            residual = residual.index_select(0, last_index)
+        hidden, _, _ = K.fused_add_rmsnorm_quant_fp8(hidden, residual, self.norm.weight.data, self.norm.variance_epsilon,
+                                                     want_norm=True, want_quant=False)
+        return K.dense_linear(hidden, self.lm_head, None, out_dtype=self.dtype)
+
     def forward(self, input_ids, positions, forward_batch: ForwardBatch, last_index: Optional[torch.Tensor] = None):
         if self._fused_decode_ok(forward_batch):
             return self.forward_decode_fused(input_ids, positions, forward_batch)
+        if self._fused_extend_ok(forward_batch):
+            return self.forward_extend_fused(input_ids, positions, forward_batch, last_index)
         hidden_states = K.embedding(input_ids, self.embed_tokens)
         residual = None
         for layer in self.layers:

@@ -83,6 +83,7 @@ def test_fused_and_graph_decode_are_bit_identical(pkg):
     for mode in ("plain", "fused_ops", "fused", "graph"):
         runner = SyntheticModelRunner(cfg, "w8a8_fp8", max_running_requests=8, context_len=256, max_total_tokens=2048, device=DEV, seed=5)
         runner.model.fused_decode = mode != "plain"
+        runner.model.fused_extend = mode != "plain"   # seq[0] (the prefill logits) compares fused vs plain extend
         runner.model.fused_epilogues = mode in ("fused", "graph")
         g = torch.Generator().manual_seed(1)
         ids = [torch.randint(0, cfg.vocab_size, (n,), generator=g).to(DEV) for n in (50, 7, 33, 1)]
