@@ -215,7 +215,7 @@ __device__ __forceinline__ float rnd_to(float x) {
 }
 
 template <int ES, int MT, int DS, int PD, int TPP, typename OutT, int EPI = EPI_NONE, int NWV = kV2Waves>
-__global__ __launch_bounds__(NWV * 64, 2) void skinny_gemm_v2_kernel(const SkinnyParams p, int rpt, int ntiles,
+__global__ __launch_bounds__(NWV * 64, 1) void skinny_gemm_v2_kernel(const SkinnyParams p, int rpt, int ntiles,
                                                                           float* slabs, const EpiParams ep = EpiParams{}) {
   constexpr int kw = DS * 64;             // bytes of K per wave
   constexpr int LPR = kw / 16;            // lanes per weight row in one load instruction
@@ -263,6 +263,17 @@ __global__ __launch_bounds__(NWV * 64, 2) void skinny_gemm_v2_kernel(const Skinn
 
   const unsigned wbytes = (unsigned)min((int64_t)p.N * p.w_stride, (int64_t)0xFFFFFFF0ll);
   const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, wbytes, 0x00020000);
+  // ---- X rows of this wave's K slice first (L2 hits, back within a microsecond), THEN the first W tiles (HBM): the
+  // counted wait below covers only the X loads, so the fragments are built while the weights are still in flight ----
+  u32x4_t xr[MT][DS];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int i = 0; i < DS; ++i) {
+      const int m = mt * 16 + lr + RPI * i;
+      const u32x4_t v = *(const u32x4_t*)(p.x + (int64_t)min(m, p.M - 1) * p.x_stride + (kok ? koff : 0));
+      xr[mt][i] = (m < p.M && kok) ? v : zero4;
+    }
   u32x4_t wreg[PD][DS];
   auto issue = [&](int slot, int j) {
     const int n0t = (blockIdx.x + j * G) * rpt;
@@ -276,21 +287,14 @@ __global__ __launch_bounds__(NWV * 64, 2) void skinny_gemm_v2_kernel(const Skinn
 #pragma unroll
   for (int j = 0; j < PD; ++j) issue(j, j);
 
-  // ---- X fragments of this wave's K slice, once: coalesced rows -> swizzled image -> A-fragment registers ----
+  // coalesced rows -> swizzled image -> A-fragment registers, once per workgroup
   u32x4_t xf[MT][DS];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
-    u32x4_t xr[DS];
-#pragma unroll
-    for (int i = 0; i < DS; ++i) {
-      const int m = mt * 16 + lr + RPI * i;
-      const u32x4_t v = *(const u32x4_t*)(p.x + (int64_t)min(m, p.M - 1) * p.x_stride + (kok ? koff : 0));
-      xr[i] = (m < p.M && kok) ? v : zero4;
-    }
 #pragma unroll
     for (int i = 0; i < DS; ++i) {
       const int row = lr + RPI * i;
-      *(u32x4_t*)(wl + row * kw + (((lc ^ row) & (LPR - 1)) << 4)) = xr[i];
+      *(u32x4_t*)(wl + row * kw + (((lc ^ row) & (LPR - 1)) << 4)) = xr[mt][i];
     }
 #pragma unroll
     for (int sI = 0; sI < DS; ++sI) xf[mt][sI] = *(const u32x4_t*)(wl + a * kw + ((((4 * sI + g) ^ a) & (LPR - 1)) << 4));
@@ -452,7 +456,7 @@ int launch_v2(const SkinnyParams& p, int kranges, float* slabs, hipStream_t st) 
   constexpr int PD = 1;
   constexpr int TPP = DS >= 16 ? 2 : 4;
   if (ntiles <= gx)
-    hipLaunchKernelGGL((skinny_gemm_v2_kernel<ES, MT, DS, PD, 1, OutT>), grid, dim3(kV2Waves * 64), 0, st, p, rpt, ntiles, slabs);
+    hipLaunchKernelGGL((skinny_gemm_v2_kernel<ES, MT, DS, 1, 1, OutT>), grid, dim3(kV2Waves * 64), 0, st, p, rpt, ntiles, slabs);
   else
     hipLaunchKernelGGL((skinny_gemm_v2_kernel<ES, MT, DS, PD, TPP, OutT>), grid, dim3(kV2Waves * 64), 0, st, p, rpt, ntiles, slabs);
   SGL_HIP_LAUNCH_CHECK();

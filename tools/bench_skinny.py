@@ -6,7 +6,7 @@ from __graft_entry__ import load_package
 load_package()
 from ltp_sglang_amd import sgl_kernel as K
 
-def run(m, n, k, dtype=torch.float8_e4m3fn, copies=12, iters=10):
+def run(m, n, k, dtype=torch.float8_e4m3fn, copies=12, iters=10, launches=None):
     dev = "cuda:0"
     es = 1 if dtype == torch.float8_e4m3fn else 2
     copies = max(2, min(copies, int(1.5e9 // (n * k * es))))
@@ -19,6 +19,7 @@ def run(m, n, k, dtype=torch.float8_e4m3fn, copies=12, iters=10):
         ws = [torch.randn(n, k, device=dev).to(dtype) for _ in range(copies)]
         x = torch.randn(m, k, device=dev).to(dtype)
         f = lambda w: K.dense_linear(x, w)
+    if launches: ws = [ws[i % len(ws)] for i in range(launches)]; copies = launches
     for w in ws: f(w)
     torch.cuda.synchronize()
     # capture the sweep over all weight copies in one HIP graph: no host launch overhead in the timing
