@@ -239,6 +239,21 @@ int64_t sgl_mi355_radix_total_size(void* tree);
 int64_t sgl_mi355_radix_num_nodes(void* tree);
 int64_t sgl_mi355_radix_node_info(void* tree, int64_t node, int64_t* parent, int64_t* lock_ref, int64_t* num_children);
 
+/* Fused int4 dequant + GEMM for decode-sized M (<= 32): the product AWQLinearMethod.apply computes as awq_dequantize +
+ * torch.matmul (python/sglang/srt/layers/quantization/awq.py:401-418), with the weight values bit-identical to
+ * sgl_mi355_awq_dequantize's and nothing but int4 read from HBM.  The weight is re-laid once at load time
+ * (process_weights_after_loading, awq.py:393-399; the role awq_marlin_repack plays for the reference's Marlin path,
+ * sgl-kernel/csrc/gemm/marlin/awq_marlin_repack.cu) into MFMA-fragment order:
+ *   qpacked int32 [N/16][K/128][64][4], sz int32 [K/G][N] = (zero << 16) | scale bits.   K % 128 == 0, N % 16 == 0,
+ *   group_size 32, 64 or a multiple of 128. */
+int sgl_mi355_awq_repack(const void* qweight, const void* scales, const void* qzeros, void* qpacked, void* sz, int K, int N,
+                         int group_size, int scale_dtype, void* stream);
+/* number of f32 [M, N] slabs sgl_mi355_awq_gemm needs as workspace for this K (1: none) */
+int sgl_mi355_awq_gemm_num_kranges(int K);
+int sgl_mi355_awq_gemm(const void* x, int64_t x_stride_elems, const void* qpacked, const void* sz, void* y,
+                       int64_t y_stride_elems, const void* bias, int M, int N, int K, int group_size, int dtype,
+                       float* workspace, int64_t workspace_floats, void* stream);
+
 /* out[cols, rows] = in[rows, cols]^T for 16-bit elements (weight re-layout between awq_dequantize's [K, N] and
  * the [N, K] the GEMMs stream; AWQLinearMethod.apply, layers/quantization/awq.py:401-418) */
 int sgl_mi355_transpose_2d(void* out, const void* in, int rows, int cols, void* stream);

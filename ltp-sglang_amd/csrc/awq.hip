@@ -37,6 +37,326 @@ __global__ __launch_bounds__(256) void awq_dequant_kernel(const uint32_t* __rest
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Fused int4 dequant + skinny GEMM for decode-sized M (<= 32):  y[m][n] = sum_k x[m][k] * W[k][n] (+ bias), with
+// W[k][n] EXACTLY the value awq_dequantize produces (the dequantisation happens in registers, between the global
+// load and the MFMA; nothing but int4 weights is ever read from HBM).
+//
+// Replaces the reference's AWQLinearMethod.apply = awq_dequantize + torch.matmul
+// (python/sglang/srt/layers/quantization/awq.py:401-418), which re-materialises the whole bf16 weight every call
+// (0.5 B read + 2 B written + 2 B read per parameter; fused: 0.5 B).
+//
+// The weight is re-laid once at load time (the role awq_marlin_repack plays for the reference's Marlin path,
+// sgl-kernel/csrc/gemm/marlin/awq_marlin_repack.cu) into MFMA-fragment order, so that a wave-wide 16-byte load IS the
+// B operand of four v_mfma_f32_16x16x32 k-steps:
+//   qpacked int32 [N/16][K/128][64 lanes][4]:  word s of lane (a = n % 16, g) of tile n/16, block k/128 holds
+//   q[k = 128 b + 32 s + 8 g + e][n], e = 0..7, in nibble (e & 1) * 4 + e / 2, so (word >> 4 i) & 0x000F000F is the pair
+//   (e = 2 i, 2 i + 1) in the two 16-bit halves     (1 KiB contiguous per (tile, block): perfectly coalesced)
+//   sz     int32 [K/G][N]:  (zero point << 16) | scale bits     (one 4-byte load per lane, block and scale group)
+// Structure = the X-stationary skinny GEMM of skinny_gemm.hip without the LDS re-layout: one 512-thread workgroup per
+// CU; wave w owns k-blocks w, w+8, w+16, w+24 of the k-range (blockIdx.y: 32 blocks = 4096 k) for the whole launch and
+// keeps their X fragments in registers; the workgroup walks 16-column tiles; the 8 waves' partial sums of TPP tiles
+// meet in LDS between two barriers.  k-ranges > 1 (K > 4096) go through f32 slabs and a reduce kernel.
+// Dequantisation, bit-identical to awq_dequantize's T(float(q - z) * float(s)):
+//   f16:  pair | 0x64006400 = (1024 + q) as packed f16; v_pk_add_f16 with -(1024 + z) gives q - z exactly; v_pk_mul_f16 by
+//         the scale rounds once  ->  2 VALU lane-ops per weight;
+//   bf16: v_cvt_f32_ubyteN of the nibbles, v_pk_fma_f32 (q * s - z * s is exact in f32), v_cvt_pk_bf16_f32  ->  2.4 per weight.
+// ---------------------------------------------------------------------------------------------------------
+struct AwqGemmParams {
+  const char* x;            // [M][K] T
+  int64_t x_stride;         // elements
+  const uint32_t* qpacked;  // [N/16][KB][64][4]
+  const uint32_t* sz;       // [K/G][N]
+  void* y;
+  int64_t y_stride;
+  const void* bias;
+  int M, N, K, G, KB;  // KB = K / 128
+};
+
+
+template <int B>
+__device__ __forceinline__ float cvt_ubyte(uint32_t x) {  // float(byte B of x): one VALU op, no shift / mask
+  float f;
+  if constexpr (B == 0) asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(f) : "v"(x));
+  else if constexpr (B == 1) asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(f) : "v"(x));
+  else if constexpr (B == 2) asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(f) : "v"(x));
+  else asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(f) : "v"(x));
+  return f;
+}
+
+template <typename T>
+struct AwqDequant;
+// (szw: zero << 16 | scale bits)  ->  per-lane constants of one scale group, then 8 weights of one packed word
+template <>
+struct AwqDequant<_Float16> {
+  uint32_t s2;      // scale in both halves
+  f16x2_t negzm;    // -(1024 + z) in both halves
+  __device__ __forceinline__ void setup(uint32_t szw) {
+    s2 = (szw & 0xFFFFu) * 0x00010001u;
+    const _Float16 nz = -(_Float16)(float)(1024u + (szw >> 16));
+    negzm = f16x2_t{nz, nz};
+  }
+  __device__ __forceinline__ f16x8_t run(uint32_t wq) const {
+    f16x2_t o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint32_t pr;  // (1024 + q[2i], 1024 + q[2i+1]); one v_and_or_b32 (hipcc emits v_and + v_or for two literals)
+      asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(pr) : "v"(wq >> (4 * i)), "s"(0x000F000Fu), "v"(0x64006400u));
+      const f16x2_t d = __builtin_bit_cast(f16x2_t, pr) + negzm;         // exact small integers
+      o[i] = d * __builtin_bit_cast(f16x2_t, s2);                        // one rounding: T(d * s)
+    }
+    struct P { f16x2_t v[4]; } pk{{o[0], o[1], o[2], o[3]}};
+    return __builtin_bit_cast(f16x8_t, pk);
+  }
+};
+template <>
+struct AwqDequant<__bf16> {
+  float sf, nzs;
+  __device__ __forceinline__ void setup(uint32_t szw) {
+    sf = (float)__builtin_bit_cast(__bf16, (uint16_t)(szw & 0xFFFFu));
+    nzs = -(float)(szw >> 16) * sf;  // exact: 4-bit zero point x 8-bit scale
+  }
+  __device__ __forceinline__ bf16x8_t run(uint32_t wq) const {
+    const uint32_t lo = wq & 0x0F0F0F0Fu, hi = (wq >> 4) & 0x0F0F0F0Fu;  // nibbles 0,2,4,6 = e 0,4,1,5 / 1,3,5,7 = e 2,6,3,7
+    const float e0 = cvt_ubyte<0>(lo), e4 = cvt_ubyte<1>(lo);
+    const float e1 = cvt_ubyte<2>(lo), e5 = cvt_ubyte<3>(lo);
+    const float e2 = cvt_ubyte<0>(hi), e6 = cvt_ubyte<1>(hi);
+    const float e3 = cvt_ubyte<2>(hi), e7 = cvt_ubyte<3>(hi);
+    struct P { __bf16 v[8]; } pk;
+    pk.v[0] = (__bf16)fmaf(e0, sf, nzs); pk.v[1] = (__bf16)fmaf(e1, sf, nzs);
+    pk.v[2] = (__bf16)fmaf(e2, sf, nzs); pk.v[3] = (__bf16)fmaf(e3, sf, nzs);
+    pk.v[4] = (__bf16)fmaf(e4, sf, nzs); pk.v[5] = (__bf16)fmaf(e5, sf, nzs);
+    pk.v[6] = (__bf16)fmaf(e6, sf, nzs); pk.v[7] = (__bf16)fmaf(e7, sf, nzs);
+    return __builtin_bit_cast(bf16x8_t, pk);
+  }
+};
+
+constexpr int kAwqWaves = 8;
+constexpr int kAwqBpw = 4;  // k-blocks (128 k each) per wave and k-range
+
+template <typename T, int MT, int PD, int TPP, int SG>  // SG = scale groups per 128-k block (1: G % 128 == 0, 2: G = 64, 4: G = 32)
+__global__ __launch_bounds__(kAwqWaves * 64, 1) void awq_gemm_kernel(const AwqGemmParams p, int ntiles, float* slabs) {
+  typedef ElemTraits<T> Tr;
+  typedef typename Tr::vec8 vec8;
+  static_assert(TPP == 1 || TPP % PD == 0, "static slot indices");
+  __shared__ float red[TPP][kAwqWaves][MT * 16][16];
+  __shared__ __attribute__((aligned(16))) char ximg[kAwqWaves * 4096];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int a = lane & 15, g = lane >> 4;
+  const int kr = blockIdx.y;
+  const int b0 = kr * (kAwqWaves * kAwqBpw);
+  const int nb = min(kAwqWaves * kAwqBpw, p.KB - b0);  // k-blocks of this range
+  const int G_ = gridDim.x;
+  const int cnt = (ntiles - (int)blockIdx.x + G_ - 1) / G_;  // tiles of this workgroup: blockIdx.x + j * G_
+
+  // ---- X fragments of this wave's k-blocks, once: coalesced 256-byte row pieces -> swizzled wave-private LDS image ->
+  // A-operand registers (lane (a, g) holds X[m = 16 mt + a][128 b + 32 s + 8 g .. + 7]) ----
+  char* xl = ximg + w * 4096;                 // 16 rows x 256 B
+  const int lc = lane & 15, lr = lane >> 4;   // staging: 16-byte chunk lc of row lr + 4 i
+  vec8 xf[MT][kAwqBpw][4];
+#pragma unroll
+  for (int bi = 0; bi < kAwqBpw; ++bi) {
+    const bool bok = w + kAwqWaves * bi < nb;
+    const int b = b0 + (bok ? w + kAwqWaves * bi : 0);
+    u32x4_t xr[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = mt * 16 + lr + 4 * i;
+        const u32x4_t v = *(const u32x4_t*)((const T*)p.x + (int64_t)min(m, p.M - 1) * p.x_stride + 128 * b + 8 * lc);
+        xr[mt][i] = (m < p.M && bok) ? v : u32x4_t{0u, 0u, 0u, 0u};
+      }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = lr + 4 * i;
+        *(u32x4_t*)(xl + row * 256 + (((lc ^ row) & 15) << 4)) = xr[mt][i];
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        xf[mt][bi][s] = __builtin_bit_cast(vec8, *(const u32x4_t*)(xl + a * 256 + ((((4 * s + g) ^ a) & 15) << 4)));
+    }
+  }
+
+  const int64_t wbytes64 = (int64_t)(p.N / 16) * p.KB * 1024;
+  const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.qpacked, 0, (unsigned)min(wbytes64, (int64_t)0xFFFFFFF0ll), 0x00020000);
+  u32x4_t wreg[PD][kAwqBpw];
+  uint32_t szreg[PD][kAwqBpw][SG];
+  auto issue = [&](int slot, int j) {
+    const int t = blockIdx.x + j * G_;
+    const int tc = min(t, ntiles - 1);  // scale loads stay in range; weight loads past the end are predicated off
+#pragma unroll
+    for (int bi = 0; bi < kAwqBpw; ++bi) {
+      const bool bok = w + kAwqWaves * bi < nb;
+      const int b = b0 + (bok ? w + kAwqWaves * bi : 0);
+      const unsigned off = (j < cnt && bok) ? (unsigned)((((int64_t)t * p.KB + b) * 64 + lane) * 16) : 0xFFFFFFF0u;
+      wreg[slot][bi] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off, 0, 0));
+#pragma unroll
+      for (int q = 0; q < SG; ++q) {
+        const int grp = (128 * b + (128 / SG) * q) / p.G;
+        szreg[slot][bi][q] = p.sz[(int64_t)grp * p.N + 16 * tc + a];
+      }
+    }
+  };
+#pragma unroll
+  for (int j = 0; j < PD; ++j) issue(j, j);
+
+  const int em = tid >> 4, en = tid & 15;  // this thread's output element of every tile
+  const bool has_bias = p.bias != nullptr;
+  const T* biasp = has_bias ? (const T*)p.bias : (const T*)p.sz;  // any readable address when absent
+
+  for (int j0 = 0; j0 < cnt; j0 += TPP) {
+    uint16_t braw[TPP];
+    if (slabs == nullptr) {
+#pragma unroll
+      for (int jj = 0; jj < TPP; ++jj) {
+        const int ne = min((int)(blockIdx.x + min(j0 + jj, cnt - 1) * G_) * 16 + en, p.N - 1);
+        braw[jj] = *(const uint16_t*)(biasp + (has_bias ? ne : 0));
+      }
+    }
+#pragma unroll
+    for (int jj = 0; jj < TPP; ++jj) {
+      const int j = j0 + jj;
+      const int slot = (TPP == 1) ? 0 : (jj % PD);
+      f32x4_t acc[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int bi = 0; bi < kAwqBpw; ++bi) {
+        const u32x4_t wq = wreg[slot][bi];
+        AwqDequant<T> dq;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          if (s % (4 / SG) == 0) dq.setup(szreg[slot][bi][(s * SG) / 4]);
+          const vec8 wfrag = dq.run(wq[s]);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) acc[mt] = Tr::mfma16(xf[mt][bi][s], wfrag, acc[mt]);
+        }
+      }
+      if constexpr (TPP > 1) issue(slot, j + PD);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[jj][w][mt * 16 + 4 * g + r][a] = acc[mt][r];
+    }
+    __syncthreads();
+    if (em < MT * 16) {
+#pragma unroll
+      for (int jj = 0; jj < TPP; ++jj) {
+        const int j = j0 + jj;
+        const int n0 = (blockIdx.x + j * G_) * 16;
+        float v = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < kAwqWaves; ++ww) v += red[jj][ww][em][en];
+        const bool live = j < cnt && em < p.M && n0 + en < p.N;
+        if (slabs != nullptr) {
+          if (live) slabs[((int64_t)kr * p.M + em) * p.N + n0 + en] = v;
+        } else if (live) {
+          if (has_bias) v += (float)__builtin_bit_cast(T, braw[jj]);
+          ((T*)p.y)[(int64_t)em * p.y_stride + n0 + en] = (T)v;
+        }
+      }
+    }
+    if (TPP > 1) __syncthreads();  // the next phase overwrites red
+  }
+}
+
+// y[m][n] = T(sum_kr slabs[kr][m][n] + bias[n])
+template <typename T>
+__global__ __launch_bounds__(256) void awq_slab_reduce_kernel(const float* __restrict__ slabs, int S, const T* bias, T* out,
+                                                              int64_t out_stride, int M, int N) {
+  const int64_t total = (int64_t)M * (N / 4);
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int m = (int)(idx / (N / 4)), n = (int)(idx - (int64_t)m * (N / 4)) * 4;
+    f32x4_t v = *(const f32x4_t*)(slabs + (int64_t)m * N + n);
+    for (int sI = 1; sI < S; ++sI) v += *(const f32x4_t*)(slabs + ((int64_t)sI * M + m) * N + n);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float r = v[c];
+      if (bias) r += (float)bias[n + c];
+      out[(int64_t)m * out_stride + n + c] = (T)r;
+    }
+  }
+}
+
+// qweight [K][N/8] (AWQ nibble order) + qzeros [K/G][N/8] + scales [K/G][N]  ->  qpacked, sz (layouts above)
+__global__ __launch_bounds__(256) void awq_repack_w_kernel(const uint32_t* __restrict__ qweight, uint32_t* __restrict__ qpacked,
+                                                           int K, int N) {
+  const int KB = K / 128, NC = N / 8;
+  const int64_t total = (int64_t)(N / 16) * KB * 256;
+  for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
+    const int s = (int)(o & 3), lane = (int)((o >> 2) & 63);
+    const int64_t tb = o >> 8;
+    const int b = (int)(tb % KB), t = (int)(tb / KB);
+    const int a = lane & 15, g = lane >> 4;
+    const int n = 16 * t + a;
+    const int shift = 4 * ((n & 1) * 4 + ((n & 7) >> 1));  // AWQ order [0,4,1,5,2,6,3,7]: column j sits in nibble (j&1)*4 + j/2
+    uint32_t out = 0;
+#pragma unroll
+    for (int pq = 0; pq < 8; ++pq) {
+      const int k = 128 * b + 32 * s + 8 * g + pq;
+      const int nib = (pq & 1) * 4 + (pq >> 1);  // element pq of the lane's k-run sits in nibble (pq & 1) * 4 + pq / 2
+      out |= ((qweight[(int64_t)k * NC + (n >> 3)] >> shift) & 0xFu) << (4 * nib);
+    }
+    qpacked[o] = out;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void awq_repack_sz_kernel(const uint32_t* __restrict__ qzeros, const T* __restrict__ scales,
+                                                            uint32_t* __restrict__ sz, int groups, int N) {
+  const int NC = N / 8;
+  const int64_t total = (int64_t)groups * N;
+  for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
+    const int n = (int)(o % N);
+    const int64_t grp = o / N;
+    const int shift = 4 * ((n & 1) * 4 + ((n & 7) >> 1));
+    const uint32_t z = (qzeros[grp * NC + (n >> 3)] >> shift) & 0xFu;
+    sz[o] = (z << 16) | (uint32_t)__builtin_bit_cast(uint16_t, scales[o]);
+  }
+}
+
+inline int awq_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+  }
+  return cus;
+}
+
+template <typename T, int MT, int SG>
+int awq_launch(const AwqGemmParams& p, int kranges, float* slabs, hipStream_t st) {
+  const int cus = awq_cus();
+  const int per_range = cus / kranges > 0 ? cus / kranges : 1;
+  const int ntiles = p.N / 16;
+  const int gx = ntiles < per_range ? ntiles : per_range;
+  const dim3 grid(gx, kranges);
+  if (ntiles <= gx)
+    hipLaunchKernelGGL((awq_gemm_kernel<T, MT, 1, 1, SG>), grid, dim3(kAwqWaves * 64), 0, st, p, ntiles, slabs);
+  else
+    hipLaunchKernelGGL((awq_gemm_kernel<T, MT, 2, 4, SG>), grid, dim3(kAwqWaves * 64), 0, st, p, ntiles, slabs);
+  SGL_HIP_LAUNCH_CHECK();
+  return SGL_MI355_OK;
+}
+
+template <typename T>
+int awq_dispatch(const AwqGemmParams& p, int kranges, float* slabs, hipStream_t st) {
+  const int sg = p.G % 128 == 0 ? 1 : 128 / p.G;
+#define SGL_AWQ_CASE(MTv)                                                   \
+  if (sg == 1) return awq_launch<T, MTv, 1>(p, kranges, slabs, st);         \
+  if (sg == 2) return awq_launch<T, MTv, 2>(p, kranges, slabs, st);         \
+  return awq_launch<T, MTv, 4>(p, kranges, slabs, st)
+  if (p.M <= 16) { SGL_AWQ_CASE(1); }
+  SGL_AWQ_CASE(2);
+#undef SGL_AWQ_CASE
+}
+
 }  // namespace
 
 // qweight [K, N/8] int32, scales [K/G, N] (bf16/f16), qzeros [K/G, N/8] int32 -> out [K, N] in the scale dtype.
@@ -58,6 +378,76 @@ extern "C" int sgl_mi355_awq_dequantize(const void* qweight, const void* scales,
   else
     hipLaunchKernelGGL((awq_dequant_kernel<__bf16>), dim3(blocks), dim3(256), 0, st, (const uint32_t*)qweight,
                        (const __bf16*)scales, (const uint32_t*)qzeros, (__bf16*)out, K, num_packed_cols, group_size);
+  SGL_HIP_LAUNCH_CHECK();
+  return SGL_MI355_OK;
+}
+
+// One-off re-layout of an AWQ weight for sgl_mi355_awq_gemm (see the layout note above).  qpacked: K*N/8 int32, sz: (K/G)*N int32.
+extern "C" int sgl_mi355_awq_repack(const void* qweight, const void* scales, const void* qzeros, void* qpacked, void* sz, int K,
+                                    int N, int group_size, int scale_dtype, void* stream) {
+  SGL_CHECK(K > 0 && N > 0 && group_size > 0, "awq_repack: bad shape");
+  SGL_CHECK(qweight && scales && qzeros && qpacked && sz, "awq_repack: null pointer");
+  SGL_CHECK(K % 128 == 0 && N % 16 == 0, "awq_repack: needs K %% 128 == 0 and N %% 16 == 0 (K=%d N=%d)", K, N);
+  SGL_CHECK(K % group_size == 0 && (group_size % 128 == 0 || group_size == 64 || group_size == 32),
+            "awq_repack: group_size=%d must be 32, 64 or a multiple of 128 dividing K", group_size);
+  SGL_CHECK(scale_dtype == SGL_BF16 || scale_dtype == SGL_F16, "awq_repack: scales must be f16 or bf16");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t tw = (int64_t)K * N / 8, ts = (int64_t)(K / group_size) * N;
+  const unsigned bw = (unsigned)((tw + 255) / 256 > 16384 ? 16384 : (tw + 255) / 256);
+  const unsigned bs = (unsigned)((ts + 255) / 256 > 16384 ? 16384 : (ts + 255) / 256);
+  hipLaunchKernelGGL(awq_repack_w_kernel, dim3(bw), dim3(256), 0, st, (const uint32_t*)qweight, (uint32_t*)qpacked, K, N);
+  SGL_HIP_LAUNCH_CHECK();
+  if (scale_dtype == SGL_F16)
+    hipLaunchKernelGGL((awq_repack_sz_kernel<_Float16>), dim3(bs), dim3(256), 0, st, (const uint32_t*)qzeros,
+                       (const _Float16*)scales, (uint32_t*)sz, K / group_size, N);
+  else
+    hipLaunchKernelGGL((awq_repack_sz_kernel<__bf16>), dim3(bs), dim3(256), 0, st, (const uint32_t*)qzeros, (const __bf16*)scales,
+                       (uint32_t*)sz, K / group_size, N);
+  SGL_HIP_LAUNCH_CHECK();
+  return SGL_MI355_OK;
+}
+
+// f32 [M, N] slabs of workspace sgl_mi355_awq_gemm wants (1: none)
+extern "C" int sgl_mi355_awq_gemm_num_kranges(int K) { return (K / 128 + kAwqWaves * kAwqBpw - 1) / (kAwqWaves * kAwqBpw); }
+
+// y [M, N] = x [M, K] . dequant(qpacked, sz) (+ bias); M <= 32; dtype of x / y / bias / scales: SGL_BF16 or SGL_F16.
+extern "C" int sgl_mi355_awq_gemm(const void* x, int64_t x_stride_elems, const void* qpacked, const void* sz, void* y,
+                                  int64_t y_stride_elems, const void* bias, int M, int N, int K, int group_size, int dtype,
+                                  float* workspace, int64_t workspace_floats, void* stream) {
+  SGL_CHECK(M >= 0 && N > 0 && K > 0 && group_size > 0, "awq_gemm: bad shape");
+  if (M == 0) return SGL_MI355_OK;
+  SGL_CHECK(M <= 32, "awq_gemm: M=%d exceeds 32 (use awq_dequantize + the tiled GEMM)", M);
+  SGL_CHECK(x && qpacked && sz && y, "awq_gemm: null pointer");
+  SGL_CHECK(K % 128 == 0 && N % 16 == 0, "awq_gemm: needs K %% 128 == 0 and N %% 16 == 0 (K=%d N=%d)", K, N);
+  SGL_CHECK(K % group_size == 0 && (group_size % 128 == 0 || group_size == 64 || group_size == 32),
+            "awq_gemm: group_size=%d must be 32, 64 or a multiple of 128 dividing K", group_size);
+  SGL_CHECK(dtype == SGL_BF16 || dtype == SGL_F16, "awq_gemm: dtype must be bf16 or f16");
+  SGL_CHECK(x_stride_elems % 8 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)qpacked % 16) == 0,
+            "awq_gemm: x rows and qpacked must be 16-byte aligned");
+  SGL_CHECK((int64_t)K * N / 2 < 0xFFFFFFF0ll, "awq_gemm: weight larger than 4 GiB");
+  AwqGemmParams p;
+  p.x = (const char*)x; p.x_stride = x_stride_elems;
+  p.qpacked = (const uint32_t*)qpacked; p.sz = (const uint32_t*)sz;
+  p.y = y; p.y_stride = y_stride_elems; p.bias = bias;
+  p.M = M; p.N = N; p.K = K; p.G = group_size; p.KB = K / 128;
+  hipStream_t st = (hipStream_t)stream;
+  const int kranges = sgl_mi355_awq_gemm_num_kranges(K);
+  float* slabs = nullptr;
+  if (kranges > 1) {
+    SGL_CHECK(workspace != nullptr && workspace_floats >= (int64_t)kranges * M * N && N % 4 == 0,
+              "awq_gemm: K=%d needs a workspace of %d x M x N floats", K, kranges);
+    slabs = workspace;
+  }
+  const int rc = dtype == SGL_BF16 ? awq_dispatch<__bf16>(p, kranges, slabs, st) : awq_dispatch<_Float16>(p, kranges, slabs, st);
+  if (rc != SGL_MI355_OK || kranges == 1) return rc;
+  const int64_t items = (int64_t)M * (N / 4);
+  const unsigned blocks = (unsigned)((items + 255) / 256 > 2048 ? 2048 : (items + 255) / 256);
+  if (dtype == SGL_BF16)
+    hipLaunchKernelGGL((awq_slab_reduce_kernel<__bf16>), dim3(blocks), dim3(256), 0, st, slabs, kranges, (const __bf16*)bias,
+                       (__bf16*)y, y_stride_elems, M, N);
+  else
+    hipLaunchKernelGGL((awq_slab_reduce_kernel<_Float16>), dim3(blocks), dim3(256), 0, st, slabs, kranges, (const _Float16*)bias,
+                       (_Float16*)y, y_stride_elems, M, N);
   SGL_HIP_LAUNCH_CHECK();
   return SGL_MI355_OK;
 }

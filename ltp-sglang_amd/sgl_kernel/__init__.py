@@ -25,6 +25,8 @@ from .fused import (
 )
 from .gemm import (
     awq_dequantize,
+    awq_gemm,
+    awq_repack,
     dense_linear,
     fp8_linear_slabs,
     fp8_scaled_mm,

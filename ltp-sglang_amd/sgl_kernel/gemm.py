@@ -1,6 +1,6 @@
 """GEMM / quantisation ops with the reference's ``sgl_kernel`` signatures
 (sgl-kernel/python/sgl_kernel/gemm.py:7-10,34-42,100-146)."""
-from typing import Optional
+from typing import Optional, Tuple
 
 import torch
 
@@ -42,6 +42,49 @@ def awq_dequantize(qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.Te
     out = torch.empty((k, nc * 8), dtype=scales.dtype, device=qweight.device)
     check(lib.sgl_mi355_awq_dequantize(ptr(qweight), ptr(scales), ptr(qzeros), ptr(out), k, nc, k // groups,
                                        dtype_code(scales.dtype), current_stream()))
+    return out
+
+
+def awq_repack(qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """One-off re-layout of an AWQ weight into MFMA-fragment order for :func:`awq_gemm`.
+    Returns (qpacked int32 [N/16, K/128, 64, 4], sz int32 [K/G, N] = zero << 16 | scale bits)."""
+    _cuda(qweight, scales, qzeros)
+    if qweight.dtype != torch.int32 or qzeros.dtype != torch.int32:
+        raise RuntimeError("qweight and qzeros must be int32")
+    assert qweight.is_contiguous() and scales.is_contiguous() and qzeros.is_contiguous()
+    k, nc = qweight.shape
+    groups, n = scales.shape
+    if n != nc * 8 or tuple(qzeros.shape) != (groups, nc) or k % groups != 0:
+        raise RuntimeError("awq_repack: inconsistent qweight / scales / qzeros shapes")
+    qpacked = torch.empty((n // 16, k // 128, 64, 4), dtype=torch.int32, device=qweight.device)
+    sz = torch.empty((groups, n), dtype=torch.int32, device=qweight.device)
+    check(lib.sgl_mi355_awq_repack(ptr(qweight), ptr(scales), ptr(qzeros), ptr(qpacked), ptr(sz), k, n, k // groups,
+                                   dtype_code(scales.dtype), current_stream()))
+    return qpacked, sz
+
+
+def awq_gemm(x: torch.Tensor, qpacked: torch.Tensor, sz: torch.Tensor, group_size: int,
+             bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y [M, N] = x [M, K] @ dequant(W) (+ bias) for M <= 32 on a weight re-laid by :func:`awq_repack`; the weight values
+    are exactly awq_dequantize's (awq.py:401-418 computes the same product as dequantize + matmul)."""
+    _cuda(x, qpacked, sz, bias)
+    assert x.dim() == 2 and x.stride(1) == 1 and qpacked.is_contiguous() and sz.is_contiguous()
+    m, k = x.shape
+    n = sz.shape[1]
+    if qpacked.shape[0] * 16 != n or qpacked.shape[1] * 128 != k:
+        raise RuntimeError("awq_gemm: x / qpacked / sz shapes do not match")
+    out = torch.empty((m, n), dtype=x.dtype, device=x.device)
+    kr = lib.sgl_mi355_awq_gemm_num_kranges(k)
+    ws, ws_n = None, 0
+    if kr > 1:
+        need = kr * m * n
+        ws = _WORKSPACES.get(x.device)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(max(need, 1 << 22), dtype=torch.float32, device=x.device)
+            _WORKSPACES[x.device] = ws
+        ws_n = ws.numel()
+    check(lib.sgl_mi355_awq_gemm(ptr(x), x.stride(0), ptr(qpacked), ptr(sz), ptr(out), out.stride(0), ptr(bias), m, n, k,
+                                 int(group_size), dtype_code(x.dtype), ptr(ws), ws_n, current_stream()))
     return out
 
 

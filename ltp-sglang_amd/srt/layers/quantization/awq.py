@@ -1,15 +1,18 @@
 """AWQConfig / AWQLinearMethod: int4 AWQ weights (python/sglang/srt/layers/quantization/awq.py:60-418; linear only,
 Marlin / MoE variants are NVIDIA layouts and out of scope).
 
-apply() follows the reference (:401-418): ``out = awq_dequantize(qweight, scales, qzeros); y = x @ out (+ bias)`` with
-the dequantisation done by the HIP kernel (bit-exact with the reference's) and the product by the HIP GEMMs."""
+apply() computes the reference's product (:401-418): ``out = awq_dequantize(qweight, scales, qzeros); y = x @ out (+ bias)``.
+* decode-sized batches (M <= 32): the FUSED int4 dequant-GEMM (``sgl_kernel.awq_gemm``) on a copy of the weight re-laid
+  once in process_weights_after_loading (``awq_repack``; what awq_marlin_repack is to the reference's Marlin path) — only
+  the int4 bytes are read, the weight values are bit-identical to awq_dequantize's;
+* larger M: awq_dequantize (bit-exact HIP kernel) + the tiled MFMA GEMM, the reference's unfused structure."""
 from typing import Any, Dict, List, Optional
 
 import torch
 from torch.nn.parameter import Parameter
 
 from ...._cabi import check, current_stream, lib, ptr
-from ....sgl_kernel import awq_dequantize, dense_linear
+from ....sgl_kernel import awq_dequantize, awq_gemm, awq_repack, dense_linear
 from .base_config import LinearMethodBase, QuantizationConfig
 
 
@@ -70,11 +73,18 @@ class AWQLinearMethod(LinearMethodBase):
         layer.qweight = Parameter(layer.qweight.data, requires_grad=False)
         layer.qzeros = Parameter(layer.qzeros.data, requires_grad=False)
         layer.scales = Parameter(layer.scales.data, requires_grad=False)
+        k, n, g = layer.qweight.shape[0], layer.scales.shape[1], self.quant_config.group_size
+        layer._awq_packed = None
+        if layer.qweight.is_cuda and k % 128 == 0 and n % 16 == 0 and (g % 128 == 0 or g in (32, 64)):
+            layer._awq_packed = awq_repack(layer.qweight.data, layer.scales.data, layer.qzeros.data)
 
     def apply(self, layer, x: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
         qweight, scales, qzeros = layer.qweight, layer.scales, layer.qzeros
         out_shape = x.shape[:-1] + (qweight.shape[-1] * self.quant_config.pack_factor,)
         x2d = x.reshape(-1, x.shape[-1])
+        packed = getattr(layer, "_awq_packed", None)
+        if packed is not None and x2d.shape[0] <= 32 and x2d.dtype == scales.dtype:
+            return awq_gemm(x2d.contiguous(), packed[0], packed[1], self.quant_config.group_size, bias).reshape(out_shape)
         w_kn = awq_dequantize(qweight, scales, qzeros)              # [K, N], what the reference multiplies by
         w_nk = torch.empty((w_kn.shape[1], w_kn.shape[0]), dtype=w_kn.dtype, device=w_kn.device)
         check(lib.sgl_mi355_transpose_2d(ptr(w_nk), ptr(w_kn), w_kn.shape[0], w_kn.shape[1], current_stream()))

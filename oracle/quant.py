@@ -60,6 +60,23 @@ def _awq_unpack(packed):
     return ((packed.unsqueeze(-1) >> shifts) & 0xF).reshape(packed.shape[0], -1)
 
 
+def awq_repack(qweight, scales, qzeros):
+    """Layout oracle of sgl_mi355_awq_repack (include/sgl_mi355.h): qpacked int32 [N/16, K/128, 64, 4] whose word s of lane
+    (a = n % 16, g) holds q[128 b + 32 s + 8 g + e][n] in nibble (e & 1) * 4 + e / 2; sz int32 [K/G, N] = zero << 16 | scale bits."""
+    k, nc = qweight.shape
+    n = nc * 8
+    q = _awq_unpack(qweight).to(torch.int64)                                 # [K, N] natural column order
+    z = _awq_unpack(qzeros).to(torch.int64)                                  # [K/G, N]
+    qb = q.reshape(k // 128, 4, 4, 8, n // 16, 16)                           # [b, s, g, e, t, a]
+    nib = torch.tensor([(e & 1) * 4 + (e >> 1) for e in range(8)])           # element e of the lane's k-run -> nibble
+    words = (qb << (4 * nib.view(1, 1, 1, 8, 1, 1))).sum(dim=3)              # [b, s, g, t, a]
+    words = words.permute(3, 0, 2, 4, 1).reshape(n // 16, k // 128, 64, 4)   # [t, b, (g, a), s]
+    sbits = scales.contiguous().view(torch.int16).to(torch.int64) & 0xFFFF
+    sz = (z << 16) | sbits
+    to_i32 = lambda t: torch.where(t >= 2**31, t - 2**32, t).to(torch.int32)
+    return to_i32(words), to_i32(sz)
+
+
 def awq_dequantize(qweight, scales, qzeros, group_size=None):
     """qweight [K, N/8] i32, scales [K/G, N] f16/bf16, qzeros [K/G, N/8] i32 -> [K, N] in scales.dtype."""
     k = qweight.shape[0]

@@ -261,6 +261,85 @@ def test_awq_dequantize_qwen2_shapes_vs_oracle(k, nc, dtype, sk):
     assert torch.equal(o.cpu(), oq.awq_dequantize(qw, sc, qz, 128))
 
 
+def _awq_case(k, n, g, dtype, seed):
+    gen = torch.Generator().manual_seed(seed)
+    qw = torch.randint(-2**31, 2**31 - 1, (k, n // 8), generator=gen, dtype=torch.int32)
+    qz = torch.randint(-2**31, 2**31 - 1, (k // g, n // 8), generator=gen, dtype=torch.int32)
+    sc = (torch.rand(k // g, n, generator=gen) * 0.02 + 1e-3).to(dtype)
+    return qw, qz, sc
+
+
+@pytest.mark.parametrize("k,n,g,dtype", [(256, 32, 128, torch.bfloat16), (3584, 4608, 128, torch.float16), (512, 144, 64, torch.bfloat16),
+                                         (384, 48, 32, torch.float16), (1024, 64, 256, torch.bfloat16)])
+def test_awq_repack_bit_exact_vs_oracle(k, n, g, dtype, sk):
+    qw, qz, sc = _awq_case(k, n, g, dtype, seed=k + n)
+    qp, sz = sk.awq_repack(qw.to(DEV), sc.to(DEV), qz.to(DEV))
+    rp, rs = oq.awq_repack(qw, sc, qz)
+    assert torch.equal(qp.cpu(), rp) and torch.equal(sz.cpu(), rs)
+
+
+@pytest.mark.parametrize("m,k,n,g,dtype,bias", [
+    (32, 3584, 4608, 128, torch.bfloat16, True),     # Qwen2-7B qkv (bench_awq_dequant.py:59-62 shapes)
+    (32, 3584, 3584, 128, torch.float16, False),     # o_proj
+    (7, 18944, 3584, 128, torch.bfloat16, False),    # down_proj: 5 k-ranges through the slab reduce
+    (17, 4096, 1024, 128, torch.float16, True),
+    (1, 512, 144, 64, torch.bfloat16, False),        # two scale groups per 128-k block
+    (16, 384, 48, 32, torch.float16, True),          # four scale groups per block, ragged last k-range
+    (3, 1024, 64, 256, torch.bfloat16, False),       # group spanning two blocks
+])
+def test_awq_gemm_vs_oracle(m, k, n, g, dtype, bias, sk):
+    """Fused int4 dequant-GEMM == x @ awq_dequantize(...) of the oracle (float64 product of the SAME dequantised weights,
+    which the kernel reproduces bit for bit in registers); the tolerance covers f32 accumulation order + the output rounding."""
+    qw, qz, sc = _awq_case(k, n, g, dtype, seed=m + k)
+    gen = torch.Generator().manual_seed(m)
+    x = torch.randn(m, k, generator=gen).to(dtype)
+    b = torch.randn(n, generator=gen).to(dtype) if bias else None
+    qp, sz = sk.awq_repack(qw.to(DEV), sc.to(DEV), qz.to(DEV))
+    y = sk.awq_gemm(x.to(DEV), qp, sz, g, None if b is None else b.to(DEV))
+    w = oq.awq_dequantize(qw, sc, qz, g)             # [K, N] in dtype, the reference's weight values
+    ref = x.double() @ w.double()
+    if b is not None:
+        ref = ref + b.double()
+    err = (y.cpu().double() - ref).abs().max().item()
+    tol = (2e-2 if dtype == torch.bfloat16 else 3e-3) * max(1.0, ref.abs().max().item())
+    assert err <= tol, (err, tol)
+
+
+def test_awq_gemm_exact_small_integers(sk):
+    # power-of-two scales and small-integer activations: every product and partial sum is exact, so the fused kernel
+    # must equal dequantize -> matmul bit for bit (pins the nibble order, zero points and group indexing)
+    k, n, g, m = 768, 96, 128, 20
+    gen = torch.Generator().manual_seed(11)
+    qw = torch.randint(-2**31, 2**31 - 1, (k, n // 8), generator=gen, dtype=torch.int32)
+    qz = torch.randint(-2**31, 2**31 - 1, (k // g, n // 8), generator=gen, dtype=torch.int32)
+    sc = (2.0 ** torch.randint(-3, 2, (k // g, n), generator=gen).float()).to(torch.float16)
+    x = torch.randint(-2, 3, (m, k), generator=gen).to(torch.float16)
+    qp, sz = sk.awq_repack(qw.to(DEV), sc.to(DEV), qz.to(DEV))
+    y = sk.awq_gemm(x.to(DEV), qp, sz, g)
+    ref = (x.double() @ oq.awq_dequantize(qw, sc, qz, g).double()).to(torch.float16)
+    assert torch.equal(y.cpu(), ref)
+
+
+def test_awq_linear_method_fused_matches_unfused(sk, pkg):
+    from ltp_sglang_amd.srt.layers.quantization.awq import AWQConfig, AWQLinearMethod
+    k, n, g = 1024, 256, 128
+    qw, qz, sc = _awq_case(k, n, g, torch.bfloat16, seed=3)
+    layer = torch.nn.Module()
+    meth = AWQLinearMethod(AWQConfig(4, g, True))
+    meth.create_weights(layer, k, [n], k, n, torch.bfloat16)
+    layer.qweight.data, layer.qzeros.data, layer.scales.data = qw.to(DEV), qz.to(DEV), sc.to(DEV)
+    meth.process_weights_after_loading(layer)
+    assert layer._awq_packed is not None
+    x = torch.randn(24, k, generator=torch.Generator().manual_seed(1)).to(torch.bfloat16).to(DEV)
+    fused = meth.apply(layer, x)
+    packed, layer._awq_packed = layer._awq_packed, None
+    unfused = meth.apply(layer, x)
+    layer._awq_packed = packed
+    torch.testing.assert_close(fused.float(), unfused.float(), rtol=2e-2, atol=2e-2)
+    big = torch.randn(80, k, generator=torch.Generator().manual_seed(2)).to(torch.bfloat16).to(DEV)   # M > 32: unfused path
+    assert meth.apply(layer, big).shape == (80, n)
+
+
 # ---------------------------------------------------------------- tiled GEMM at prefill-sized M
 @pytest.mark.parametrize("tile_mode", [1, 2])
 @pytest.mark.parametrize("m,n,k,out", [(256, 384, 4096, "bf16"), (1000, 136, 1024, "bf16"), (129, 6144, 512, "f16"),
