@@ -66,6 +66,31 @@ def test_awq_oracle_bit_exact(case, golden):
     assert np.array_equal(_cases.bits16(o), golden("quant")[case["name"] + ".deq"])
 
 
+@pytest.mark.parametrize("case", _cases.AWQ_CASES, ids=lambda c: c["name"])
+def test_awq_repack_oracle_round_trips_to_golden_dequant(case, golden):
+    """The re-laid weight (qpacked / sz, include/sgl_mi355.h) holds exactly the reference's values: unpacking it by the
+    documented layout and applying (q - z) * s reproduces the golden awq_dequantize output bit for bit."""
+    c = _cases.build_awq_case(case)
+    k, n, g = c["qweight"].shape[0], c["scales"].shape[1], c["g"]
+    if k % 128 or n % 16 or not (g % 128 == 0 or g in (32, 64)):
+        pytest.skip("shape outside the fused kernel's rules")
+    qp, sz = oq.awq_repack(c["qweight"], c["scales"], c["qzeros"])
+    qp = qp.to(torch.int64) & 0xFFFFFFFF
+    sz = sz.to(torch.int64) & 0xFFFFFFFF
+    w = torch.empty(k, n, dtype=torch.float32)
+    for e in range(8):
+        nib = (e & 1) * 4 + (e >> 1)
+        q = ((qp >> (4 * nib)) & 0xF).reshape(n // 16, k // 128, 4, 16, 4)        # [t, b, g, a, s]
+        rows = (128 * torch.arange(k // 128).view(1, -1, 1, 1, 1) + 32 * torch.arange(4).view(1, 1, 1, 1, 4)
+                + 8 * torch.arange(4).view(1, 1, 4, 1, 1) + e).expand_as(q)
+        cols = (16 * torch.arange(n // 16).view(-1, 1, 1, 1, 1) + torch.arange(16).view(1, 1, 1, 16, 1)).expand_as(q)
+        w[rows.reshape(-1), cols.reshape(-1)] = q.reshape(-1).float()
+    z = (sz >> 16).float().repeat_interleave(g, dim=0)
+    sc = (sz & 0xFFFF).to(torch.int16).view(c["scales"].dtype).float().repeat_interleave(g, dim=0)
+    deq = ((w - z) * sc).to(c["scales"].dtype)
+    assert np.array_equal(_cases.bits16(deq), golden("quant")[case["name"] + ".deq"])
+
+
 @pytest.mark.parametrize("case", _cases.NORM_CASES, ids=lambda c: c["name"])
 def test_rmsnorm_oracle(case, golden):
     g = golden("elementwise")
