@@ -191,8 +191,11 @@ __device__ __forceinline__ void glds16(const char* g, char* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <typename OutT>
-__global__ __launch_bounds__(512, 1) void fp8_gemm256_kernel(const GemmParams p) {
+template <typename OutT, int NWV>  // NWV = 8: waves 2 (M) x 4 (N), 128 x 64 outputs each; 4: 2 x 2, 128 x 128 each (accumulators in AGPRs)
+__global__ __launch_bounds__(NWV * 64, 1) void fp8_gemm256_kernel(const GemmParams p) {
+  constexpr int WCOLS = NWV == 8 ? 4 : 2;     // waves along N
+  constexpr int JN = 256 / WCOLS / 16;        // 16-column W fragments per wave
+  constexpr int RPW = 256 / NWV;              // staging rows per wave and operand
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][W 32 KiB | X 32 KiB]
   const int nwg = p.tiles_m * p.tiles_n;
   const int bid = blockIdx.x;
@@ -203,63 +206,84 @@ __global__ __launch_bounds__(512, 1) void fp8_gemm256_kernel(const GemmParams p)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = (w >> 2) * 128, wn = (w & 3) * 64;
+  const int wm = (w / WCOLS) * 128, wn = (w % WCOLS) * (16 * JN);
   const int a = lane & 15, g = lane >> 4;
 
-  // LDS-DMA staging: wave w fills rows 32 w .. 32 w + 31 of both operands, 8 rows (1 KiB) per instruction; the lane
-  // that writes position (lane & 7) of row R loads the chunk the swizzle keeps there
-  const char* wsrc[4];
-  const char* xsrc[4];
+  // LDS-DMA staging (buffer_load ... lds): wave w fills rows RPW w .. RPW w + RPW - 1 of both operands, 8 rows (1 KiB) per
+  // instruction.  The lane that writes position (lane & 7) of row R loads the chunk the swizzle keeps there; that chunk
+  // only depends on the parity of the 8-row group, so two per-lane offsets per operand + wave-uniform scalar offsets cover
+  // every instruction.  Rows past M / N are out of the buffer's range and arrive as zeros.
+  const auto wrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (unsigned)((int64_t)p.N * p.w_stride), 0x00020000);
+  const auto xrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (unsigned)((int64_t)p.M * p.x_stride), 0x00020000);
+  unsigned wvo[2], xvo[2];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int row = 32 * w + 8 * t + (lane >> 3);
-    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-    wsrc[t] = p.w + (int64_t)min(n0 + row, p.N - 1) * p.w_stride + chunk * 16;
-    xsrc[t] = p.x + (int64_t)min(m0 + row, p.M - 1) * p.x_stride + chunk * 16;
+  for (int par = 0; par < 2; ++par) {
+    const int rl = RPW * w + (lane >> 3);                          // row of 8-row group 0 (parity `par` adds 8 par rows)
+    const int chunk = (lane & 7) ^ (((lane >> 4) + 4 * par) & 7);  // ((row >> 1) & 7) for row = rl + 8 t, t & 1 == par
+    wvo[par] = (unsigned)((int64_t)(n0 + rl) * p.w_stride) + chunk * 16;
+    xvo[par] = (unsigned)((int64_t)(m0 + rl) * p.x_stride) + chunk * 16;
   }
   const int nk = p.kbytes / BKB;
   auto stage = [&](int kt, int buf) {
-    char* wb = smem + buf * 2 * OPB + (32 * w) * BKB;
+    auto* wb = (__attribute__((address_space(3))) char*)(smem + buf * 2 * OPB + (RPW * w) * BKB);
     const int off = kt * BKB;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      glds16(wsrc[t] + off, wb + t * 8 * BKB);
-      glds16(xsrc[t] + off, wb + OPB + t * 8 * BKB);
+    for (int t = 0; t < RPW / 8; ++t) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, wb + t * 8 * BKB, 16, wvo[t & 1], (int)(t * 8 * p.w_stride) + off, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, wb + OPB + t * 8 * BKB, 16, xvo[t & 1], (int)(t * 8 * p.x_stride) + off, 0, 0);
     }
   };
 
-  f32x4_t acc[4][8];
+  f32x4_t acc[JN][8];
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < JN; ++j)
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  stage(0, 0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    stage(min(kt + 1, nk - 1), buf ^ 1);  // (the last iteration re-stages its own slice into the idle buffer: branch free)
+  // Software pipeline: every LDS read of slice kt is issued before the slice's single barrier, the fragments of the next
+  // MFMA group are fetched while the current group runs, and the barrier sits before the LAST group, so that its wait,
+  // the re-staging of the buffer just drained and the first fragment reads of slice kt + 1 all hide behind 8-16 MFMAs.
+  constexpr int NG = 4;                 // MFMA groups per slice: 2 X row-tiles (32 rows) x JN column tiles each
+  u32x4_t wf[JN][2], xf[2][2][2];
+  auto load_w = [&](int buf) {
     const char* wa = smem + buf * 2 * OPB;
-    const char* xa = wa + OPB;
-    u32x4_t wf[4][2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < JN; ++j)
 #pragma unroll
       for (int h = 0; h < 2; ++h) wf[j][h] = *(const u32x4_t*)(wa + lds_off(wn + 16 * j + a, 4 * h + g));
+  };
+  auto load_x = [&](int buf, int grp, int slot) {
+    const char* xa = smem + buf * 2 * OPB + OPB;
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      u32x4_t xf[4][2];
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int h = 0; h < 2; ++h) xf[slot][i][h] = *(const u32x4_t*)(xa + lds_off(wm + 32 * grp + 16 * i + a, 4 * h + g));
+  };
+  auto mma = [&](int grp, int slot) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) xf[i][h] = *(const u32x4_t*)(xa + lds_off(wm + 64 * half + 16 * i + a, 4 * h + g));
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < JN; ++j) mfma_mx(wf[j][0], wf[j][1], xf[slot][i][0], xf[slot][i][1], acc[j][2 * grp + i]);
+  };
+  stage(0, 0);
+  __syncthreads();
+  stage(min(1, nk - 1), 1);
+  load_w(0);
+  load_x(0, 0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) mfma_mx(wf[j][0], wf[j][1], xf[i][0], xf[i][1], acc[j][4 * half + i]);
+    for (int grp = 0; grp < NG - 1; ++grp) {
+      load_x(buf, grp + 1, (grp + 1) & 1);
+      mma(grp, grp & 1);
     }
-    __syncthreads();  // drains this wave's LDS-DMA (vmcnt) and everybody's reads of buf before it is re-staged
+    __syncthreads();  // slice kt + 1 has landed for every wave (vmcnt) and nobody reads buf any more (lgkmcnt)
+    stage(min(kt + 2, nk - 1), buf);  // branch free: the last two iterations re-stage the final slice into drained buffers
+    mma(NG - 1, (NG - 1) & 1);
+    load_w(buf ^ 1);                  // (after the last slice these read the re-staged copy and are never used)
+    load_x(buf ^ 1, 0, 0);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may be in flight when the workgroup ends
 
   // ---- epilogue: acc[j][i][r] -> row m0+wm+16i+a, col n0+wn+16j+4g+r ----
   const bool vec_ok = (p.y_stride % 4 == 0) && (((uintptr_t)p.y & 7) == 0);
@@ -270,7 +294,7 @@ __global__ __launch_bounds__(512, 1) void fp8_gemm256_kernel(const GemmParams p)
     const float sxv = p.sx ? p.sx[m] : 1.0f;
     OutT* yrow = (OutT*)p.y + (int64_t)m * p.y_stride;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < JN; ++j) {
       const int n = n0 + wn + 16 * j + 4 * g;
       if (n >= p.N) continue;
       float v[4];
@@ -307,17 +331,17 @@ int tg_cus() {
 }
 int g_tiled_force = 0;  // test hook: 1 = always the 128x128 kernel, 2 = the 256x256 kernel whenever its shape rules allow
 
-template <typename OutT>
+template <typename OutT, int NWV>
 int launch256(GemmParams& p, hipStream_t st) {
   constexpr int smem = 2 * 2 * OPB;  // 128 KiB
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)fp8_gemm256_kernel<OutT>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)fp8_gemm256_kernel<OutT, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
   p.tiles_m = (p.M + T2 - 1) / T2;
   p.tiles_n = (p.N + T2 - 1) / T2;
-  hipLaunchKernelGGL((fp8_gemm256_kernel<OutT>), dim3(p.tiles_m * p.tiles_n), dim3(512), smem, st, p);
+  hipLaunchKernelGGL((fp8_gemm256_kernel<OutT, NWV>), dim3(p.tiles_m * p.tiles_n), dim3(NWV * 64), smem, st, p);
   SGL_HIP_LAUNCH_CHECK();
   return SGL_MI355_OK;
 }
@@ -358,9 +382,11 @@ int run(const void* x, int64_t xs, const void* w, int64_t ws, void* y, int64_t y
   if (in_dtype == SGL_FP8_E4M3) {
     // the 256x256 kernel wants whole 128-byte K slices and enough tiles to fill every CU at least once
     const int64_t tiles256 = (int64_t)((M + T2 - 1) / T2) * ((N + T2 - 1) / T2);
-    const bool can256 = p.kbytes % BKB == 0 && p.kbytes >= BKB;
+    const bool can256 = p.kbytes % BKB == 0 && p.kbytes >= BKB && (int64_t)N * p.w_stride < 0xFFFFFFF0ll &&
+                        (int64_t)M * p.x_stride < 0xFFFFFFF0ll;  // 32-bit buffer offsets
+    if (can256 && g_tiled_force == 3) return out_dtype == SGL_BF16 ? launch256<__bf16, 4>(p, st) : launch256<_Float16, 4>(p, st);
     if (can256 && g_tiled_force != 1 && (g_tiled_force == 2 || tiles256 >= tg_cus()))
-      return out_dtype == SGL_BF16 ? launch256<__bf16>(p, st) : launch256<_Float16>(p, st);
+      return out_dtype == SGL_BF16 ? launch256<__bf16, 8>(p, st) : launch256<_Float16, 8>(p, st);
     return out_dtype == SGL_BF16 ? launch<TG_FP8, __bf16>(p, st) : launch<TG_FP8, _Float16>(p, st);
   }
   if (in_dtype == SGL_BF16) return out_dtype == SGL_BF16 ? launch<TG_BF16, __bf16>(p, st) : launch<TG_BF16, _Float16>(p, st);
