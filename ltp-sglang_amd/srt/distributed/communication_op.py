@@ -14,15 +14,17 @@ import torch.distributed as dist
 _TP_GROUP: Optional[dist.ProcessGroup] = None
 _TP_SIZE = 1
 _TP_RANK = 0
+_HOST_STAGED = False  # gloo group + device tensors (single-GPU rehearsal of the TP path): collectives go through host copies
 
 
 def init_tensor_parallel(group: Optional[dist.ProcessGroup] = None) -> None:
     """Adopts an initialised torch.distributed group (default: WORLD) as the tensor-parallel group."""
-    global _TP_GROUP, _TP_SIZE, _TP_RANK
+    global _TP_GROUP, _TP_SIZE, _TP_RANK, _HOST_STAGED
     if not dist.is_initialized():
-        _TP_GROUP, _TP_SIZE, _TP_RANK = None, 1, 0
+        _TP_GROUP, _TP_SIZE, _TP_RANK, _HOST_STAGED = None, 1, 0, False
         return
     _TP_GROUP = group if group is not None else dist.group.WORLD
+    _HOST_STAGED = dist.get_backend(_TP_GROUP) == "gloo"
     _TP_SIZE = dist.get_world_size(_TP_GROUP)
     _TP_RANK = dist.get_rank(_TP_GROUP)
 
@@ -39,6 +41,11 @@ def tensor_model_parallel_all_reduce(input_: torch.Tensor) -> torch.Tensor:
     """In-place sum over the TP group (bypassed when tp == 1, parallel_state.py:466-468)."""
     if _TP_SIZE == 1:
         return input_
+    if _HOST_STAGED and input_.is_cuda:
+        host = input_.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=_TP_GROUP)
+        input_.copy_(host)
+        return input_
     dist.all_reduce(input_, op=dist.ReduceOp.SUM, group=_TP_GROUP)
     return input_
 
@@ -49,6 +56,11 @@ def tensor_model_parallel_all_gather(input_: torch.Tensor, dim: int = -1) -> tor
         return input_
     if dim < 0:
         dim += input_.dim()
+    if _HOST_STAGED and input_.is_cuda:
+        host = input_.contiguous().cpu()
+        parts = [torch.empty_like(host) for _ in range(_TP_SIZE)]
+        dist.all_gather(parts, host, group=_TP_GROUP)
+        return torch.cat(parts, dim=dim).to(input_.device)
     parts = [torch.empty_like(input_) for _ in range(_TP_SIZE)]
     dist.all_gather(parts, input_.contiguous(), group=_TP_GROUP)
     return torch.cat(parts, dim=dim)

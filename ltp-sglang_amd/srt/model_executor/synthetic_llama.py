@@ -185,7 +185,7 @@ class LlamaForCausalLM(nn.Module):
             qm.process_weights_after_loading(mod)
 
     def _fused_decode_ok(self, forward_batch) -> bool:
-        return (self.fused_decode and forward_batch.forward_mode.is_decode() and self.tp_size == 1
+        return (self.fused_decode and forward_batch.forward_mode.is_decode()
                 and self.quant_config is not None and self.quant_config.get_name() == "w8a8_fp8"
                 and forward_batch.batch_size <= 32 and self.cfg.hidden_size <= 8192)
 
@@ -218,7 +218,12 @@ class LlamaForCausalLM(nn.Module):
     def forward_decode_fused(self, input_ids, positions, forward_batch: ForwardBatch):
         """The same decode step with the elementwise work fused into 4 kernels per layer (sgl_kernel/fused.py) and the
         down_proj split-K combine folded into the next layer's RMSNorm.  Every fused kernel is bit-identical to the op
-        sequence it replaces, so this path and forward() give the same logits."""
+        sequence it replaces, so this path and forward() give the same logits.  Under tensor parallelism the two
+        row-parallel outputs are materialised and all-reduced at the reference's call sites (linear.py:1302-1303); the
+        split-K slab hand-off is a single-rank shortcut."""
+        from ..distributed.communication_op import tensor_model_parallel_all_gather, tensor_model_parallel_all_reduce
+
+        tp = self.tp_size
         pool = forward_batch.token_to_kv_pool
         backend = forward_batch.attn_backend
         m = input_ids.numel()
@@ -227,9 +232,11 @@ class LlamaForCausalLM(nn.Module):
         for layer in self.layers:
             attn, mlp = layer.self_attn, layer.mlp
             ln1 = layer.input_layernorm
-            if slabs is None:
+            if residual is None:
                 _, xq, xs = K.fused_add_rmsnorm_quant_fp8(hidden, None, ln1.weight.data, ln1.variance_epsilon)
                 residual = hidden
+            elif slabs is None:
+                _, xq, xs = K.fused_add_rmsnorm_quant_fp8(hidden, residual, ln1.weight.data, ln1.variance_epsilon)
             else:
                 _, xq, xs = K.fused_add_rmsnorm_quant_fp8(None, residual, ln1.weight.data, ln1.variance_epsilon, slabs=slabs,
                                                           slab_sx=slab_sx, slab_sw=slab_sw, dtype=self.dtype)
@@ -249,6 +256,8 @@ class LlamaForCausalLM(nn.Module):
             _, oq, osc = K.decode_merge_quant_fp8(md.attn_logits, md.attn_lse, md.kv_indptr, md.num_kv_splits,
                                                   backend.max_kv_splits, self.dtype)
             attn_out = K.fp8_scaled_mm(oq, attn.o_proj.weight, osc.view(-1), attn.o_proj.weight_scale.view(-1), self.dtype)
+            if tp > 1:
+                attn_out = tensor_model_parallel_all_reduce(attn_out)
             ln2 = layer.post_attention_layernorm
             _, hq2, hs2 = K.fused_add_rmsnorm_quant_fp8(attn_out, residual, ln2.weight.data, ln2.variance_epsilon)
             if fw is not None:   # gate_up GEMM with the SiluAndMul epilogue, then the per-token quantisation
@@ -258,21 +267,33 @@ class LlamaForCausalLM(nn.Module):
                 gate_up = K.fp8_scaled_mm(hq2, mlp.gate_up_proj.weight, hs2.view(-1), mlp.gate_up_proj.weight_scale.view(-1), self.dtype)
                 aq, asc = K.silu_and_mul_quant_fp8(gate_up)
             wd = mlp.down_proj.weight  # [K, N] column-major view of the [N, K] parameter
-            slabs = K.fp8_linear_slabs(aq, wd.t(), m, wd.shape[1], wd.shape[0])
-            slab_sx, slab_sw = asc.view(-1), mlp.down_proj.weight_scale.view(-1)
-        hidden, _, _ = K.fused_add_rmsnorm_quant_fp8(None, residual, self.norm.weight.data, self.norm.variance_epsilon, slabs=slabs,
-                                                     slab_sx=slab_sx, slab_sw=slab_sw, want_norm=True, want_quant=False,
-                                                     dtype=self.dtype)
-        return K.dense_linear(hidden, self.lm_head, None, out_dtype=self.dtype)
+            if tp == 1:
+                slabs = K.fp8_linear_slabs(aq, wd.t(), m, wd.shape[1], wd.shape[0])
+                slab_sx, slab_sw = asc.view(-1), mlp.down_proj.weight_scale.view(-1)
+            else:
+                hidden = K.fp8_scaled_mm(aq, wd, asc.view(-1), mlp.down_proj.weight_scale.view(-1), self.dtype)
+                hidden = tensor_model_parallel_all_reduce(hidden)
+        if slabs is not None:
+            hidden, _, _ = K.fused_add_rmsnorm_quant_fp8(None, residual, self.norm.weight.data, self.norm.variance_epsilon,
+                                                         slabs=slabs, slab_sx=slab_sx, slab_sw=slab_sw, want_norm=True,
+                                                         want_quant=False, dtype=self.dtype)
+        else:
+            hidden, _, _ = K.fused_add_rmsnorm_quant_fp8(hidden, residual, self.norm.weight.data, self.norm.variance_epsilon,
+                                                         want_norm=True, want_quant=False)
+        logits = K.dense_linear(hidden, self.lm_head, None, out_dtype=self.dtype)
+        return tensor_model_parallel_all_gather(logits) if tp > 1 else logits
 
     def _fused_extend_ok(self, forward_batch) -> bool:
-        return (self.fused_extend and forward_batch.forward_mode.is_extend() and self.tp_size == 1
+        return (self.fused_extend and forward_batch.forward_mode.is_extend()
                 and self.quant_config is not None and self.quant_config.get_name() == "w8a8_fp8"
                 and self.cfg.hidden_size <= 8192 and 2 * self.cfg.intermediate_size <= 65536)
 
     def forward_extend_fused(self, input_ids, positions, forward_batch: ForwardBatch, last_index):
         """Prefill with the same fused elementwise kernels as the decode step (add+RMSNorm+quant, RoPE+KV write,
         SiluAndMul+quant); the linears are the tiled fp8 GEMM.  Bit-identical to the unfused op sequence of forward()."""
+        from ..distributed.communication_op import tensor_model_parallel_all_gather, tensor_model_parallel_all_reduce
+
+        tp = self.tp_size
         pool = forward_batch.token_to_kv_pool
         backend = forward_batch.attn_backend
         hidden = K.embedding(input_ids, self.embed_tokens)
@@ -295,16 +316,21 @@ class LlamaForCausalLM(nn.Module):
                                        attn.attn, forward_batch, save_kv_cache=False)
             oq, osc = K.sglang_per_token_quant_fp8(o)
             hidden = K.fp8_scaled_mm(oq, attn.o_proj.weight, osc.view(-1), attn.o_proj.weight_scale.view(-1), self.dtype)
+            if tp > 1:
+                hidden = tensor_model_parallel_all_reduce(hidden)
             _, hq2, hs2 = K.fused_add_rmsnorm_quant_fp8(hidden, residual, ln2.weight.data, ln2.variance_epsilon)
             gate_up = K.fp8_scaled_mm(hq2, mlp.gate_up_proj.weight, hs2.view(-1), mlp.gate_up_proj.weight_scale.view(-1), self.dtype)
             aq, asc = K.silu_and_mul_quant_fp8(gate_up)
             hidden = K.fp8_scaled_mm(aq, mlp.down_proj.weight, asc.view(-1), mlp.down_proj.weight_scale.view(-1), self.dtype)
+            if tp > 1:
+                hidden = tensor_model_parallel_all_reduce(hidden)
         if last_index is not None:  # only the last token of each request reaches the final norm and lm_head
             hidden = hidden.index_select(0, last_index)
             residual = residual.index_select(0, last_index)
         hidden, _, _ = K.fused_add_rmsnorm_quant_fp8(hidden, residual, self.norm.weight.data, self.norm.variance_epsilon,
                                                      want_norm=True, want_quant=False)
-        return K.dense_linear(hidden, self.lm_head, None, out_dtype=self.dtype)
+        logits = K.dense_linear(hidden, self.lm_head, None, out_dtype=self.dtype)
+        return tensor_model_parallel_all_gather(logits) if tp > 1 else logits
 
     def forward(self, input_ids, positions, forward_batch: ForwardBatch, last_index: Optional[torch.Tensor] = None):
         if self._fused_decode_ok(forward_batch):
