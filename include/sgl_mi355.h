@@ -52,7 +52,11 @@ int sgl_mi355_decode_attention(const void* q, int64_t q_stride_t, const void* k_
                                const int32_t* req_to_token, int64_t req_to_token_stride, const int64_t* req_pool_indices,
                                const int64_t* seq_lens, float* attn_logits, float* attn_lse, const int32_t* num_kv_splits,
                                int max_kv_splits, int batch, int num_q_heads, int num_kv_heads, int head_dim,
-                               int v_head_dim, float sm_scale, float logit_cap, int dtype, void* stream);
+                               int v_head_dim, float sm_scale, float logit_cap, int dtype, int kv_dtype, float k_scale,
+                               float v_scale, void* stream);
+/* kv_dtype: the q dtype, or SGL_FP8_E4M3 (3) for kv_cache_dtype = fp8_e4m3 pools (memory_pool.py:385-395; head_dim 64 / 128):
+ * rows are converted exactly to the q dtype on the way into LDS, K_true = K_fp8 * k_scale, V_true = V_fp8 * v_scale
+ * (RadixAttention.k_scale / v_scale, radix_attention.py:73-76; the Triton backend leaves both at 1). */
 
 /* Measurement hook: 1 (default) = every wave owns one (request, kv head, split) unit; 0 = the first design, a
  * 4-wave workgroup sharing one split with an LDS merge. */
@@ -73,7 +77,8 @@ int sgl_mi355_extend_attention(const void* q_extend, const void* k_extend, const
                                int64_t req_to_token_stride, const int64_t* req_pool_indices, const int64_t* seq_lens,
                                const int32_t* extend_seq_lens, const int32_t* extend_start_loc, int batch,
                                int total_q_tokens, int max_len_extend, int num_q_heads, int num_kv_heads, int head_dim,
-                               int v_head_dim, float sm_scale, float logit_cap, int is_causal, int dtype, void* stream);
+                               int v_head_dim, float sm_scale, float logit_cap, int is_causal, int dtype, int kv_dtype,
+                               float k_scale, float v_scale, void* stream);
 
 /* ---- KV pool / index kernels (bit-exact) -------------------------------------------------- */
 /* create_flashinfer_kv_indices_triton, python/sglang/srt/layers/attention/utils.py:10-45 */
@@ -97,6 +102,13 @@ int sgl_mi355_get_last_loc(const int32_t* req_to_token, int64_t req_to_token_str
 int sgl_mi355_set_kv_buffer(void* k_buffer, void* v_buffer, int64_t k_slot_bytes, int64_t v_slot_bytes,
                             const int64_t* loc, const void* cache_k, const void* cache_v, int64_t cache_k_stride_bytes,
                             int64_t cache_v_stride_bytes, int k_row_bytes, int v_row_bytes, int64_t tokens, void* stream);
+/* The same scatter for kv_cache_dtype = fp8_e4m3 (memory_pool.py:385-395): cache_k.div_(k_scale) in the source dtype when a
+ * scale is given (k_scale / v_scale <= 0: none), then .to(float8_e4m3fn) with torch's rounding and NaN rule.  Strides and
+ * row sizes in elements of the bf16 / f16 source; pool slot strides in bytes. */
+int sgl_mi355_set_kv_buffer_fp8(void* k_buffer, void* v_buffer, int64_t k_slot_bytes, int64_t v_slot_bytes, const int64_t* loc,
+                                const void* cache_k, const void* cache_v, int64_t cache_k_stride, int64_t cache_v_stride,
+                                int k_row, int v_row, int64_t tokens, int src_dtype, float k_scale, float v_scale,
+                                void* stream);
 /* kv_indptr[1:bs+1] = cumsum(seq_lens) (triton_backend.py:172) and get_num_kv_splits_triton
  * (triton_backend.py:876-924); either output may be NULL.  static_splits: 0 = reference heuristic, 1 = max everywhere,
  * 2 = MI355X balance rule (about two rounds of resident workgroups). */

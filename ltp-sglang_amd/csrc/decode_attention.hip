@@ -50,6 +50,8 @@ struct DecodeParams {
   int max_kv_splits;
   int bs, hq, hkv, group, dv;
   float sm_scale, logit_cap;
+  int kv_fp8;             // K/V pool rows are e4m3fn bytes (kv_cache_dtype fp8_e4m3, memory_pool.py:385-395), else the q dtype
+  float k_scale, v_scale;  // K_true = K_fp8 * k_scale, V_true = V_fp8 * v_scale (radix_attention.py:73-76); 1 for 16-bit pools
 };
 
 constexpr int kTile = 32;  // tokens per wave tile == reference _MIN_BLOCK_KV (decode_attention.py:35)
@@ -80,12 +82,29 @@ __device__ __forceinline__ float softcap_log2(float s_scaled, float cap) {
   return cap * t * kLog2e;
 }
 
+// 16 e4m3 bytes -> 16 T (exact: every e4m3 value is representable in bf16 and f16)
+template <typename T>
+__device__ __forceinline__ void cvt16_fp8(const u32x4_t& in, u32x4_t& lo, u32x4_t& hi) {
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  struct P2 { T a, b; };
+  uint32_t out[8];
+#pragma unroll
+  for (int w4 = 0; w4 < 4; ++w4) {
+    const f32x2 f01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)in[w4], false);
+    const f32x2 f23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)in[w4], true);
+    out[2 * w4] = __builtin_bit_cast(uint32_t, P2{(T)f01[0], (T)f01[1]});
+    out[2 * w4 + 1] = __builtin_bit_cast(uint32_t, P2{(T)f23[0], (T)f23[1]});
+  }
+  lo = u32x4_t{out[0], out[1], out[2], out[3]};
+  hi = u32x4_t{out[4], out[5], out[6], out[7]};
+}
+
 // MODE 0: the NW waves of a workgroup share one (request, kv head, split) and interleave its tiles; LDS merge.
 // MODE 1: every wave is its own (request, kv head, split) unit; the NW waves of a workgroup are NW consecutive
 //         units of one request with the kv head fastest, so they read ADJACENT 256-byte pieces of the same token rows
 //         at about the same time (whole 2-KiB token rows per workgroup instead of scattered 256-byte pieces) and no
 //         barrier or cross-wave merge exists at all.
-template <typename T, int D, int NW, int MODE>
+template <typename T, int D, int NW, int MODE, int KVB = 2>  // KVB: bytes per pool element (1 = e4m3 KV cache, converted on the way into LDS)
 __global__ __launch_bounds__(NW * 64, 2) void decode_attn_stage1(const DecodeParams p) {
   using Tr = ElemTraits<T>;
   using vec8 = typename Tr::vec8;
@@ -93,6 +112,9 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attn_stage1(const DecodePar
   constexpr int LPR = ROWB / 16;   // lanes covering one K/V row with 16-byte loads
   constexpr int RPI = 64 / LPR;    // rows per wave-wide load instruction
   constexpr int NI = kTile / RPI;  // load instructions per tile
+  constexpr int GLPR = D * KVB / 16;  // the same three for the rows as they lie in the pool
+  constexpr int GRPI = 64 / GLPR;
+  constexpr int GNI = kTile / GRPI;
   constexpr int KS = D / 32;       // QK^T k-steps
   constexpr int NT = D / 16;       // PV output column tiles
   constexpr int TILE_B = kTile * ROWB;
@@ -135,8 +157,8 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attn_stage1(const DecodePar
 
   const int a = lane & 15;  // MFMA n index: q head within the chunk
   const int g = lane >> 4;  // MFMA k/m group
-  const int c16 = lane % LPR;
-  const int rsub = lane / LPR;
+  const int c16 = lane % GLPR;  // 16-byte chunk of the pool row / row within a load instruction, of this lane
+  const int rsub = lane / GLPR;
 
   char* kl = smem + w * (2 * TILE_B);
   char* vl = kl + TILE_B;
@@ -156,12 +178,13 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attn_stage1(const DecodePar
     }
   }
 
-  const char* kbase = (const char*)p.k_buf + ((int64_t)kh * p.k_stride_h) * 2 + c16 * 16;
-  const char* vbase = (const char*)p.v_buf + ((int64_t)kh * p.v_stride_h) * 2 + c16 * 16;
-  const int64_t kst = p.k_stride_t * 2, vst = p.v_stride_t * 2;
+  const char* kbase = (const char*)p.k_buf + ((int64_t)kh * p.k_stride_h) * KVB + c16 * 16;
+  const char* vbase = (const char*)p.v_buf + ((int64_t)kh * p.v_stride_h) * KVB + c16 * 16;
+  const int64_t kst = p.k_stride_t * KVB, vst = p.v_stride_t * KVB;
 
   const int ntiles = (end - start + kTile - 1) / kTile;
-  const float scale_log2 = p.sm_scale * kLog2e;
+  const float sm_scale = p.sm_scale * p.k_scale;
+  const float scale_log2 = sm_scale * kLog2e;
   const bool use_cap = p.logit_cap > 0.0f;
 
   float m_i = -INFINITY, l_i = 0.0f;
@@ -169,7 +192,7 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attn_stage1(const DecodePar
 #pragma unroll
   for (int n = 0; n < NT; ++n) acc[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  u32x4_t kreg[NI], vreg[NI];
+  u32x4_t kreg[GNI], vreg[GNI];
 
   auto load_idx = [&](int t) -> int {
     const int tok = start + t * kTile + (lane & 31);
@@ -177,8 +200,8 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attn_stage1(const DecodePar
   };
   auto issue = [&](int idxreg) {
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int id = __shfl(idxreg, i * RPI + rsub, WAVE);
+    for (int i = 0; i < GNI; ++i) {
+      const int id = __shfl(idxreg, i * GRPI + rsub, WAVE);
       kreg[i] = *(const u32x4_t*)(kbase + (int64_t)id * kst);
       vreg[i] = *(const u32x4_t*)(vbase + (int64_t)id * vst);
     }
@@ -196,14 +219,26 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attn_stage1(const DecodePar
     const int tok0 = start + tile * kTile;
     // ---- staged registers -> swizzled LDS images (wave private, no barrier) ----
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int row = i * RPI + rsub;
+    for (int i = 0; i < GNI; ++i) {
+      const int row = i * GRPI + rsub;
       const int fk = (row / RPB) & KMASK;
       const int fv = (row / RPB) & VMASK;
-      *(u32x4_t*)(kl + row * ROWB + ((c16 ^ fk) << 4)) = kreg[i];
-      u32x4_t vv = vreg[i];
-      if (tok0 + row >= end) vv = u32x4_t{0u, 0u, 0u, 0u};  // 0 * garbage must stay 0
-      *(u32x4_t*)(vl + row * ROWB + ((((c16 >> 1) ^ fv) << 5) | ((c16 & 1) << 4))) = vv;
+      const bool dead = tok0 + row >= end;  // 0 * garbage must stay 0
+      if constexpr (KVB == 2) {
+        *(u32x4_t*)(kl + row * ROWB + ((c16 ^ fk) << 4)) = kreg[i];
+        u32x4_t vv = vreg[i];
+        if (dead) vv = u32x4_t{0u, 0u, 0u, 0u};
+        *(u32x4_t*)(vl + row * ROWB + ((((c16 >> 1) ^ fv) << 5) | ((c16 & 1) << 4))) = vv;
+      } else {  // 16 e4m3 bytes = the 16-bit chunks 2 c16 and 2 c16 + 1 of the row
+        u32x4_t k0, k1, v0, v1;
+        cvt16_fp8<T>(kreg[i], k0, k1);
+        cvt16_fp8<T>(vreg[i], v0, v1);
+        if (dead) v0 = v1 = u32x4_t{0u, 0u, 0u, 0u};
+        *(u32x4_t*)(kl + row * ROWB + (((2 * c16) ^ fk) << 4)) = k0;
+        *(u32x4_t*)(kl + row * ROWB + (((2 * c16 + 1) ^ fk) << 4)) = k1;
+        *(u32x4_t*)(vl + row * ROWB + ((c16 ^ fv) << 5)) = v0;
+        *(u32x4_t*)(vl + row * ROWB + (((c16 ^ fv) << 5) | 16)) = v1;
+      }
     }
     // ---- issue the gather of this wave's next tile, prefetch indices two tiles ahead ----
     if (tile + TS < ntiles) issue(idx_next);
@@ -231,7 +266,7 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attn_stage1(const DecodePar
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int tok = tok0 + 16 * tt + 4 * g + r;
-        float v = use_cap ? softcap_log2(s[tt][r] * p.sm_scale, p.logit_cap) : s[tt][r] * scale_log2;
+        float v = use_cap ? softcap_log2(s[tt][r] * sm_scale, p.logit_cap) : s[tt][r] * scale_log2;
         v = (tok < end) ? v : -INFINITY;
         x[tt][r] = v;
         mt = fmaxf(mt, v);
@@ -283,7 +318,7 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attn_stage1(const DecodePar
     // the wave IS the split: write acc / l and m + log(l) straight from the accumulator layout
     if (a < nh) {
       const int64_t slot = ((int64_t)b * p.hq + (h0 + a)) * p.max_kv_splits + split;
-      const float inv = 1.0f / l_i;
+      const float inv = p.v_scale / l_i;
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         f32x4_t o = acc[n];
@@ -321,7 +356,7 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attn_stage1(const DecodePar
       val += red_acc[(ww * 16 + h) * D + d] * sc;
     }
     const int64_t slot = ((int64_t)b * p.hq + (h0 + h)) * p.max_kv_splits + split;
-    p.attn_logits[slot * D + d] = val / L;
+    p.attn_logits[slot * D + d] = val / L * p.v_scale;
     if (d == 0) p.attn_lse[slot] = M * kLn2 + __logf(L);
   }
 }
@@ -419,7 +454,7 @@ __global__ __launch_bounds__(128) void decode_attn_stage2(const DecodeParams p) 
 
 int g_decode_mode = 0;  // 0 = workgroup-shared split (default: faster at batch 32), 1 = wave-per-unit (faster for 1 kv head per rank)
 
-template <typename T, int D>
+template <typename T, int D, int KVB>
 int launch_mfma(const DecodeParams& p, hipStream_t st) {
   const int hchunks = (p.group + 15) / 16;
   if (g_decode_mode == 0) {
@@ -427,24 +462,24 @@ int launch_mfma(const DecodeParams& p, hipStream_t st) {
     constexpr int smem = NW * 2 * kTile * D * 2;
     static bool attr_set = false;
     if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)decode_attn_stage1<T, D, NW, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+      (void)hipFuncSetAttribute((const void*)decode_attn_stage1<T, D, NW, 0, KVB>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
       attr_set = true;
     }
     // (kv head, request, split): with the split index slowest, the empty workgroups of unused splits sit at the end of
     // the dispatch order instead of being interleaved with the real ones (bs 128 x 1 split: 417 us -> 201 us)
     dim3 grid(p.hkv * hchunks, p.bs, p.max_kv_splits);
-    hipLaunchKernelGGL((decode_attn_stage1<T, D, NW, 0>), grid, dim3(NW * 64), smem, st, p);
+    hipLaunchKernelGGL((decode_attn_stage1<T, D, NW, 0, KVB>), grid, dim3(NW * 64), smem, st, p);
   } else {
     constexpr int NW = 8;
     constexpr int smem = NW * 2 * kTile * D * 2;
     static bool attr_set = false;
     if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)decode_attn_stage1<T, D, NW, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+      (void)hipFuncSetAttribute((const void*)decode_attn_stage1<T, D, NW, 1, KVB>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
       attr_set = true;
     }
     const int units = p.hkv * hchunks * p.max_kv_splits;
     dim3 grid((units + NW - 1) / NW, p.bs, 1);
-    hipLaunchKernelGGL((decode_attn_stage1<T, D, NW, 1>), grid, dim3(NW * 64), smem, st, p);
+    hipLaunchKernelGGL((decode_attn_stage1<T, D, NW, 1, KVB>), grid, dim3(NW * 64), smem, st, p);
   }
   SGL_HIP_LAUNCH_CHECK();
   return SGL_MI355_OK;
@@ -454,9 +489,9 @@ template <typename T>
 int launch_all(const DecodeParams& p, int d_qk, hipStream_t st) {
   int rc;
   if (d_qk == p.dv && d_qk == 128) {
-    rc = launch_mfma<T, 128>(p, st);
+    rc = p.kv_fp8 ? launch_mfma<T, 128, 1>(p, st) : launch_mfma<T, 128, 2>(p, st);
   } else if (d_qk == p.dv && d_qk == 64) {
-    rc = launch_mfma<T, 64>(p, st);
+    rc = p.kv_fp8 ? launch_mfma<T, 64, 1>(p, st) : launch_mfma<T, 64, 2>(p, st);
   } else {
     dim3 grid(p.hq, p.max_kv_splits, p.bs);
     hipLaunchKernelGGL((decode_attn_stage1_generic<T>), grid, dim3(64), 0, st, p, d_qk);
@@ -483,7 +518,7 @@ extern "C" int sgl_mi355_decode_attention(
     const int32_t* kv_indices, const int32_t* req_to_token, int64_t req_to_token_stride, const int64_t* req_pool_indices,
     const int64_t* seq_lens, float* attn_logits, float* attn_lse, const int32_t* num_kv_splits, int max_kv_splits,
     int batch, int num_q_heads, int num_kv_heads, int head_dim, int v_head_dim, float sm_scale, float logit_cap,
-    int dtype, void* stream) {
+    int dtype, int kv_dtype, float k_scale, float v_scale, void* stream) {
   SGL_CHECK(batch >= 0, "decode_attention: negative batch %d", batch);
   if (batch == 0) return SGL_MI355_OK;
   SGL_CHECK(q && k_buffer && v_buffer, "decode_attention: null tensor pointer");  // o == NULL: split partials only
@@ -498,6 +533,12 @@ extern "C" int sgl_mi355_decode_attention(
             max_kv_splits);
   SGL_CHECK(batch <= 65535, "decode_attention: batch %d exceeds grid.z limit", batch);
   SGL_CHECK(dtype == SGL_BF16 || dtype == SGL_F16, "decode_attention: dtype code %d unsupported (bf16=0, f16=1)", dtype);
+  SGL_CHECK(kv_dtype == dtype || kv_dtype == SGL_FP8_E4M3, "decode_attention: kv_dtype %d must be the q dtype or fp8_e4m3", kv_dtype);
+  const bool kv8 = kv_dtype == SGL_FP8_E4M3;
+  SGL_CHECK(!kv8 || (head_dim == v_head_dim && (head_dim == 128 || head_dim == 64)),
+            "decode_attention: the fp8 KV cache needs head_dim == v_head_dim in {64, 128} (got %d, %d)", head_dim, v_head_dim);
+  SGL_CHECK(!kv8 || (k_stride_t % 16 == 0 && v_stride_t % 16 == 0 && k_stride_h % 16 == 0 && v_stride_h % 16 == 0),
+            "decode_attention: fp8 K/V rows must be 16-byte aligned");
   if (head_dim == v_head_dim && (head_dim == 128 || head_dim == 64)) {
     SGL_CHECK(k_stride_t % 8 == 0 && v_stride_t % 8 == 0 && k_stride_h % 8 == 0 && v_stride_h % 8 == 0 &&
                   q_stride_t % 8 == 0 && ((uintptr_t)k_buffer % 16) == 0 && ((uintptr_t)v_buffer % 16) == 0 &&
@@ -515,6 +556,8 @@ extern "C" int sgl_mi355_decode_attention(
   p.attn_logits = attn_logits; p.attn_lse = attn_lse; p.num_kv_splits = num_kv_splits; p.max_kv_splits = max_kv_splits;
   p.bs = batch; p.hq = num_q_heads; p.hkv = num_kv_heads; p.group = num_q_heads / num_kv_heads; p.dv = v_head_dim;
   p.sm_scale = sm_scale; p.logit_cap = logit_cap;
+  p.kv_fp8 = kv8 ? 1 : 0;
+  p.k_scale = kv8 ? k_scale : 1.0f; p.v_scale = kv8 ? v_scale : 1.0f;
   hipStream_t st = (hipStream_t)stream;
   return dtype == SGL_BF16 ? launch_all<__bf16>(p, head_dim, st) : launch_all<_Float16>(p, head_dim, st);
 }

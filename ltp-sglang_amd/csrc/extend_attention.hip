@@ -42,6 +42,8 @@ struct ExtendParams {
   int bs, hq, hkv, group, nqb, bq_log2, hchunks;
   float sm_scale, logit_cap;
   int is_causal;
+  int kv_fp8;              // the pool (prefix) rows are e4m3fn bytes; k_extend / v_extend stay in the q dtype
+  float k_scale, v_scale;  // K_true = K_fp8 * k_scale, V_true = V_fp8 * v_scale for the prefix part
 };
 
 constexpr int kKT = 64;  // kv tokens per tile
@@ -53,7 +55,23 @@ __device__ __forceinline__ float softcap2(float s_scaled, float cap) {
   return cap * t * kLog2e;
 }
 
-template <typename T, int D>
+// 8 e4m3 bytes -> 8 T (exact)
+template <typename T>
+__device__ __forceinline__ u32x4_t cvt8_fp8(const u32x2_t& in) {
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  struct P2 { T a, b; };
+  u32x4_t out;
+#pragma unroll
+  for (int w2 = 0; w2 < 2; ++w2) {
+    const f32x2 f01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)in[w2], false);
+    const f32x2 f23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)in[w2], true);
+    out[2 * w2] = __builtin_bit_cast(uint32_t, P2{(T)f01[0], (T)f01[1]});
+    out[2 * w2 + 1] = __builtin_bit_cast(uint32_t, P2{(T)f23[0], (T)f23[1]});
+  }
+  return out;
+}
+
+template <typename T, int D, bool KV8 = false>
 __global__ __launch_bounds__(256, 2) void extend_attn_kernel(const ExtendParams p) {
   using Tr = ElemTraits<T>;
   using vec8 = typename Tr::vec8;
@@ -130,11 +148,12 @@ __global__ __launch_bounds__(256, 2) void extend_attn_kernel(const ExtendParams 
 
   // ---- cooperative staging: thread loads chunk c16 of rows rsub + RPI*i ----
   const int c16 = tid % LPR, rsub = tid / LPR;
-  const char* kpool = (const char*)p.k_buf + ((int64_t)kh * p.k_stride_h) * 2 + c16 * 16;
-  const char* vpool = (const char*)p.v_buf + ((int64_t)kh * p.v_stride_h) * 2 + c16 * 16;
+  constexpr int PB = KV8 ? 1 : 2;  // bytes per pool element; a thread's 8 elements are 8 * PB bytes of the pool row
+  const char* kpool = (const char*)p.k_buf + ((int64_t)kh * p.k_stride_h) * PB + c16 * 8 * PB;
+  const char* vpool = (const char*)p.v_buf + ((int64_t)kh * p.v_stride_h) * PB + c16 * 8 * PB;
   const char* kext = (const char*)p.ke + ((int64_t)q0 * p.ke_stride_t + (int64_t)kh * D) * 2 + c16 * 16;
   const char* vext = (const char*)p.ve + ((int64_t)q0 * p.ve_stride_t + (int64_t)kh * D) * 2 + c16 * 16;
-  const int64_t kpst = p.k_stride_t * 2, vpst = p.v_stride_t * 2, kest = p.ke_stride_t * 2, vest = p.ve_stride_t * 2;
+  const int64_t kpst = p.k_stride_t * PB, vpst = p.v_stride_t * PB, kest = p.ke_stride_t * 2, vest = p.ve_stride_t * 2;
 
   const int npre_tiles = (pre_len + kKT - 1) / kKT;
   const int ext_end = p.is_causal ? min(ext_len, qpos0 + bq) : ext_len;  // keys any row of this block may see
@@ -151,8 +170,14 @@ __global__ __launch_bounds__(256, 2) void extend_attn_kernel(const ExtendParams 
         const int r = base + rsub + RPI * i;
         const bool ok = r < pre_len;
         const int id = ok ? idx_row[r] : 0;
-        kreg[i] = *(const u32x4_t*)(kpool + (int64_t)id * kpst);
-        const u32x4_t vv = *(const u32x4_t*)(vpool + (int64_t)id * vpst);
+        u32x4_t vv;
+        if constexpr (KV8) {
+          kreg[i] = cvt8_fp8<T>(*(const u32x2_t*)(kpool + (int64_t)id * kpst));
+          vv = cvt8_fp8<T>(*(const u32x2_t*)(vpool + (int64_t)id * vpst));
+        } else {
+          kreg[i] = *(const u32x4_t*)(kpool + (int64_t)id * kpst);
+          vv = *(const u32x4_t*)(vpool + (int64_t)id * vpst);
+        }
         vreg[i] = ok ? vv : zero4;
       }
     } else {
@@ -203,6 +228,14 @@ __global__ __launch_bounds__(256, 2) void extend_attn_kernel(const ExtendParams 
     const bool in_prefix = t < npre_tiles;
     const int kbase = in_prefix ? t * kKT : (t - npre_tiles) * kKT;  // index of the tile's first key in its phase
     const int klimit = in_prefix ? pre_len : ext_len;
+    float tsm = p.sm_scale, tlog2 = scale_log2, pvs = 1.0f;  // the pool's k_scale / v_scale apply to prefix tiles only
+    if constexpr (KV8) {
+      if (in_prefix) {
+        tsm *= p.k_scale;
+        tlog2 *= p.k_scale;
+        pvs = p.v_scale;
+      }
+    }
 
     // a wave whose rows all lie in the causal past of this tile skips it (wave-uniform)
     const int wave_qmax = qpos0 + (((2 * w + 1) * 16) & (bq - 1)) + 15;
@@ -236,7 +269,7 @@ __global__ __launch_bounds__(256, 2) void extend_attn_kernel(const ExtendParams 
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int key = kbase + 16 * tt + 4 * g + r;
-            float v = use_cap ? softcap2(s[qt][tt][r] * p.sm_scale, p.logit_cap) : s[qt][tt][r] * scale_log2;
+            float v = use_cap ? softcap2(s[qt][tt][r] * tsm, p.logit_cap) : s[qt][tt][r] * tlog2;
             bool ok = key < klimit;
             if (!in_prefix && p.is_causal) ok = ok && (key <= qpos[qt]);
             v = ok ? v : -INFINITY;
@@ -257,7 +290,7 @@ __global__ __launch_bounds__(256, 2) void extend_attn_kernel(const ExtendParams 
             const float pv = dead ? 0.0f : __builtin_amdgcn_exp2f(s[qt][tt][r] - m_new);
             lsum += pv;
             // PV k-step u = tt / 2 takes keys 32 u + {4 g + j, 16 + 4 g + j}: element index 4 (tt & 1) + r
-            pf[qt][tt >> 1][4 * (tt & 1) + r] = Tr::from_f32(pv);
+            pf[qt][tt >> 1][4 * (tt & 1) + r] = Tr::from_f32(KV8 ? pv * pvs : pv);
           }
         }
         l_i[qt] = l_i[qt] * alpha + lsum;
@@ -395,12 +428,12 @@ __global__ __launch_bounds__(64) void extend_attn_generic(const ExtendParams p, 
   }
 }
 
-template <typename T, int D>
+template <typename T, int D, bool KV8>
 int launch_mfma(ExtendParams& p, int max_len_extend, hipStream_t st) {
   constexpr int smem = 2 * 2 * kKT * D * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)extend_attn_kernel<T, D>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)extend_attn_kernel<T, D, KV8>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
   // head slots per workgroup: smallest power of two >= min(group, 8); positions per workgroup = 128 / slots
@@ -418,15 +451,15 @@ int launch_mfma(ExtendParams& p, int max_len_extend, hipStream_t st) {
     snprintf(g_sgl_mi355_err, sizeof(g_sgl_mi355_err), "extend_attention: grid too large");
     return SGL_MI355_EINVAL;
   }
-  hipLaunchKernelGGL((extend_attn_kernel<T, D>), dim3((unsigned)nblocks), dim3(256), smem, st, p);
+  hipLaunchKernelGGL((extend_attn_kernel<T, D, KV8>), dim3((unsigned)nblocks), dim3(256), smem, st, p);
   SGL_HIP_LAUNCH_CHECK();
   return SGL_MI355_OK;
 }
 
 template <typename T>
 int launch_all(ExtendParams& p, int d_qk, int dv, int total_q, int max_len_extend, hipStream_t st) {
-  if (d_qk == dv && d_qk == 128) return launch_mfma<T, 128>(p, max_len_extend, st);
-  if (d_qk == dv && d_qk == 64) return launch_mfma<T, 64>(p, max_len_extend, st);
+  if (d_qk == dv && d_qk == 128) return p.kv_fp8 ? launch_mfma<T, 128, true>(p, max_len_extend, st) : launch_mfma<T, 128, false>(p, max_len_extend, st);
+  if (d_qk == dv && d_qk == 64) return p.kv_fp8 ? launch_mfma<T, 64, true>(p, max_len_extend, st) : launch_mfma<T, 64, false>(p, max_len_extend, st);
   hipLaunchKernelGGL((extend_attn_generic<T>), dim3(total_q, p.hq), dim3(64), 0, st, p, d_qk, dv, total_q);
   SGL_HIP_LAUNCH_CHECK();
   return SGL_MI355_OK;
@@ -442,7 +475,7 @@ extern "C" int sgl_mi355_extend_attention(
     const int64_t* req_pool_indices, const int64_t* seq_lens, const int32_t* extend_seq_lens,
     const int32_t* extend_start_loc, int batch, int total_q_tokens, int max_len_extend, int num_q_heads,
     int num_kv_heads, int head_dim, int v_head_dim, float sm_scale, float logit_cap, int is_causal, int dtype,
-    void* stream) {
+    int kv_dtype, float k_scale, float v_scale, void* stream) {
   SGL_CHECK(batch >= 0 && total_q_tokens >= 0, "extend_attention: negative sizes");
   if (batch == 0 || total_q_tokens == 0 || max_len_extend <= 0) return SGL_MI355_OK;
   SGL_CHECK(q_extend && k_extend && v_extend && o_extend, "extend_attention: null tensor pointer");
@@ -454,6 +487,10 @@ extern "C" int sgl_mi355_extend_attention(
   SGL_CHECK(head_dim > 0 && head_dim <= 256 && v_head_dim > 0 && v_head_dim <= 256,
             "extend_attention: head dims (%d, %d) outside (0, 256]", head_dim, v_head_dim);
   SGL_CHECK(dtype == SGL_BF16 || dtype == SGL_F16, "extend_attention: dtype code %d unsupported (bf16=0, f16=1)", dtype);
+  SGL_CHECK(kv_dtype == dtype || kv_dtype == SGL_FP8_E4M3, "extend_attention: kv_dtype %d must be the q dtype or fp8_e4m3", kv_dtype);
+  const bool kv8 = kv_dtype == SGL_FP8_E4M3 && k_buffer != nullptr;
+  SGL_CHECK(!kv8 || (head_dim == v_head_dim && (head_dim == 128 || head_dim == 64)),
+            "extend_attention: the fp8 KV cache needs head_dim == v_head_dim in {64, 128} (got %d, %d)", head_dim, v_head_dim);
   if (head_dim == v_head_dim && (head_dim == 128 || head_dim == 64)) {
     SGL_CHECK(q_stride_t % 8 == 0 && k_stride_t_ext % 8 == 0 && v_stride_t_ext % 8 == 0 && o_stride_t % 4 == 0 &&
                   k_stride_t % 8 == 0 && v_stride_t % 8 == 0 && k_stride_h % 8 == 0 && v_stride_h % 8 == 0 &&
@@ -473,6 +510,7 @@ extern "C" int sgl_mi355_extend_attention(
   p.seq_lens = seq_lens; p.extend_seq_lens = extend_seq_lens; p.extend_start_loc = extend_start_loc;
   p.bs = batch; p.hq = num_q_heads; p.hkv = num_kv_heads; p.group = num_q_heads / num_kv_heads;
   p.sm_scale = sm_scale; p.logit_cap = logit_cap; p.is_causal = is_causal;
+  p.kv_fp8 = kv8 ? 1 : 0; p.k_scale = kv8 ? k_scale : 1.0f; p.v_scale = kv8 ? v_scale : 1.0f;
   p.nqb = 0; p.bq_log2 = 0; p.hchunks = 1;
   hipStream_t st = (hipStream_t)stream;
   return dtype == SGL_BF16 ? launch_all<__bf16>(p, head_dim, v_head_dim, total_q_tokens, max_len_extend, st)

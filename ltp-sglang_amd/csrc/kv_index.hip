@@ -270,6 +270,95 @@ extern "C" int sgl_mi355_get_last_loc(const int32_t* req_to_token, int64_t req_t
   return SGL_MI355_OK;
 }
 
+// ---- fp8 (e4m3fn) KV cache: set_kv_buffer with kv_cache_dtype = fp8_e4m3 (memory_pool.py:385-395) ----
+// cache_k.div_(k_scale) in the source dtype (when a scale is given), then .to(float8_e4m3fn): round-to-nearest-even, and
+// what torch turns into NaN (|x| > 464, inf, NaN -> 0x7F | sign; c10/util/Float8_e4m3fn.h) instead of the hardware's
+// saturation to 448.
+namespace {
+template <typename T>
+__device__ __forceinline__ uint32_t cvt4_to_fp8(const T* x, float inv_or_zero, float scale) {
+  float f[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float v = (float)x[i];
+    if (scale > 0.0f) {  // div_ rounds to the tensor dtype before the cast (forced through the bit pattern: clang keeps
+      uint32_t bits = __builtin_bit_cast(uint16_t, (T)(v / scale));  // 16-bit float expressions in excess precision)
+      asm volatile("" : "+v"(bits));
+      v = (float)__builtin_bit_cast(T, (uint16_t)bits);
+    }
+    f[i] = v;
+  }
+  (void)inv_or_zero;
+  int w = 0;
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], w, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w, true);
+  uint32_t u = (uint32_t)w;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (!(fabsf(f[i]) <= 464.0f)) {
+      const uint32_t nanb = 0x7Fu | ((__builtin_bit_cast(uint32_t, f[i]) >> 24) & 0x80u);
+      u = (u & ~(0xFFu << (8 * i))) | (nanb << (8 * i));
+    }
+  }
+  return u;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void set_kv_buffer_fp8_kernel(uint8_t* k_buffer, uint8_t* v_buffer, int64_t k_slot_bytes,
+                                                                int64_t v_slot_bytes, const int64_t* loc, const T* cache_k,
+                                                                const T* cache_v, int64_t ck_stride, int64_t cv_stride,
+                                                                int k_row, int v_row, int64_t tokens, float k_scale,
+                                                                float v_scale) {
+  const int kch = k_row / 8, vch = v_row / 8;  // 8-element chunks per row
+  const int64_t total = tokens * (kch + vch);
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t t = idx / (kch + vch);
+    const int c = (int)(idx - t * (kch + vch));
+    const int64_t slot = loc[t];
+    const bool is_k = c < kch;
+    const int cc = is_k ? c : c - kch;
+    const T* src = (is_k ? cache_k + t * ck_stride : cache_v + t * cv_stride) + 8 * cc;
+    const u32x4_t raw = *(const u32x4_t*)src;
+    struct P8 { T v[8]; };
+    const P8 x = __builtin_bit_cast(P8, raw);
+    const float sc = is_k ? k_scale : v_scale;
+    u32x2_t out;
+    out[0] = cvt4_to_fp8<T>(x.v, 0.f, sc);
+    out[1] = cvt4_to_fp8<T>(x.v + 4, 0.f, sc);
+    uint8_t* dst = (is_k ? k_buffer + slot * k_slot_bytes : v_buffer + slot * v_slot_bytes) + 8 * cc;
+    *(u32x2_t*)dst = out;
+  }
+}
+}  // namespace
+
+// strides / row sizes in ELEMENTS of the source dtype (bf16 / f16); pool slot strides in bytes; k_scale / v_scale <= 0: none
+extern "C" int sgl_mi355_set_kv_buffer_fp8(void* k_buffer, void* v_buffer, int64_t k_slot_bytes, int64_t v_slot_bytes,
+                                           const int64_t* loc, const void* cache_k, const void* cache_v,
+                                           int64_t cache_k_stride, int64_t cache_v_stride, int k_row, int v_row,
+                                           int64_t tokens, int src_dtype, float k_scale, float v_scale, void* stream) {
+  SGL_CHECK(tokens >= 0, "set_kv_buffer_fp8: negative token count");
+  if (tokens == 0) return SGL_MI355_OK;
+  SGL_CHECK(k_buffer && v_buffer && loc && cache_k && cache_v, "set_kv_buffer_fp8: null pointer");
+  SGL_CHECK(src_dtype == SGL_BF16 || src_dtype == SGL_F16, "set_kv_buffer_fp8: source dtype must be bf16 or f16");
+  SGL_CHECK(k_row % 8 == 0 && v_row % 8 == 0 && k_slot_bytes % 8 == 0 && v_slot_bytes % 8 == 0 && cache_k_stride % 8 == 0 &&
+                cache_v_stride % 8 == 0 && ((uintptr_t)k_buffer % 8) == 0 && ((uintptr_t)v_buffer % 8) == 0 &&
+                ((uintptr_t)cache_k % 16) == 0 && ((uintptr_t)cache_v % 16) == 0,
+            "set_kv_buffer_fp8: rows must be multiples of 8 elements and 16-byte aligned at the source");
+  const int64_t total = tokens * (k_row / 8 + v_row / 8);
+  const unsigned blocks = (unsigned)((total + 255) / 256 > 65535 ? 65535 : (total + 255) / 256);
+  hipStream_t st = (hipStream_t)stream;
+  if (src_dtype == SGL_BF16)
+    hipLaunchKernelGGL((set_kv_buffer_fp8_kernel<__bf16>), dim3(blocks), dim3(256), 0, st, (uint8_t*)k_buffer, (uint8_t*)v_buffer,
+                       k_slot_bytes, v_slot_bytes, loc, (const __bf16*)cache_k, (const __bf16*)cache_v, cache_k_stride,
+                       cache_v_stride, k_row, v_row, tokens, k_scale, v_scale);
+  else
+    hipLaunchKernelGGL((set_kv_buffer_fp8_kernel<_Float16>), dim3(blocks), dim3(256), 0, st, (uint8_t*)k_buffer,
+                       (uint8_t*)v_buffer, k_slot_bytes, v_slot_bytes, loc, (const _Float16*)cache_k, (const _Float16*)cache_v,
+                       cache_k_stride, cache_v_stride, k_row, v_row, tokens, k_scale, v_scale);
+  SGL_HIP_LAUNCH_CHECK();
+  return SGL_MI355_OK;
+}
+
 // k_buffer/v_buffer: pool bases for one layer; slot strides in bytes.  cache_k/cache_v: [tokens, row] with byte strides.
 extern "C" int sgl_mi355_set_kv_buffer(void* k_buffer, void* v_buffer, int64_t k_slot_bytes, int64_t v_slot_bytes,
                                        const int64_t* loc, const void* cache_k, const void* cache_v,

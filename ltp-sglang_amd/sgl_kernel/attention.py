@@ -46,8 +46,11 @@ def decode_attention_fwd(
     max_kv_splits: int,
     sm_scale: float,
     logit_cap: float = 0.0,
+    k_scale: float = 1.0,
+    v_scale: float = 1.0,
 ) -> None:
     """o[b,h,:] = softmax(sm_scale * q[b,h] K^T) V over kv_indices[kv_indptr[b]:kv_indptr[b+1]].
+    k/v_buffer may be float8_e4m3fn (kv_cache_dtype fp8_e4m3): K_true = K * k_scale, V_true = V * v_scale.
 
     Same contract as decode_attention.py:677-728: q [bs, Hq, D]; k/v_buffer [pool, Hkv, D(v)];
     o [bs, Hq, Dv]; attn_logits f32 [bs, Hq, max_kv_splits, Dv]; attn_lse f32 [bs, Hq, max_kv_splits].
@@ -64,7 +67,7 @@ def decode_attention_fwd(
     hkv, dv = v_buffer.shape[1], v_buffer.shape[2]
     assert q.stride(2) == 1 and q.stride(1) == d, "q must be [bs, Hq, D] with contiguous heads"
     assert o is None or (o.stride(2) == 1 and o.stride(1) == dv and o.dtype == q.dtype)
-    assert q.dtype == k_buffer.dtype == v_buffer.dtype
+    assert k_buffer.dtype == v_buffer.dtype and k_buffer.dtype in (q.dtype, torch.float8_e4m3fn)
     kst, ksh = _row_strides(k_buffer)
     vst, vsh = _row_strides(v_buffer)
     check(
@@ -72,7 +75,8 @@ def decode_attention_fwd(
             ptr(q), q.stride(0), ptr(k_buffer), ptr(v_buffer), kst, ksh, vst, vsh, ptr(o), 0 if o is None else o.stride(0),
             ptr(kv_indptr), ptr(kv_indices), None, 0, None, None,
             ptr(attn_logits), ptr(attn_lse), ptr(num_kv_splits), int(max_kv_splits),
-            bs, hq, hkv, d, dv, float(sm_scale), float(logit_cap), dtype_code(q.dtype), current_stream(),
+            bs, hq, hkv, d, dv, float(sm_scale), float(logit_cap), dtype_code(q.dtype), dtype_code(k_buffer.dtype),
+            float(k_scale), float(v_scale), current_stream(),
         )
     )
 
@@ -80,7 +84,7 @@ def decode_attention_fwd(
 def extend_attention_fwd(
     q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr, kv_indptr, kv_indices, custom_mask,
     is_causal, mask_indptr, max_len_extend, sm_scale=None, logit_cap=0.0, skip_prefix_custom_mask=True,
-    sliding_window_size=-1,
+    sliding_window_size=-1, k_scale=1.0, v_scale=1.0,
 ) -> None:
     """Same contract as extend_attention.py:306-438: q/o_extend [T, Hq, D], k/v_extend [T, Hkv, D] contiguous new
     tokens, k/v_buffer the pool, kv_indices the cached prefix slots of each request."""
@@ -103,7 +107,8 @@ def extend_attention_fwd(
             v_extend.stride(0), o_extend.stride(0), ptr(k_buffer), ptr(v_buffer), kst, ksh, vst, vsh, ptr(qo_indptr),
             ptr(kv_indptr), ptr(kv_indices), None, 0, None, None, None, None, qo_indptr.numel() - 1, t,
             int(max_len_extend), hq, hkv, d, dv, float(sm_scale), float(logit_cap), int(bool(is_causal)),
-            dtype_code(q_extend.dtype), current_stream(),
+            dtype_code(q_extend.dtype), dtype_code(q_extend.dtype if k_buffer is None else k_buffer.dtype), float(k_scale),
+            float(v_scale), current_stream(),
         )
     )
 
@@ -132,7 +137,7 @@ def decode_attention(query, k_cache, v_cache, output, key, value, loc, attn_logi
             ptr(query), query.stride(0), ptr(k_cache), ptr(v_cache), kst, ksh, vst, vsh, ptr(output), output.stride(0),
             None, None, ptr(req_to_token), req_to_token.stride(0), ptr(req_pool_indices), ptr(seq_lens), ptr(logits),
             ptr(lse), ptr(nsplit), splits, bs, hq, hkv, d, dv, float(sm_scale), float(logit_cap), dtype_code(query.dtype),
-            current_stream(),
+            dtype_code(k_cache.dtype), 1.0, 1.0, current_stream(),
         )
     )
 
@@ -154,6 +159,6 @@ def extend_attention(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer,
             v_extend.stride(0), o_extend.stride(0), ptr(k_buffer), ptr(v_buffer), kst, ksh, vst, vsh, None, None, None,
             ptr(req_to_token), req_to_token.stride(0), ptr(req_pool_indices), ptr(seq_lens), ptr(extend_seq_lens),
             ptr(extend_start_loc), seq_lens.numel(), t, int(max_len_extend), hq, hkv, d, dv, float(sm_scale),
-            float(logit_cap), 1, dtype_code(q_extend.dtype), current_stream(),
+            float(logit_cap), 1, dtype_code(q_extend.dtype), dtype_code(k_buffer.dtype), 1.0, 1.0, current_stream(),
         )
     )

@@ -5,7 +5,7 @@ from typing import Optional
 
 import torch
 
-from .._cabi import check, current_stream, is64, lib, ptr
+from .._cabi import dtype_code, check, current_stream, is64, lib, ptr
 
 
 def create_kv_indices(req_to_token, req_pool_indices, page_kernel_lens, kv_indptr, kv_start_idx, kv_indices) -> None:
@@ -47,12 +47,21 @@ def get_last_loc(req_to_token, req_pool_indices, prefix_lens) -> torch.Tensor:
     return result
 
 
-def set_kv_buffer(k_buffer, v_buffer, loc, cache_k, cache_v) -> None:
-    """k_buffer[loc] = cache_k ; v_buffer[loc] = cache_v for one layer's [slots, Hkv, D] pools."""
-    assert loc.dtype == torch.int64 and k_buffer.dtype == cache_k.dtype and v_buffer.dtype == cache_v.dtype
+def set_kv_buffer(k_buffer, v_buffer, loc, cache_k, cache_v, k_scale=None, v_scale=None) -> None:
+    """k_buffer[loc] = cache_k ; v_buffer[loc] = cache_v for one layer's [slots, Hkv, D] pools.  float8_e4m3fn pools
+    (kv_cache_dtype fp8_e4m3, memory_pool.py:385-395): cache.div_(scale) if a scale is given, then .to(fp8)."""
     t = loc.numel()
     ck, cv = cache_k.reshape(t, -1), cache_v.reshape(t, -1)
+    assert loc.dtype == torch.int64
     assert ck.stride(1) == 1 and cv.stride(1) == 1 and k_buffer[0].is_contiguous() and v_buffer[0].is_contiguous()
+    if k_buffer.dtype == torch.float8_e4m3fn and cache_k.dtype != k_buffer.dtype:
+        assert v_buffer.dtype == torch.float8_e4m3fn and cache_k.dtype == cache_v.dtype
+        check(lib.sgl_mi355_set_kv_buffer_fp8(ptr(k_buffer), ptr(v_buffer), k_buffer.stride(0), v_buffer.stride(0), ptr(loc),
+                                              ptr(ck), ptr(cv), ck.stride(0), cv.stride(0), ck.shape[1], cv.shape[1], t,
+                                              dtype_code(cache_k.dtype), -1.0 if k_scale is None else float(k_scale),
+                                              -1.0 if v_scale is None else float(v_scale), current_stream()))
+        return
+    assert k_buffer.dtype == cache_k.dtype and v_buffer.dtype == cache_v.dtype
     es = k_buffer.element_size()
     check(lib.sgl_mi355_set_kv_buffer(ptr(k_buffer), ptr(v_buffer), k_buffer.stride(0) * es, v_buffer.stride(0) * es,
                                       ptr(loc), ptr(ck), ptr(cv), ck.stride(0) * es, cv.stride(0) * es, ck.shape[1] * es,

@@ -151,7 +151,7 @@ class HipAttnBackend(AttentionBackend):
         self._check_layer(layer)
         o = q.new_empty((q.shape[0], layer.tp_q_head_num * layer.v_head_dim))
         if save_kv_cache:
-            forward_batch.token_to_kv_pool.set_kv_buffer(layer, forward_batch.out_cache_loc, k, v)
+            forward_batch.token_to_kv_pool.set_kv_buffer(layer, forward_batch.out_cache_loc, k, v, layer.k_scale, layer.v_scale)
         md = self.forward_metadata
         causal = not (layer.is_cross_attention or getattr(layer.attn_type, "value", "decoder") == "encoder_only")
         K.extend_attention_fwd(
@@ -160,6 +160,7 @@ class HipAttnBackend(AttentionBackend):
             forward_batch.token_to_kv_pool.get_key_buffer(layer.layer_id),
             forward_batch.token_to_kv_pool.get_value_buffer(layer.layer_id),
             md.qo_indptr, md.kv_indptr, md.kv_indices, None, causal, None, md.max_extend_len, layer.scaling, layer.logit_cap,
+            k_scale=layer.k_scale_float or 1.0, v_scale=layer.v_scale_float or 1.0,
         )
         return o
 
@@ -168,7 +169,7 @@ class HipAttnBackend(AttentionBackend):
         q = q.reshape(-1, layer.tp_q_head_num * layer.qk_head_dim)
         o = q.new_empty((q.shape[0], layer.tp_q_head_num * layer.v_head_dim))
         if save_kv_cache:  # decode reads the new token from the pool, so this must precede the attention launch
-            forward_batch.token_to_kv_pool.set_kv_buffer(layer, forward_batch.out_cache_loc, k, v)
+            forward_batch.token_to_kv_pool.set_kv_buffer(layer, forward_batch.out_cache_loc, k, v, layer.k_scale, layer.v_scale)
         md = self.forward_metadata
         K.decode_attention_fwd(
             q.view(-1, layer.tp_q_head_num, layer.qk_head_dim),
@@ -176,7 +177,7 @@ class HipAttnBackend(AttentionBackend):
             forward_batch.token_to_kv_pool.get_value_buffer(layer.layer_id),
             o.view(-1, layer.tp_q_head_num, layer.v_head_dim),
             md.kv_indptr, md.kv_indices, md.attn_logits, md.attn_lse, md.num_kv_splits, self.max_kv_splits,
-            layer.scaling, layer.logit_cap,
+            layer.scaling, layer.logit_cap, layer.k_scale_float or 1.0, layer.v_scale_float or 1.0,
         )
         return o
 
@@ -190,7 +191,7 @@ class HipAttnBackend(AttentionBackend):
             forward_batch.token_to_kv_pool.get_key_buffer(layer.layer_id),
             forward_batch.token_to_kv_pool.get_value_buffer(layer.layer_id),
             None, md.kv_indptr, md.kv_indices, md.attn_logits, md.attn_lse, md.num_kv_splits, self.max_kv_splits,
-            layer.scaling, layer.logit_cap,
+            layer.scaling, layer.logit_cap, layer.k_scale_float or 1.0, layer.v_scale_float or 1.0,
         )
         return md
 

@@ -100,6 +100,13 @@ class MHATokenToKVPool(KVCache):
         from ...sgl_kernel import set_kv_buffer
 
         layer_id = layer.layer_id if layer_id_override is None else layer_id_override
+        if self.dtype == torch.float8_e4m3fn and cache_k.dtype in (torch.bfloat16, torch.float16) and cache_k.is_cuda:
+            # kv_cache_dtype fp8_e4m3: division by the scale (if any) and the e4m3 conversion happen inside the scatter
+            # kernel (the reference's div_ / .to() / index_put sequence, :385-407; the caller's tensors stay untouched)
+            i = layer_id - self.start_layer
+            set_kv_buffer(self._typed(self.k_buffer[i]), self._typed(self.v_buffer[i]), loc, cache_k, cache_v,
+                          None if k_scale is None else float(k_scale), None if v_scale is None else float(v_scale))
+            return
         if cache_k.dtype != self.dtype:
             if k_scale is not None:
                 cache_k.div_(k_scale)

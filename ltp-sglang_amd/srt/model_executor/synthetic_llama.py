@@ -242,7 +242,8 @@ class LlamaForCausalLM(nn.Module):
                                                           slab_sx=slab_sx, slab_sw=slab_sw, dtype=self.dtype)
             lid = attn.attn.layer_id
             fw = self._fused_weights(layer)
-            if fw is not None:   # qkv GEMM with the RoPE + KV-write epilogue
+            kv8 = pool.dtype == torch.float8_e4m3fn   # fp8 KV cache: the pool write converts, so it is its own kernel
+            if fw is not None and not kv8:   # qkv GEMM with the RoPE + KV-write epilogue
                 q = K.fp8_qkv_rope_set_kv(xq, xs.view(-1), fw["qkv_w"], fw["qkv_s"], fw["qkv_b"], positions,
                                           attn.rotary_emb.cos_sin_cache, forward_batch.out_cache_loc, pool.get_key_buffer(lid),
                                           pool.get_value_buffer(lid), attn.num_heads, attn.num_kv_heads, attn.head_dim, self.dtype)
@@ -250,8 +251,12 @@ class LlamaForCausalLM(nn.Module):
                 qkv = K.fp8_scaled_mm(xq, attn.qkv_proj.weight, xs.view(-1), attn.qkv_proj.weight_scale.view(-1), self.dtype,
                                       attn.qkv_proj.bias)
                 q, k, v = qkv.split([attn.q_size, attn.kv_size, attn.kv_size], dim=-1)
-                K.rope_set_kv(positions, q, k, v, attn.head_dim, attn.rotary_emb.cos_sin_cache, True, pool.get_key_buffer(lid),
-                              pool.get_value_buffer(lid), forward_batch.out_cache_loc)
+                if kv8:
+                    attn.rotary_emb(positions, q, k)
+                    pool.set_kv_buffer(attn.attn, forward_batch.out_cache_loc, k, v, attn.attn.k_scale, attn.attn.v_scale)
+                else:
+                    K.rope_set_kv(positions, q, k, v, attn.head_dim, attn.rotary_emb.cos_sin_cache, True,
+                                  pool.get_key_buffer(lid), pool.get_value_buffer(lid), forward_batch.out_cache_loc)
             md = backend.forward_decode_partial(q, attn.attn, forward_batch)
             _, oq, osc = K.decode_merge_quant_fp8(md.attn_logits, md.attn_lse, md.kv_indptr, md.num_kv_splits,
                                                   backend.max_kv_splits, self.dtype)
@@ -310,8 +315,12 @@ class LlamaForCausalLM(nn.Module):
             qkv = K.fp8_scaled_mm(xq, attn.qkv_proj.weight, xs.view(-1), attn.qkv_proj.weight_scale.view(-1), self.dtype,
                                   attn.qkv_proj.bias)
             q, k, v = qkv.split([attn.q_size, attn.kv_size, attn.kv_size], dim=-1)
-            K.rope_set_kv(positions, q, k, v, attn.head_dim, attn.rotary_emb.cos_sin_cache, True, pool.get_key_buffer(lid),
-                          pool.get_value_buffer(lid), forward_batch.out_cache_loc)
+            if pool.dtype == torch.float8_e4m3fn:
+                attn.rotary_emb(positions, q, k)
+                pool.set_kv_buffer(attn.attn, forward_batch.out_cache_loc, k, v, attn.attn.k_scale, attn.attn.v_scale)
+            else:
+                K.rope_set_kv(positions, q, k, v, attn.head_dim, attn.rotary_emb.cos_sin_cache, True, pool.get_key_buffer(lid),
+                              pool.get_value_buffer(lid), forward_batch.out_cache_loc)
             o = backend.forward_extend(q, k.view(-1, attn.num_kv_heads, attn.head_dim), v.view(-1, attn.num_kv_heads, attn.head_dim),
                                        attn.attn, forward_batch, save_kv_cache=False)
             oq, osc = K.sglang_per_token_quant_fp8(o)

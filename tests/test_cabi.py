@@ -37,13 +37,13 @@ def test_error_convention_status_and_message(pkg):
     with pytest.raises(RuntimeError, match="divisible by 8"):
         _cabi.check(rc)
     rc = lib.sgl_mi355_decode_attention(None, 0, None, None, 0, 0, 0, 0, None, 0, None, None, None, 0, None, None, None, None,
-                                        None, 4, 2, 8, 2, 128, 128, 1.0, 0.0, 0, None)
+                                        None, 4, 2, 8, 2, 128, 128, 1.0, 0.0, 0, 0, 1.0, 1.0, None)
     assert rc == 1 and "null" in _cabi.last_error()
     rc = lib.sgl_mi355_skinny_gemm(ctypes.c_void_p(16), 64, ctypes.c_void_p(16), 64, ctypes.c_void_p(16), 64, None, None, None,
                                    128, 8, 64, 3, 0, None, 0, None)
     assert rc == 1 and "exceeds 64" in _cabi.last_error()
     assert lib.sgl_mi355_decode_attention(None, 0, None, None, 0, 0, 0, 0, None, 0, None, None, None, 0, None, None, None,
-                                          None, None, 4, 0, 8, 2, 128, 128, 1.0, 0.0, 0, None) == 0  # empty batch: no-op
+                                          None, None, 4, 0, 8, 2, 128, 128, 1.0, 0.0, 0, 0, 1.0, 1.0, None) == 0  # empty batch: no-op
 
 
 def test_product_has_no_oracle_or_cpu_fallback():
