@@ -37,6 +37,9 @@ def parse_args():
     ap.add_argument("--model", default="llama3-8b", choices=["llama3-8b", "llama3-70b", "qwen2-7b", "tiny"])
     ap.add_argument("--quant", default="w8a8_fp8", choices=["w8a8_fp8", "fp8", "awq", "none"])
     ap.add_argument("--layers", type=int, default=0, help="override layer count (debug only; invalidates the metric)")
+    ap.add_argument("--kv-cache-dtype", default="auto", choices=["auto", "fp8_e4m3"],
+                    help="auto = the model dtype (the BASELINE configuration); fp8_e4m3 halves the KV stream (reported separately)")
+    ap.add_argument("--decode-attn-mode", type=int, default=-1, help="measurement hook: 0 / 1 = sgl_mi355_decode_attention_set_mode")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prefill-chunk", type=int, default=8, help="requests per prefill call")
@@ -110,6 +113,10 @@ def main():
     from ltp_sglang_amd.srt.model_executor.synthetic_llama import LlamaShape, SyntheticModelRunner
 
     comm.init_tensor_parallel()
+    if args.decode_attn_mode >= 0:
+        from ltp_sglang_amd import _cabi
+
+        _cabi.check(_cabi.lib.sgl_mi355_decode_attention_set_mode(args.decode_attn_mode))
     cfg = {"llama3-8b": LlamaShape.llama3_8b, "llama3-70b": LlamaShape.llama3_70b, "qwen2-7b": LlamaShape.qwen2_7b,
            "tiny": LlamaShape.tiny}[args.model]()
     if args.layers:
@@ -118,7 +125,9 @@ def main():
     bs, seq = args.batch, args.seq_len
     total_steps = args.steps + args.warmup + 4
     runner = SyntheticModelRunner(cfg, quant, max_running_requests=bs, context_len=seq + total_steps + 8,
-                                  max_total_tokens=bs * (seq + total_steps) + 64, device=dev, seed=0)
+                                  max_total_tokens=bs * (seq + total_steps) + 64, device=dev, seed=0,
+                                  kv_cache_dtype=torch.float8_e4m3fn if args.kv_cache_dtype == "fp8_e4m3" else None)
+    kv_es = 1 if args.kv_cache_dtype == "fp8_e4m3" else 2
     tp = comm.get_tensor_model_parallel_world_size()
 
     def barrier():
@@ -202,7 +211,7 @@ def main():
     torch.cuda.synchronize()
     attn_ms = sorted(a.elapsed_time(b) for a, b in evs[L:])  # first sweep = warm-up
     attn_ms = sum(attn_ms) / len(attn_ms)
-    kv_bytes = float(sum(state.seq_lens_cpu)) * hkv_r * d * 2 * 2  # K and V rows of every cached token, bf16
+    kv_bytes = float(sum(state.seq_lens_cpu)) * hkv_r * d * 2 * kv_es  # K and V rows of every cached token
     achieved = kv_bytes / (attn_ms * 1e-3) / 1e9
 
     if rank != 0:
@@ -211,7 +220,7 @@ def main():
     # comes from the committed summary of a `rocprofv3 --pmc` pass over this same command (tools/pmc_traffic.py)
     traffic, traffic_src = None, None
     pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_pmc_traffic.json")
-    if os.path.exists(pmc_path) and (args.model, args.quant, bs, seq, world) == ("llama3-8b", "w8a8_fp8", 32, 2048, 1):
+    if os.path.exists(pmc_path) and (args.model, args.quant, bs, seq, world, args.kv_cache_dtype) == ("llama3-8b", "w8a8_fp8", 32, 2048, 1, "auto"):
         with open(pmc_path) as f:
             pmc = json.load(f)
         k1 = pmc.get("kernels", {}).get("decode_attn_stage1", {})
@@ -220,18 +229,18 @@ def main():
             traffic_src = "profiles/round1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; FETCH_SIZE x2 on gfx950)"
     tok_s = bs * args.steps / elapsed
     weights_bytes = lin_params * (1 if quant in ("w8a8_fp8", "fp8") else (0.5 if quant == "awq" else 2)) + V * hid * 2
-    step_bytes = weights_bytes + bs * (seq + args.warmup + args.steps / 2) * L * 2 * hkv * d * 2
+    step_bytes = weights_bytes + bs * (seq + args.warmup + args.steps / 2) * L * 2 * hkv * d * kv_es
     out = {
         "metric": ("decode tokens/sec (whole job) + prefill TFLOPS, Llama-3-8B fp8 batch=32 seq=2048"
-                   if (args.model, args.quant, bs, seq) == ("llama3-8b", "w8a8_fp8", 32, 2048) else
-                   f"decode tokens/sec (whole job) + prefill TFLOPS, {args.model} {args.quant} batch={bs} seq={seq}"),
+                   if (args.model, args.quant, bs, seq, args.kv_cache_dtype) == ("llama3-8b", "w8a8_fp8", 32, 2048, "auto") else
+                   f"decode tokens/sec (whole job) + prefill TFLOPS, {args.model} {args.quant} batch={bs} seq={seq} kv={args.kv_cache_dtype}"),
         "value": tok_s, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "fp8_e4m3 weights+activations (f32 accumulate), bf16 KV/attention" if quant in ("w8a8_fp8", "fp8") else str(quant or "bf16"),
         "data": "synthetic",
         "config": {"workload": f"{args.model} {args.quant} decode, batch {bs} x context {seq} (+{args.warmup}+{args.steps} steps), "
                                f"KV pool filled by a real {bs}x{seq} prefill", "global_batch": bs, "seq_len": seq,
-                   "parallelism": f"tp{tp}", "hip_graph": bool(use_graph), "layers": L},
+                   "parallelism": f"tp{tp}", "hip_graph": bool(use_graph), "layers": L, "kv_cache_dtype": args.kv_cache_dtype},
         "prefill": {"tflops": prefill_flops / prefill_s / 1e12, "seconds": prefill_s, "tokens": bs * seq,
                     "tokens_per_s": bs * seq / prefill_s, "flops": prefill_flops},
         "step_roofline": {"algorithmic_bytes_per_step": step_bytes, "hbm_peak_GBps": 8000.0,

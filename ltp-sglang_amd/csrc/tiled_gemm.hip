@@ -24,6 +24,10 @@ struct GemmParams {
   const void* bias;
   int M, N, kbytes;
   int tiles_m, tiles_n;
+  int group_m;  // row tiles per scheduling group (256x256 kernel)
+#ifdef SGL_GEMM_TIMELINE
+  long long* tl;  // tools/microbench/gemm256_timeline.hip: s_memtime stamps of workgroup 0, slices 8..11
+#endif
 };
 
 enum { TG_FP8 = 0, TG_BF16 = 1, TG_F16 = 2 };
@@ -186,12 +190,24 @@ __global__ __launch_bounds__(256, 2) void tiled_gemm_kernel(const GemmParams p) 
 constexpr int T2 = 256;
 constexpr int OPB = T2 * BKB;  // 32 KiB per operand per buffer
 
+#ifdef SGL_GEMM_TIMELINE
+#define TL_STAMP(i)                                                                            \
+  do {                                                                                         \
+    if (bid == 0 && kt >= 8 && kt < 12) {                                                      \
+      const long long t_ = (long long)__builtin_amdgcn_s_memtime();                            \
+      if (lane == 0) p.tl[(((kt - 8) * 8 + w) * 16) + (i)] = t_;                               \
+    }                                                                                          \
+  } while (0)
+#else
+#define TL_STAMP(i)
+#endif
+
 __device__ __forceinline__ void glds16(const char* g, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <typename OutT, int NWV>  // NWV = 8: waves 2 (M) x 4 (N), 128 x 64 outputs each; 4: 2 x 2, 128 x 128 each (accumulators in AGPRs)
+template <typename OutT, int NWV, bool DMA = true>  // NWV = 8: waves 2 (M) x 4 (N), 128 x 64 outputs each; 4: 2 x 2, 128 x 128 each
 __global__ __launch_bounds__(NWV * 64, 1) void fp8_gemm256_kernel(const GemmParams p) {
   constexpr int WCOLS = NWV == 8 ? 4 : 2;     // waves along N
   constexpr int JN = 256 / WCOLS / 16;        // 16-column W fragments per wave
@@ -201,7 +217,14 @@ __global__ __launch_bounds__(NWV * 64, 1) void fp8_gemm256_kernel(const GemmPara
   const int bid = blockIdx.x;
   const int q = nwg / 8, r8 = nwg % 8, xcd = bid % 8;
   const int wgid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + bid / 8;
-  const int tm = wgid / p.tiles_n, tn = wgid - tm * p.tiles_n;
+  // grouped order: consecutive workgroups (the ~32 resident on one XCD at a time) cover a block of GM row tiles x 8 column
+  // tiles, so an X panel is fetched into that XCD's L2 once per 8 and a W panel once per GM of them instead of one W panel
+  // per workgroup (W re-reads from the Infinity Cache were the limiter: 7.5 GB per gate_up GEMM)
+  const int GM = p.group_m;
+  const int per_group = GM * p.tiles_n;
+  const int grp = wgid / per_group, in_grp = wgid - grp * per_group;
+  const int gsz = min(p.tiles_m - grp * GM, GM);
+  const int tm = grp * GM + in_grp % gsz, tn = in_grp / gsz;
   const int m0 = tm * T2, n0 = tn * T2;
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -224,13 +247,32 @@ __global__ __launch_bounds__(NWV * 64, 1) void fp8_gemm256_kernel(const GemmPara
     xvo[par] = (unsigned)((int64_t)(m0 + rl) * p.x_stride) + chunk * 16;
   }
   const int nk = p.kbytes / BKB;
+  u32x4_t sreg[DMA ? 1 : RPW / 8][2];  // register staging (DMA == false): one 16-byte piece per 8-row group and operand
   auto stage = [&](int kt, int buf) {
-    auto* wb = (__attribute__((address_space(3))) char*)(smem + buf * 2 * OPB + (RPW * w) * BKB);
     const int off = kt * BKB;
+    if constexpr (DMA) {
+      auto* wb = (__attribute__((address_space(3))) char*)(smem + buf * 2 * OPB + (RPW * w) * BKB);
 #pragma unroll
-    for (int t = 0; t < RPW / 8; ++t) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, wb + t * 8 * BKB, 16, wvo[t & 1], (int)(t * 8 * p.w_stride) + off, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, wb + OPB + t * 8 * BKB, 16, xvo[t & 1], (int)(t * 8 * p.x_stride) + off, 0, 0);
+      for (int t = 0; t < RPW / 8; ++t) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, wb + t * 8 * BKB, 16, wvo[t & 1], (int)(t * 8 * p.w_stride) + off, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, wb + OPB + t * 8 * BKB, 16, xvo[t & 1], (int)(t * 8 * p.x_stride) + off, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < RPW / 8; ++t) {
+        sreg[t][0] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvo[t & 1], (int)(t * 8 * p.w_stride) + off, 0));
+        sreg[t][1] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(xrs, xvo[t & 1], (int)(t * 8 * p.x_stride) + off, 0));
+      }
+    }
+  };
+  auto commit = [&](int buf) {  // register staging: the pieces land where the LDS-DMA would have put them
+    if constexpr (!DMA) {
+      char* wb = smem + buf * 2 * OPB + (RPW * w) * BKB + lane * 16;
+#pragma unroll
+      for (int t = 0; t < RPW / 8; ++t) {
+        *(u32x4_t*)(wb + t * 8 * BKB) = sreg[t][0];
+        *(u32x4_t*)(wb + OPB + t * 8 * BKB) = sreg[t][1];
+      }
     }
   };
 
@@ -244,13 +286,13 @@ __global__ __launch_bounds__(NWV * 64, 1) void fp8_gemm256_kernel(const GemmPara
   // MFMA group are fetched while the current group runs, and the barrier sits before the LAST group, so that its wait,
   // the re-staging of the buffer just drained and the first fragment reads of slice kt + 1 all hide behind 8-16 MFMAs.
   constexpr int NG = 4;                 // MFMA groups per slice: 2 X row-tiles (32 rows) x JN column tiles each
-  u32x4_t wf[JN][2], xf[2][2][2];
-  auto load_w = [&](int buf) {
+  u32x4_t wf[2][JN][2], xf[2][2][2];    // W fragments double-buffered across slices, X fragments across groups
+  auto load_w = [&](int buf, int ws) {
     const char* wa = smem + buf * 2 * OPB;
 #pragma unroll
     for (int j = 0; j < JN; ++j)
 #pragma unroll
-      for (int h = 0; h < 2; ++h) wf[j][h] = *(const u32x4_t*)(wa + lds_off(wn + 16 * j + a, 4 * h + g));
+      for (int h = 0; h < 2; ++h) wf[ws][j][h] = *(const u32x4_t*)(wa + lds_off(wn + 16 * j + a, 4 * h + g));
   };
   auto load_x = [&](int buf, int grp, int slot) {
     const char* xa = smem + buf * 2 * OPB + OPB;
@@ -259,29 +301,56 @@ __global__ __launch_bounds__(NWV * 64, 1) void fp8_gemm256_kernel(const GemmPara
 #pragma unroll
       for (int h = 0; h < 2; ++h) xf[slot][i][h] = *(const u32x4_t*)(xa + lds_off(wm + 32 * grp + 16 * i + a, 4 * h + g));
   };
-  auto mma = [&](int grp, int slot) {
+  auto mma = [&](int grp, int slot, int ws) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < JN; ++j) mfma_mx(wf[j][0], wf[j][1], xf[slot][i][0], xf[slot][i][1], acc[j][2 * grp + i]);
+      for (int j = 0; j < JN; ++j) mfma_mx(wf[ws][j][0], wf[ws][j][1], xf[slot][i][0], xf[slot][i][1], acc[j][2 * grp + i]);
   };
-  stage(0, 0);
-  __syncthreads();
-  stage(min(1, nk - 1), 1);
-  load_w(0);
-  load_x(0, 0, 0);
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
+  if constexpr (DMA) {
+    stage(0, 0);
+    __syncthreads();
+    stage(min(1, nk - 1), 1);
+    load_w(0, 0);
+    load_x(0, 0, 0);
+    // one slice; `ws` (which W fragment set it computes with) alternates, so the loop is unrolled by two
+    auto slice = [&](int kt, int buf, int ws) {
 #pragma unroll
-    for (int grp = 0; grp < NG - 1; ++grp) {
-      load_x(buf, grp + 1, (grp + 1) & 1);
-      mma(grp, grp & 1);
+      for (int grp = 0; grp < NG - 1; ++grp) {
+        load_x(buf, grp + 1, (grp + 1) & 1);
+        mma(grp, grp & 1, ws);
+      }
+      TL_STAMP(0);  // (stamps only where the wave drains lgkmcnt anyway: an s_memtime elsewhere serialises the LDS reads)
+      __syncthreads();  // slice kt + 1 has landed for every wave (vmcnt) and nobody reads buf any more (lgkmcnt)
+      TL_STAMP(1);
+      load_w(buf ^ 1, ws ^ 1);          // next slice's first fragments: in flight under the last MFMA group and the staging
+      load_x(buf ^ 1, 0, 0);            // (after the last slice these read a re-staged copy and are never used)
+      mma(NG - 1, (NG - 1) & 1, ws);
+      stage(min(kt + 2, nk - 1), buf);  // branch free: the last two iterations re-stage the final slice into drained buffers
+    };
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+      slice(kt, 0, 0);
+      slice(kt + 1, 1, 1);
     }
-    __syncthreads();  // slice kt + 1 has landed for every wave (vmcnt) and nobody reads buf any more (lgkmcnt)
-    stage(min(kt + 2, nk - 1), buf);  // branch free: the last two iterations re-stage the final slice into drained buffers
-    mma(NG - 1, (NG - 1) & 1);
-    load_w(buf ^ 1);                  // (after the last slice these read the re-staged copy and are never used)
-    load_x(buf ^ 1, 0, 0);
+    if (kt < nk) slice(kt, 0, 0);
+  } else {
+    stage(0, 0);
+    commit(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int buf = kt & 1;
+      stage(min(kt + 1, nk - 1), buf ^ 1);  // global loads of the next slice fly during this slice's MFMAs
+      load_w(buf, 0);
+      load_x(buf, 0, 0);
+#pragma unroll
+      for (int grp = 0; grp < NG; ++grp) {
+        if (grp + 1 < NG) load_x(buf, grp + 1, (grp + 1) & 1);
+        mma(grp, grp & 1, 0);
+      }
+      commit(buf ^ 1);
+      __syncthreads();
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may be in flight when the workgroup ends
 
@@ -329,19 +398,21 @@ int tg_cus() {
   }
   return cus;
 }
+int g_tiled_group_m = 4;
 int g_tiled_force = 0;  // test hook: 1 = always the 128x128 kernel, 2 = the 256x256 kernel whenever its shape rules allow
 
-template <typename OutT, int NWV>
+template <typename OutT, int NWV, bool DMA = true>
 int launch256(GemmParams& p, hipStream_t st) {
   constexpr int smem = 2 * 2 * OPB;  // 128 KiB
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)fp8_gemm256_kernel<OutT, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)fp8_gemm256_kernel<OutT, NWV, DMA>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
   p.tiles_m = (p.M + T2 - 1) / T2;
   p.tiles_n = (p.N + T2 - 1) / T2;
-  hipLaunchKernelGGL((fp8_gemm256_kernel<OutT, NWV>), dim3(p.tiles_m * p.tiles_n), dim3(NWV * 64), smem, st, p);
+  p.group_m = g_tiled_group_m;
+  hipLaunchKernelGGL((fp8_gemm256_kernel<OutT, NWV, DMA>), dim3(p.tiles_m * p.tiles_n), dim3(NWV * 64), smem, st, p);
   SGL_HIP_LAUNCH_CHECK();
   return SGL_MI355_OK;
 }
@@ -384,6 +455,7 @@ int run(const void* x, int64_t xs, const void* w, int64_t ws, void* y, int64_t y
     const int64_t tiles256 = (int64_t)((M + T2 - 1) / T2) * ((N + T2 - 1) / T2);
     const bool can256 = p.kbytes % BKB == 0 && p.kbytes >= BKB && (int64_t)N * p.w_stride < 0xFFFFFFF0ll &&
                         (int64_t)M * p.x_stride < 0xFFFFFFF0ll;  // 32-bit buffer offsets
+    if (can256 && g_tiled_force == 4) return out_dtype == SGL_BF16 ? launch256<__bf16, 8, false>(p, st) : launch256<_Float16, 8, false>(p, st);
     if (can256 && g_tiled_force == 3) return out_dtype == SGL_BF16 ? launch256<__bf16, 4>(p, st) : launch256<_Float16, 4>(p, st);
     if (can256 && g_tiled_force != 1 && (g_tiled_force == 2 || tiles256 >= tg_cus()))
       return out_dtype == SGL_BF16 ? launch256<__bf16, 8>(p, st) : launch256<_Float16, 8>(p, st);
@@ -396,6 +468,10 @@ int run(const void* x, int64_t xs, const void* w, int64_t ws, void* y, int64_t y
 }  // namespace
 
 extern "C" int sgl_mi355_fp8_gemm_force_tile(int mode) {
+  if (mode >= 100) {  // measurement hook: 100 + GM sets the scheduling group height of the 256x256 kernel
+    g_tiled_group_m = mode - 100 > 0 ? mode - 100 : 1;
+    return SGL_MI355_OK;
+  }
   g_tiled_force = mode;
   return SGL_MI355_OK;
 }

@@ -23,7 +23,8 @@ def run(m, n, k, mode, iters=10):
     print(f"mode={mode} M={m} N={n} K={k}: {ms:7.3f} ms  {2.0*m*n*k/ms/1e9:7.0f} TFLOP/s", flush=True)
 
 if __name__ == "__main__":
-    for mode in (1, 2, 3):
+    modes = [int(a) for a in sys.argv[1:]] or [1, 2, 3, 4]
+    for mode in modes:
         for n, k in [(6144, 4096), (4096, 4096), (28672, 4096), (4096, 14336)]:
             run(16384, n, k, mode)
     _cabi.lib.sgl_mi355_fp8_gemm_force_tile(0)

@@ -18,6 +18,11 @@ timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv 
   python3 $R/bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline > $OUT/${TAG}_pmc_write.log 2>&1
 echo "[profile] WRITE_SIZE pass done"
 python3 $R/tools/pmc_traffic.py $OUT/pmc_fetch_$TAG $OUT/pmc_write_$TAG > $OUT/${TAG}_pmc_traffic.json
+timeout -k 10 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_mfma_$TAG -o pmc -- \
+  python3 $R/bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline > $OUT/${TAG}_pmc_mfma.log 2>&1
+echo "[profile] MFMA pass done"
+python3 $R/tools/pmc_mfma.py $OUT/pmc_mfma_$TAG > $OUT/${TAG}_pmc_mfma.json
+rm -rf $OUT/pmc_mfma_$TAG
 # the raw per-dispatch CSVs are large: keep only the summaries in gpurun_out
 rm -rf $OUT/pmc_fetch_$TAG $OUT/pmc_write_$TAG
 find $OUT/prof_$TAG -name '*kernel_trace.csv' -delete
