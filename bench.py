@@ -40,6 +40,8 @@ def parse_args():
     ap.add_argument("--kv-cache-dtype", default="auto", choices=["auto", "fp8_e4m3"],
                     help="auto = the model dtype (the BASELINE configuration); fp8_e4m3 halves the KV stream (reported separately)")
     ap.add_argument("--decode-attn-mode", type=int, default=-1, help="measurement hook: 0 / 1 = sgl_mi355_decode_attention_set_mode")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (the measured configuration); gloo = rehearsal of the N > 1 path on fewer GPUs")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prefill-chunk", type=int, default=8, help="requests per prefill call")
@@ -98,13 +100,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
+    local_rank %= max(1, torch.cuda.device_count())  # (gloo rehearsal: several ranks may share one GPU)
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(dev))
+        else:
+            dist.init_process_group("gloo")
 
     from __graft_entry__ import load_package
 
@@ -141,6 +147,9 @@ def main():
     import numpy as np
 
     ids = torch.from_numpy(np.random.RandomState(0).randint(0, 10000, (bs, seq))).to(dev)
+    # untimed warm-up prefill (one short chunk: loads every prefill kernel's code object, sets the LDS attributes), undone
+    runner.extend([ids[i][: min(seq, 512)] for i in range(min(bs, args.prefill_chunk))])
+    runner.clear()
     # the allocator hands out consecutive slots; a random permutation of the free list makes the gather non-contiguous
     alloc = runner.token_to_kv_pool_allocator
     gperm = torch.Generator(device=dev).manual_seed(1)
@@ -186,7 +195,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

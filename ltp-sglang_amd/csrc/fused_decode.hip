@@ -91,12 +91,13 @@ __device__ __forceinline__ void quant_row(const float (&vals)[MAXV][8], int nvec
   }
 }
 
-template <typename T, int MAXV>
-__global__ __launch_bounds__(256) void add_rmsnorm_quant_kernel(const T* x, const float* slabs, int nslabs,
+template <typename T, int MAXV, bool SLABS = true>  // SLABS = false drops the split-K registers: 4x the occupancy at prefill-sized M
+__global__ __launch_bounds__(256) void add_rmsnorm_quant_kernel(const T* x, const float* slabs_, int nslabs,
                                                                 const float* slab_sx, const float* slab_sw, T* residual,
                                                                 const T* weight, float eps, T* out_norm, uint8_t* out_q,
                                                                 float* out_s, int tokens, int hidden) {
   __shared__ float red[4];
+  const float* slabs = SLABS ? slabs_ : nullptr;
   const int64_t row = blockIdx.x;
   const int nvec = hidden / 8;
   // Every global load of the kernel is issued up front (inputs were just written by other CUs, so each dependent
@@ -359,10 +360,21 @@ extern "C" int sgl_mi355_fused_add_rmsnorm_quant_fp8(const void* x, const float*
   SGL_CHECK(dtype == SGL_BF16 || dtype == SGL_F16, "fused_add_rmsnorm_quant_fp8: dtype must be bf16 or f16");
   SGL_CHECK(!slabs || nslabs >= 1, "fused_add_rmsnorm_quant_fp8: nslabs must be >= 1");
   hipStream_t st = (hipStream_t)stream;
+#define SGL_NORM_LAUNCH(MV, SL)                                                                                              \
+  hipLaunchKernelGGL((add_rmsnorm_quant_kernel<T, MV, SL>), dim3(tokens), dim3(256), 0, st, (const T*)x, slabs, nslabs, slab_sx, \
+                     slab_sw, (T*)residual, (const T*)weight, eps, (T*)out_norm, (uint8_t*)out_q, out_s, tokens, hidden)
   DISPATCH_HALF(dtype, {
-    hipLaunchKernelGGL((add_rmsnorm_quant_kernel<T, 4>), dim3(tokens), dim3(256), 0, st, (const T*)x, slabs, nslabs, slab_sx,
-                       slab_sw, (T*)residual, (const T*)weight, eps, (T*)out_norm, (uint8_t*)out_q, out_s, tokens, hidden);
+    if (slabs != nullptr) {
+      SGL_NORM_LAUNCH(4, true);
+    } else if (hidden <= 2048) {
+      SGL_NORM_LAUNCH(1, false);
+    } else if (hidden <= 4096) {
+      SGL_NORM_LAUNCH(2, false);
+    } else {
+      SGL_NORM_LAUNCH(4, false);
+    }
   })
+#undef SGL_NORM_LAUNCH
   SGL_HIP_LAUNCH_CHECK();
   return SGL_MI355_OK;
 }
