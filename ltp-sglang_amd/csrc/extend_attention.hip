@@ -241,6 +241,8 @@ __global__ __launch_bounds__(256, 2) void extend_attn_kernel(const ExtendParams 
     const int wave_qmax = qpos0 + (((2 * w + 1) * 16) & (bq - 1)) + 15;
     const int wave_qmax0 = qpos0 + (((2 * w) * 16) & (bq - 1)) + 15;
     const bool skip = !in_prefix && p.is_causal && kbase > max(wave_qmax, wave_qmax0);
+    const int wave_qmin = qpos0 + (bq >= 32 ? ((32 * w) & (bq - 1)) : 0);
+    const bool need_mask = (kbase + kKT > klimit) || (!in_prefix && p.is_causal && kbase + kKT - 1 > wave_qmin);
     if (!skip) {
       // ---- S^T tiles: s[qt][tt][r] = score(query row a of tile qt, key 16 tt + 4 g + r) ----
       f32x4_t s[2][4];
@@ -268,11 +270,13 @@ __global__ __launch_bounds__(256, 2) void extend_attn_kernel(const ExtendParams 
         for (int tt = 0; tt < 4; ++tt) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int key = kbase + 16 * tt + 4 * g + r;
             float v = use_cap ? softcap2(s[qt][tt][r] * tsm, p.logit_cap) : s[qt][tt][r] * tlog2;
-            bool ok = key < klimit;
-            if (!in_prefix && p.is_causal) ok = ok && (key <= qpos[qt]);
-            v = ok ? v : -INFINITY;
+            if (need_mask) {  // wave-uniform: only the ragged last tile of a phase and the causal diagonal pay for masking
+              const int key = kbase + 16 * tt + 4 * g + r;
+              bool ok = key < klimit;
+              if (!in_prefix && p.is_causal) ok = ok && (key <= qpos[qt]);
+              v = ok ? v : -INFINITY;
+            }
             s[qt][tt][r] = v;
             mt = fmaxf(mt, v);
           }
@@ -280,14 +284,15 @@ __global__ __launch_bounds__(256, 2) void extend_attn_kernel(const ExtendParams 
         mt = fmaxf(mt, __shfl_xor(mt, 16, WAVE));
         mt = fmaxf(mt, __shfl_xor(mt, 32, WAVE));
         const float m_new = fmaxf(m_i[qt], mt);
-        const bool dead = m_new == -INFINITY;  // row has seen no key yet
+        const bool dead = need_mask && m_new == -INFINITY;  // row has seen no key yet (impossible in an unmasked tile)
         const float alpha = dead ? 1.0f : __builtin_amdgcn_exp2f(m_i[qt] - m_new);
         float lsum = 0.f;
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float pv = dead ? 0.0f : __builtin_amdgcn_exp2f(s[qt][tt][r] - m_new);
+            float pv = __builtin_amdgcn_exp2f(s[qt][tt][r] - m_new);
+            if (need_mask) pv = dead ? 0.0f : pv;
             lsum += pv;
             // PV k-step u = tt / 2 takes keys 32 u + {4 g + j, 16 + 4 g + j}: element index 4 (tt & 1) + r
             pf[qt][tt >> 1][4 * (tt & 1) + r] = Tr::from_f32(KV8 ? pv * pvs : pv);
