@@ -223,6 +223,35 @@ __global__ __launch_bounds__(256) void rope_set_kv_kernel(const int64_t* positio
   const int64_t slot = loc[t];
   T* kdst = k_buf + slot * kb_stride;
   const int npairs = (hq + hk) * half;
+  // neox layout with 16-byte aligned rows: 8 rotation pairs per thread through 16-byte loads / stores (same arithmetic)
+  const bool vec = is_neox && half % 8 == 0 && head_size % 8 == 0 && q_stride % 8 == 0 && k_stride % 8 == 0 && kb_stride % 8 == 0 &&
+                   ((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)k_buf % 16) == 0 && ((uintptr_t)cache % 16) == 0 &&
+                   rot_dim % 4 == 0;
+  if (vec) {
+    const int hv = half / 8;
+    for (int idx = threadIdx.x; idx < (hq + hk) * hv; idx += 256) {
+      const int h = idx / hv, i0 = (idx - h * hv) * 8;
+      const bool isq = h < hq;
+      T* base = isq ? q + t * q_stride + (int64_t)h * head_size : k + t * k_stride + (int64_t)(h - hq) * head_size;
+      const V8<T> x1 = ld8(base + i0), x2 = ld8(base + half + i0);
+      const f32x4_t c0 = *(const f32x4_t*)(cs + i0), c1 = *(const f32x4_t*)(cs + i0 + 4);
+      const f32x4_t s0 = *(const f32x4_t*)(cs + half + i0), s1 = *(const f32x4_t*)(cs + half + i0 + 4);
+      V8<T> o1, o2;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float c = round_via<T>(j < 4 ? c0[j] : c1[j - 4]), sn = round_via<T>(j < 4 ? s0[j] : s1[j - 4]);
+        const float a1 = (float)x1.v[j], a2 = (float)x2.v[j];
+        o1.v[j] = (T)(round_via<T>(a1 * c) - round_via<T>(a2 * sn));
+        o2.v[j] = (T)(round_via<T>(a2 * c) + round_via<T>(a1 * sn));
+      }
+      st8(base + i0, o1);
+      st8(base + half + i0, o2);
+      if (!isq) {
+        st8(kdst + (h - hq) * head_size + i0, o1);
+        st8(kdst + (h - hq) * head_size + half + i0, o2);
+      }
+    }
+  } else
   for (int idx = threadIdx.x; idx < npairs; idx += 256) {
     const int h = idx / half, i = idx - h * half;
     const bool isq = h < hq;
