@@ -258,7 +258,7 @@ def main():
                      "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                      "traffic_source": traffic_src, "launch_us": attn_ms * 1e3, "algorithmic_bytes_per_launch": kv_bytes},
     }
-    if not args.no_cpu_baseline and args.model != "tiny":
+    if not args.no_cpu_baseline and args.model != "tiny" and world == 1:  # rank 0 at N = 1 only
         out["cpu_baseline"] = cpu_baseline_sample(cfg, bs, seq, L)
     print(json.dumps(out))
 
