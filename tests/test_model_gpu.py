@@ -100,3 +100,47 @@ def test_fused_and_graph_decode_are_bit_identical(pkg):
     assert torch.equal(outs["plain"], outs["fused_ops"])
     assert torch.equal(outs["plain"], outs["fused"])
     assert torch.equal(outs["plain"], outs["graph"])
+
+
+def test_shared_prefix_hit_path_matches_full_prefill(pkg):
+    """BASELINE config 3 in miniature (RadixAttention prefix sharing): request 0 is prefilled in full and inserted into
+    the native radix tree; the other requests match their shared prefix there and run extend attention over
+    (cached prefix slots from the tree) + (their own new tokens).  Their logits must agree with a from-scratch prefill of
+    the same prompts (same function, different tile order -> fp8-stack tolerance), and decode must continue from both."""
+    from ltp_sglang_amd.srt.mem_cache.radix_cache import RadixCache
+    from ltp_sglang_amd.srt.model_executor.synthetic_llama import LlamaShape, SyntheticModelRunner
+
+    cfg = LlamaShape(hidden_size=1024, num_attention_heads=8, num_key_value_heads=2, head_dim=128, num_hidden_layers=2,
+                     intermediate_size=3584, vocab_size=4096, max_position_embeddings=1024)
+    g = torch.Generator().manual_seed(3)
+    prefix = torch.randint(0, cfg.vocab_size, (200,), generator=g)
+    prompts = [torch.cat([prefix, torch.randint(0, cfg.vocab_size, (n,), generator=g)]) for n in (40, 17, 64, 1, 33)]
+
+    def new_runner():
+        return SyntheticModelRunner(cfg, "w8a8_fp8", max_running_requests=8, context_len=512, max_total_tokens=4096, device=DEV, seed=9)
+
+    # reference: everything from scratch in one batch
+    ref_runner = new_runner()
+    ref_logits, _ = ref_runner.extend([p.to(DEV) for p in prompts])
+
+    runner = new_runner()
+    cache = RadixCache(runner.req_to_token_pool, runner.token_to_kv_pool_allocator, page_size=1)
+    l0, st0 = runner.extend([prompts[0].to(DEV)])
+    slots0 = runner.req_to_token_pool.req_to_token[st0.req_pool_indices[0], : prompts[0].numel()].to(torch.int64)
+    assert cache.insert(prompts[0].tolist(), slots0) == 0          # nothing was cached before
+    hits = [cache.match_prefix(p.tolist()) for p in prompts[1:]]
+    pre = [h.device_indices for h in hits]
+    assert all(int(x.numel()) == prefix.numel() for x in pre)       # exactly the shared prefix is found
+    assert all(torch.equal(x.cpu(), slots0[: prefix.numel()].cpu()) for x in pre)
+    l_hit, st_hit = runner.extend([p[prefix.numel():].to(DEV) for p in prompts[1:]], prefix_indices=[x.to(DEV) for x in pre])
+    got = torch.cat([l0, l_hit]).float().cpu()
+    err = (got - ref_logits.float().cpu()).abs()
+    assert err.max().item() <= 1e-1 and err.mean().item() <= 1e-2, (err.max().item(), err.mean().item())
+    # the shared slots are really shared: req_to_token rows of the hit requests start with request 0's slots
+    r2t = runner.req_to_token_pool.req_to_token
+    for i in range(len(prompts) - 1):
+        assert torch.equal(r2t[st_hit.req_pool_indices[i], : prefix.numel()].cpu(), slots0[: prefix.numel()].to(torch.int32).cpu())
+    # decode continues over shared prefix + private suffix
+    nxt = torch.argmax(l_hit.float(), dim=-1)
+    d1 = runner.decode(st_hit, nxt)
+    assert torch.isfinite(d1.float()).all()
