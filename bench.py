@@ -37,6 +37,7 @@ def parse_args():
     ap.add_argument("--model", default="llama3-8b", choices=["llama3-8b", "llama3-70b", "qwen2-7b", "tiny"])
     ap.add_argument("--quant", default="w8a8_fp8", choices=["w8a8_fp8", "fp8", "awq", "none"])
     ap.add_argument("--layers", type=int, default=0, help="override layer count (debug only; invalidates the metric)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"], help="activation / KV dtype (AWQ checkpoints usually run f16)")
     ap.add_argument("--kv-cache-dtype", default="auto", choices=["auto", "fp8_e4m3"],
                     help="auto = the model dtype (the BASELINE configuration); fp8_e4m3 halves the KV stream (reported separately)")
     ap.add_argument("--decode-attn-mode", type=int, default=-1, help="measurement hook: 0 / 1 = sgl_mi355_decode_attention_set_mode")
@@ -132,6 +133,7 @@ def main():
     total_steps = args.steps + args.warmup + 4
     runner = SyntheticModelRunner(cfg, quant, max_running_requests=bs, context_len=seq + total_steps + 8,
                                   max_total_tokens=bs * (seq + total_steps) + 64, device=dev, seed=0,
+                                  dtype=torch.float16 if args.dtype == "f16" else torch.bfloat16,
                                   kv_cache_dtype=torch.float8_e4m3fn if args.kv_cache_dtype == "fp8_e4m3" else None)
     kv_es = 1 if args.kv_cache_dtype == "fp8_e4m3" else 2
     tp = comm.get_tensor_model_parallel_world_size()
@@ -249,7 +251,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"{args.model} {args.quant} decode, batch {bs} x context {seq} (+{args.warmup}+{args.steps} steps), "
                                f"KV pool filled by a real {bs}x{seq} prefill", "global_batch": bs, "seq_len": seq,
-                   "parallelism": f"tp{tp}", "hip_graph": bool(use_graph), "layers": L, "kv_cache_dtype": args.kv_cache_dtype},
+                   "parallelism": f"tp{tp}", "hip_graph": bool(use_graph), "layers": L, "kv_cache_dtype": args.kv_cache_dtype,
+                   "act_dtype": args.dtype},
         "prefill": {"tflops": prefill_flops / prefill_s / 1e12, "seconds": prefill_s, "tokens": bs * seq,
                     "tokens_per_s": bs * seq / prefill_s, "flops": prefill_flops},
         "step_roofline": {"algorithmic_bytes_per_step": step_bytes, "hbm_peak_GBps": 8000.0,
