@@ -165,12 +165,14 @@ int sgl_mi355_fp8_gemm_force_tile(int mode);
  * fp8_scaled_mm, sgl-kernel/csrc/gemm/fp8_gemm_kernel.cu:1071-1146 (CUTLASS tile dispatch :303-440,739-796). */
 int sgl_mi355_fp8_gemm(const void* x, int64_t x_stride_elems, const void* w, int64_t w_stride_elems, void* y,
                        int64_t y_stride_elems, const float* scales_x, const float* scales_w, const void* bias, int M,
-                       int N, int K, int out_dtype, void* stream);
+                       int N, int K, int out_dtype, float* workspace, int64_t workspace_floats, void* stream);
+/* (workspace: optional f32 scratch for split-K when a launch has fewer 128x128 output tiles than half the CUs -- decode at
+ * 64 < M <= 256, the continuous-batching regime, where the weights are streamed once; NULL disables it) */
 /* Unquantised bf16/f16 linear for M > 64 (UnquantizedLinearMethod.apply, layers/quantization/unquant.py);
  * also the matmul half of AWQLinearMethod.apply (layers/quantization/awq.py:401-418). */
 int sgl_mi355_dense_gemm(const void* x, int64_t x_stride_elems, const void* w, int64_t w_stride_elems, void* y,
                          int64_t y_stride_elems, const void* bias, int M, int N, int K, int in_dtype, int out_dtype,
-                         void* stream);
+                         float* workspace, int64_t workspace_floats, void* stream);
 /* awq_dequantize, sgl-kernel/csrc/gemm/awq_kernel.cu:127-221 (python gemm.py:7-10); HIP reference path
  * awq_dequantize_triton, layers/quantization/awq_triton.py:14-108.  out [K, 8*num_packed_cols] in the scale dtype. */
 int sgl_mi355_awq_dequantize(const void* qweight, const void* scales, const void* qzeros, void* out, int K,

@@ -25,6 +25,8 @@ struct GemmParams {
   int M, N, kbytes;
   int tiles_m, tiles_n;
   int group_m;  // row tiles per scheduling group (256x256 kernel)
+  float* slabs;  // split-K (128x128 kernel, blockIdx.y = K range of `kt_per` slices): raw f32 sums [splits][M][N], else NULL
+  int kt_per;
 #ifdef SGL_GEMM_TIMELINE
   long long* tl;  // tools/microbench/gemm256_timeline.hip: s_memtime stamps of workgroup 0, slices 8..11
 #endif
@@ -115,11 +117,13 @@ __global__ __launch_bounds__(256, 2) void tiled_gemm_kernel(const GemmParams p) 
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = (p.kbytes + BKB - 1) / BKB;
-  gload(0);
-  lstore(0);
+  const int nk_all = (p.kbytes + BKB - 1) / BKB;
+  const int kt0 = p.slabs ? (int)blockIdx.y * p.kt_per : 0;            // split-K: this workgroup's slice range
+  const int nk = p.slabs ? min(nk_all, kt0 + p.kt_per) : nk_all;
+  gload(kt0);
+  lstore(kt0 & 1);
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
+  for (int kt = kt0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) gload(kt + 1);
     const char* xa = smem + buf * 2 * TILE_BYTES;
@@ -157,6 +161,22 @@ __global__ __launch_bounds__(256, 2) void tiled_gemm_kernel(const GemmParams p) 
   }
 
   // ---- epilogue: acc[i][j][r] -> row m0+wm+16i+4g+r, col n0+wn+16j+a ----
+  if (p.slabs) {  // split-K: raw partial sums; scales / bias / rounding happen in the reduce kernel
+    float* sl = p.slabs + (int64_t)blockIdx.y * p.M * p.N;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn + 16 * j + a;
+      if (n >= p.N) continue;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = m0 + wm + 16 * i + 4 * g + r;
+          if (m < p.M) sl[(int64_t)m * p.N + n] = acc[i][j][r];
+        }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int n = n0 + wn + 16 * j + a;
@@ -417,8 +437,30 @@ int launch256(GemmParams& p, hipStream_t st) {
   return SGL_MI355_OK;
 }
 
+// y[m][n] = OutT((sum_s slabs[s][m][n]) * sx[m] * sw[n] + bias[n]): the same arithmetic as the fused epilogue
+template <typename OutT>
+__global__ __launch_bounds__(256) void tiled_splitk_reduce_kernel(const float* __restrict__ slabs, int S, const float* sx,
+                                                                  const float* sw, const OutT* bias, OutT* y, int64_t y_stride,
+                                                                  int M, int N) {
+  const int64_t total = (int64_t)M * (N / 4);
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int m = (int)(idx / (N / 4)), n = (int)(idx - (int64_t)m * (N / 4)) * 4;
+    f32x4_t v = *(const f32x4_t*)(slabs + (int64_t)m * N + n);
+    for (int sI = 1; sI < S; ++sI) v += *(const f32x4_t*)(slabs + ((int64_t)sI * M + m) * N + n);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float r = v[c];
+      if (sx) r *= sx[m];
+      r = r * (sw ? sw[n + c] : 1.0f) + (bias ? (float)bias[n + c] : 0.0f);
+      y[(int64_t)m * y_stride + n + c] = (OutT)r;
+    }
+  }
+}
+
+int tg_cus();
+
 template <int ES, typename OutT>
-int launch(GemmParams& p, hipStream_t st) {
+int launch(GemmParams& p, hipStream_t st, float* workspace = nullptr, int64_t workspace_floats = 0) {
   constexpr int smem = 2 * 2 * TILE_BYTES;  // 64 KiB
   static bool attr_set = false;
   if (!attr_set) {
@@ -427,13 +469,39 @@ int launch(GemmParams& p, hipStream_t st) {
   }
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
-  hipLaunchKernelGGL((tiled_gemm_kernel<ES, OutT>), dim3(p.tiles_m * p.tiles_n), dim3(256), smem, st, p);
+  // Few output tiles (decode at 64 < M <= 256, the continuous-batching regime: the weights are streamed once and a tile per
+  // CU is all there is): split K over blockIdx.y so every CU streams a share of W; raw sums meet in f32 slabs.
+  const int tiles = p.tiles_m * p.tiles_n, nk = (p.kbytes + BKB - 1) / BKB, cus = tg_cus();
+  int splits = 1;
+  if (workspace != nullptr && tiles * 2 <= cus && p.N % 4 == 0) {
+    splits = cus / tiles;
+    if (splits > 8) splits = 8;
+    if (splits > nk / 4) splits = nk / 4;  // at least 4 slices (512 B of K) per workgroup
+    while (splits > 1 && (int64_t)splits * p.M * p.N > workspace_floats) --splits;
+  }
+  if (splits > 1) {
+    p.kt_per = (nk + splits - 1) / splits;
+    splits = (nk + p.kt_per - 1) / p.kt_per;
+    p.slabs = workspace;
+    hipLaunchKernelGGL((tiled_gemm_kernel<ES, OutT>), dim3(tiles, splits), dim3(256), smem, st, p);
+    SGL_HIP_LAUNCH_CHECK();
+    const int64_t items = (int64_t)p.M * (p.N / 4);
+    const unsigned blocks = (unsigned)((items + 255) / 256 > 4096 ? 4096 : (items + 255) / 256);
+    hipLaunchKernelGGL((tiled_splitk_reduce_kernel<OutT>), dim3(blocks), dim3(256), 0, st, workspace, splits, p.sx, p.sw,
+                       (const OutT*)p.bias, (OutT*)p.y, p.y_stride, p.M, p.N);
+    SGL_HIP_LAUNCH_CHECK();
+    return SGL_MI355_OK;
+  }
+  p.slabs = nullptr;
+  p.kt_per = 0;
+  hipLaunchKernelGGL((tiled_gemm_kernel<ES, OutT>), dim3(tiles), dim3(256), smem, st, p);
   SGL_HIP_LAUNCH_CHECK();
   return SGL_MI355_OK;
 }
 
 int run(const void* x, int64_t xs, const void* w, int64_t ws, void* y, int64_t ys, const float* sx, const float* sw,
-        const void* bias, int M, int N, int K, int in_dtype, int out_dtype, void* stream, const char* who) {
+        const void* bias, int M, int N, int K, int in_dtype, int out_dtype, void* stream, const char* who,
+        float* workspace = nullptr, int64_t workspace_floats = 0) {
   SGL_CHECK(M >= 0 && N >= 0 && K >= 0, "%s: negative shape", who);
   if (M == 0 || N == 0) return SGL_MI355_OK;
   SGL_CHECK(x && w && y, "%s: null pointer", who);
@@ -459,10 +527,14 @@ int run(const void* x, int64_t xs, const void* w, int64_t ws, void* y, int64_t y
     if (can256 && g_tiled_force == 3) return out_dtype == SGL_BF16 ? launch256<__bf16, 4>(p, st) : launch256<_Float16, 4>(p, st);
     if (can256 && g_tiled_force != 1 && (g_tiled_force == 2 || tiles256 >= tg_cus()))
       return out_dtype == SGL_BF16 ? launch256<__bf16, 8>(p, st) : launch256<_Float16, 8>(p, st);
-    return out_dtype == SGL_BF16 ? launch<TG_FP8, __bf16>(p, st) : launch<TG_FP8, _Float16>(p, st);
+    return out_dtype == SGL_BF16 ? launch<TG_FP8, __bf16>(p, st, workspace, workspace_floats)
+                                 : launch<TG_FP8, _Float16>(p, st, workspace, workspace_floats);
   }
-  if (in_dtype == SGL_BF16) return out_dtype == SGL_BF16 ? launch<TG_BF16, __bf16>(p, st) : launch<TG_BF16, _Float16>(p, st);
-  return out_dtype == SGL_BF16 ? launch<TG_F16, __bf16>(p, st) : launch<TG_F16, _Float16>(p, st);
+  if (in_dtype == SGL_BF16)
+    return out_dtype == SGL_BF16 ? launch<TG_BF16, __bf16>(p, st, workspace, workspace_floats)
+                                 : launch<TG_BF16, _Float16>(p, st, workspace, workspace_floats);
+  return out_dtype == SGL_BF16 ? launch<TG_F16, __bf16>(p, st, workspace, workspace_floats)
+                               : launch<TG_F16, _Float16>(p, st, workspace, workspace_floats);
 }
 
 }  // namespace
@@ -478,18 +550,19 @@ extern "C" int sgl_mi355_fp8_gemm_force_tile(int mode) {
 
 extern "C" int sgl_mi355_fp8_gemm(const void* x, int64_t x_stride_elems, const void* w, int64_t w_stride_elems, void* y,
                                   int64_t y_stride_elems, const float* scales_x, const float* scales_w, const void* bias,
-                                  int M, int N, int K, int out_dtype, void* stream) {
+                                  int M, int N, int K, int out_dtype, float* workspace, int64_t workspace_floats,
+                                  void* stream) {
   return run(x, x_stride_elems, w, w_stride_elems, y, y_stride_elems, scales_x, scales_w, bias, M, N, K, SGL_FP8_E4M3,
-             out_dtype, stream, "fp8_gemm");
+             out_dtype, stream, "fp8_gemm", workspace, workspace_floats);
 }
 
 extern "C" int sgl_mi355_dense_gemm(const void* x, int64_t x_stride_elems, const void* w, int64_t w_stride_elems, void* y,
                                     int64_t y_stride_elems, const void* bias, int M, int N, int K, int in_dtype,
-                                    int out_dtype, void* stream) {
+                                    int out_dtype, float* workspace, int64_t workspace_floats, void* stream) {
   if (!(in_dtype == SGL_BF16 || in_dtype == SGL_F16)) {
     snprintf(g_sgl_mi355_err, sizeof(g_sgl_mi355_err), "dense_gemm: in_dtype must be bf16 or f16");
     return SGL_MI355_EINVAL;
   }
   return run(x, x_stride_elems, w, w_stride_elems, y, y_stride_elems, nullptr, nullptr, bias, M, N, K, in_dtype, out_dtype,
-             stream, "dense_gemm");
+             stream, "dense_gemm", workspace, workspace_floats);
 }

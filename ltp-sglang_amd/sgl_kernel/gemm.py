@@ -23,6 +23,15 @@ def _splitk_workspace(m, n, k, dtype, device):
     return buf, buf.numel()
 
 
+def _tiled_workspace(device):
+    """Cached f32 scratch for the tiled GEMM's split-K (few-tile launches: decode at 64 < M <= 256)."""
+    buf = _WORKSPACES.get(device)
+    if buf is None or buf.numel() < (1 << 24):
+        buf = torch.empty(1 << 24, dtype=torch.float32, device=device)
+        _WORKSPACES[device] = buf
+    return buf, buf.numel()
+
+
 def _cuda(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
@@ -149,8 +158,9 @@ def fp8_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype, bias=None):
                                         ptr(scales_a), ptr(scales_b), ptr(bias), m, n, k, dtype_code(mat_a.dtype),
                                         dtype_code(out_dtype), ptr(ws), ws_n, current_stream()))
     else:
+        ws, ws_n = _tiled_workspace(mat_a.device)
         check(lib.sgl_mi355_fp8_gemm(ptr(mat_a), mat_a.stride(0), ptr(mat_b), w_stride, ptr(out), out.stride(0),
-                                     ptr(scales_a), ptr(scales_b), ptr(bias), m, n, k, dtype_code(out_dtype),
+                                     ptr(scales_a), ptr(scales_b), ptr(bias), m, n, k, dtype_code(out_dtype), ptr(ws), ws_n,
                                      current_stream()))
     return out
 
@@ -184,8 +194,10 @@ def dense_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
                                         None, ptr(bias), m, n, k, dtype_code(x.dtype), dtype_code(out_dtype), ptr(ws), ws_n,
                                         current_stream()))
     else:
+        ws, ws_n = _tiled_workspace(x.device)
         check(lib.sgl_mi355_dense_gemm(ptr(x), x.stride(0), ptr(weight), weight.stride(0), ptr(out), out.stride(0),
-                                       ptr(bias), m, n, k, dtype_code(x.dtype), dtype_code(out_dtype), current_stream()))
+                                       ptr(bias), m, n, k, dtype_code(x.dtype), dtype_code(out_dtype), ptr(ws), ws_n,
+                                       current_stream()))
     return out
 
 

@@ -343,7 +343,8 @@ def test_awq_linear_method_fused_matches_unfused(sk, pkg):
 # ---------------------------------------------------------------- tiled GEMM at prefill-sized M
 @pytest.mark.parametrize("tile_mode", [1, 2, 3, 4])
 @pytest.mark.parametrize("m,n,k,out", [(256, 384, 4096, "bf16"), (1000, 136, 1024, "bf16"), (129, 6144, 512, "f16"),
-                                       (515, 776, 1152, "bf16"), (768, 136, 256, "f16")])
+                                       (515, 776, 1152, "bf16"), (768, 136, 256, "f16"),
+                                       (128, 1024, 8192, "bf16"), (200, 520, 4096, "f16")])  # few tiles: the split-K path
 def test_fp8_scaled_mm_large_m_vs_oracle(m, n, k, out, tile_mode, sk):
     # tile_mode 1: 128x128 tiles; 2 / 3: the 256x256 LDS-DMA kernel with 8 / 4 waves, 4: its register-staged form (ragged M / N edges, odd K-slice counts)
     from ltp_sglang_amd import _cabi
@@ -377,10 +378,11 @@ def test_fp8_gemm_tile_kernels_agree(sk):
     assert all(torch.equal(o, ref) for o in outs)
 
 
+@pytest.mark.parametrize("shape", [(300, 200, 1032), (130, 256, 4096)])   # the second: few tiles -> split-K
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_dense_gemm_large_m(dtype, sk):
+def test_dense_gemm_large_m(dtype, shape, sk):
     g = torch.Generator().manual_seed(9)
-    m, n, k = 300, 200, 1032
+    m, n, k = shape
     x = torch.randn(m, k, generator=g).to(dtype)
     w = (torch.randn(n, k, generator=g) * 0.05).to(dtype)
     o = sk.dense_linear(x.to(DEV), w.to(DEV))
