@@ -152,7 +152,7 @@ int sgl_mi355_skinny_gemm(const void* x, int64_t x_stride_elems, const void* w, 
                           void* stream);
 int sgl_mi355_skinny_gemm_num_kranges(int M, int N, int K, int in_dtype);
 /* Producer half of the launch-boundary split-K reduce: raw f32 partial sums [kranges, M, N], scales left to the consumer
- * (sgl_mi355_fused_add_rmsnorm_quant_fp8 with slabs != NULL). fp8, M <= 32. */
+ * (sgl_mi355_fused_add_rmsnorm_quant_fp8 with slabs != NULL). fp8, M <= 64. */
 int sgl_mi355_skinny_gemm_slabs(const void* x, int64_t x_stride_elems, const void* w, int64_t w_stride_elems, float* slabs,
                                 int M, int N, int K, int in_dtype, void* stream);
 

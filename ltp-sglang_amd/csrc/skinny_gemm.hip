@@ -264,16 +264,21 @@ __global__ __launch_bounds__(NWV * 64, 1) void skinny_gemm_v2_kernel(const Skinn
   const unsigned wbytes = (unsigned)min((int64_t)p.N * p.w_stride, (int64_t)0xFFFFFFF0ll);
   const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, wbytes, 0x00020000);
   // ---- X rows of this wave's K slice first (L2 hits, back within a microsecond), THEN the first W tiles (HBM): the
-  // counted wait below covers only the X loads, so the fragments are built while the weights are still in flight ----
-  u32x4_t xr[MT][DS];
+  // counted wait below covers only the X loads, so the fragments are built while the weights are still in flight.
+  // At most two 16-row tiles of X are staged per round trip (register budget at MT = 4). ----
+  constexpr int XG = MT >= 2 ? 2 : 1;
+  u32x4_t xr[XG][DS];
+  auto load_x = [&](int mt0) {
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
+    for (int q = 0; q < XG; ++q)
 #pragma unroll
-    for (int i = 0; i < DS; ++i) {
-      const int m = mt * 16 + lr + RPI * i;
-      const u32x4_t v = *(const u32x4_t*)(p.x + (int64_t)min(m, p.M - 1) * p.x_stride + (kok ? koff : 0));
-      xr[mt][i] = (m < p.M && kok) ? v : zero4;
-    }
+      for (int i = 0; i < DS; ++i) {
+        const int m = (mt0 + q) * 16 + lr + RPI * i;
+        const u32x4_t v = *(const u32x4_t*)(p.x + (int64_t)min(m, p.M - 1) * p.x_stride + (kok ? koff : 0));
+        xr[q][i] = (m < p.M && kok) ? v : zero4;
+      }
+  };
+  load_x(0);
   u32x4_t wreg[PD][DS];
   auto issue = [&](int slot, int j) {
     const int n0t = (blockIdx.x + j * G) * rpt;
@@ -290,14 +295,19 @@ __global__ __launch_bounds__(NWV * 64, 1) void skinny_gemm_v2_kernel(const Skinn
   // coalesced rows -> swizzled image -> A-fragment registers, once per workgroup
   u32x4_t xf[MT][DS];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
+  for (int mt0 = 0; mt0 < MT; mt0 += XG) {
+    if (mt0 > 0) load_x(mt0);
 #pragma unroll
-    for (int i = 0; i < DS; ++i) {
-      const int row = lr + RPI * i;
-      *(u32x4_t*)(wl + row * kw + (((lc ^ row) & (LPR - 1)) << 4)) = xr[mt][i];
+    for (int q = 0; q < XG; ++q) {
+#pragma unroll
+      for (int i = 0; i < DS; ++i) {
+        const int row = lr + RPI * i;
+        *(u32x4_t*)(wl + row * kw + (((lc ^ row) & (LPR - 1)) << 4)) = xr[q][i];
+      }
+#pragma unroll
+      for (int sI = 0; sI < DS; ++sI)
+        xf[mt0 + q][sI] = *(const u32x4_t*)(wl + a * kw + ((((4 * sI + g) ^ a) & (LPR - 1)) << 4));
     }
-#pragma unroll
-    for (int sI = 0; sI < DS; ++sI) xf[mt][sI] = *(const u32x4_t*)(wl + a * kw + ((((4 * sI + g) ^ a) & (LPR - 1)) << 4));
   }
   const int arow = (rpt == 16) ? a : (a & 7);
 
@@ -429,12 +439,12 @@ inline int v2_cus() {
 // number of k-ranges the v2 kernel needs for this problem, 0 if it cannot take it
 template <int ES>
 inline int v2_kranges(const SkinnyParams& p, int* ds_out) {
-  if (p.M > 32 || g_skinny_force_v1 || (int64_t)p.N * p.w_stride >= 0xFFFFFFF0ll) return 0;
+  if (p.M > 64 || g_skinny_force_v1 || (int64_t)p.N * p.w_stride >= 0xFFFFFFF0ll) return 0;
   if ((ES == ES_FP8) != (p.sx != nullptr) || (!p.sx != !p.sw)) return 0;
   int ds;
   if (p.kbytes <= 1024) ds = 2;
   else if (p.kbytes <= 2048) ds = 4;
-  else ds = (p.kbytes <= 4096) ? 8 : 16;
+  else ds = (p.kbytes <= 4096 || p.M > 32) ? 8 : 16;  // (MT = 4 keeps 128 VGPRs of X fragments: 512 B of K per wave at most)
   if (p.kbytes % 64 != 0) return 0;
   *ds_out = ds;
   const int range = kV2Waves * ds * 64;
@@ -454,7 +464,7 @@ int launch_v2(const SkinnyParams& p, int kranges, float* slabs, hipStream_t st) 
   const int gx = ntiles < per_range_wgs ? ntiles : per_range_wgs;
   const dim3 grid(gx, kranges);
   constexpr int PD = 1;
-  constexpr int TPP = DS >= 16 ? 2 : 4;
+  constexpr int TPP = (DS >= 16 || MT >= 4) ? 2 : 4;  // (LDS: the cross-wave reduce buffer grows with MT)
   if (ntiles <= gx)
     hipLaunchKernelGGL((skinny_gemm_v2_kernel<ES, MT, DS, 1, 1, OutT>), grid, dim3(kV2Waves * 64), 0, st, p, rpt, ntiles, slabs);
   else
@@ -466,7 +476,9 @@ int launch_v2(const SkinnyParams& p, int kranges, float* slabs, hipStream_t st) 
 template <int ES, int MT, typename OutT>
 int launch_v2_ds(const SkinnyParams& p, int ds, int kranges, float* slabs, hipStream_t st) {
   switch (ds) {
-    case 16: return launch_v2<ES, MT, 16, OutT>(p, kranges, slabs, st);
+    case 16:
+      if constexpr (MT < 4) return launch_v2<ES, MT, 16, OutT>(p, kranges, slabs, st);  // (never chosen for M > 32)
+      return SGL_MI355_EINVAL;
     case 8: return launch_v2<ES, MT, 8, OutT>(p, kranges, slabs, st);
     case 4: return launch_v2<ES, MT, 4, OutT>(p, kranges, slabs, st);
     default: return launch_v2<ES, MT, 2, OutT>(p, kranges, slabs, st);
@@ -477,10 +489,14 @@ template <int ES, typename OutT>
 int launch_mt(const SkinnyParams& p, float* workspace, int64_t workspace_floats, hipStream_t st) {
   int ds = 0;
   const int kranges = (sizeof(OutT) == 2) ? v2_kranges<ES>(p, &ds) : 0;
-  if (kranges == 1) return p.M <= 16 ? launch_v2_ds<ES, 1, OutT>(p, ds, 1, nullptr, st) : launch_v2_ds<ES, 2, OutT>(p, ds, 1, nullptr, st);
+  auto by_m = [&](int kr, float* slabs) {
+    if (p.M <= 16) return launch_v2_ds<ES, 1, OutT>(p, ds, kr, slabs, st);
+    if (p.M <= 32) return launch_v2_ds<ES, 2, OutT>(p, ds, kr, slabs, st);
+    return launch_v2_ds<ES, 4, OutT>(p, ds, kr, slabs, st);
+  };
+  if (kranges == 1) return by_m(1, nullptr);
   if (kranges > 1 && workspace != nullptr && workspace_floats >= (int64_t)kranges * p.M * p.N && p.N % 4 == 0) {
-    const int rc = p.M <= 16 ? launch_v2_ds<ES, 1, OutT>(p, ds, kranges, workspace, st)
-                             : launch_v2_ds<ES, 2, OutT>(p, ds, kranges, workspace, st);
+    const int rc = by_m(kranges, workspace);
     if (rc != SGL_MI355_OK) return rc;
     const int64_t items = (int64_t)p.M * (p.N / 4);
     const unsigned blocks = (unsigned)((items + 255) / 256 > 2048 ? 2048 : (items + 255) / 256);
@@ -504,10 +520,11 @@ extern "C" int sgl_mi355_skinny_gemm_force_generic(int on) {
 // in_dtype: SGL_FP8_E4M3 / SGL_BF16 / SGL_F16 (X and W share it); out_dtype: SGL_BF16 / SGL_F16.
 extern "C" int sgl_mi355_skinny_gemm_num_kranges(int M, int N, int K, int in_dtype) {
   // how many f32 [M, N] slabs of workspace sgl_mi355_skinny_gemm wants for this shape (0 or 1: none needed)
-  if (M > 32 || g_skinny_force_v1) return 0;
+  if (M > 64 || g_skinny_force_v1) return 0;
   const int kbytes = K * (in_dtype == SGL_FP8_E4M3 ? 1 : 2);
   if (kbytes % 64 != 0 || kbytes <= 4096) return kbytes % 64 == 0 ? 1 : 0;
-  return (kbytes + 8191) / 8192;
+  const int range = M > 32 ? 4096 : 8192;  // K bytes one workgroup covers
+  return (kbytes + range - 1) / range;
 }
 
 extern "C" int sgl_mi355_skinny_gemm(const void* x, int64_t x_stride_elems, const void* w, int64_t w_stride_elems, void* y,
@@ -545,7 +562,7 @@ extern "C" int sgl_mi355_skinny_gemm(const void* x, int64_t x_stride_elems, cons
 // the consumer kernel (sgl_mi355_fused_add_rmsnorm_quant_fp8 with slabs) combines them at its own launch boundary.
 extern "C" int sgl_mi355_skinny_gemm_slabs(const void* x, int64_t x_stride_elems, const void* w, int64_t w_stride_elems,
                                            float* slabs, int M, int N, int K, int in_dtype, void* stream) {
-  SGL_CHECK(M > 0 && M <= 32 && N > 0 && K > 0, "skinny_gemm_slabs: needs 0 < M <= 32");
+  SGL_CHECK(M > 0 && M <= 64 && N > 0 && K > 0, "skinny_gemm_slabs: needs 0 < M <= 64");
   SGL_CHECK(x && w && slabs, "skinny_gemm_slabs: null pointer");
   SGL_CHECK(in_dtype == SGL_FP8_E4M3, "skinny_gemm_slabs: fp8 only");
   SGL_CHECK(K % 64 == 0 && x_stride_elems % 16 == 0 && w_stride_elems % 16 == 0 && ((uintptr_t)x % 16) == 0 &&
@@ -557,11 +574,13 @@ extern "C" int sgl_mi355_skinny_gemm_slabs(const void* x, int64_t x_stride_elems
   p.y = nullptr; p.y_stride = 0;
   p.sx = nullptr; p.sw = nullptr; p.bias = nullptr;  // slab mode never reads scales or bias
   p.M = M; p.N = N; p.K = K; p.kbytes = K;
-  const int ds = K <= 1024 ? 2 : (K <= 2048 ? 4 : (K <= 4096 ? 8 : 16));
+  const int ds = K <= 1024 ? 2 : (K <= 2048 ? 4 : ((K <= 4096 || M > 32) ? 8 : 16));
   const int range = kV2Waves * ds * 64;
   const int kranges = (K + range - 1) / range;
   hipStream_t st = (hipStream_t)stream;
-  return M <= 16 ? launch_v2_ds<ES_FP8, 1, __bf16>(p, ds, kranges, slabs, st) : launch_v2_ds<ES_FP8, 2, __bf16>(p, ds, kranges, slabs, st);
+  if (M <= 16) return launch_v2_ds<ES_FP8, 1, __bf16>(p, ds, kranges, slabs, st);
+  if (M <= 32) return launch_v2_ds<ES_FP8, 2, __bf16>(p, ds, kranges, slabs, st);
+  return launch_v2_ds<ES_FP8, 4, __bf16>(p, ds, kranges, slabs, st);
 }
 
 namespace {
@@ -574,15 +593,15 @@ int launch_v2_epi(const SkinnyParams& p, const EpiParams& ep, hipStream_t st) {
     hipLaunchKernelGGL((skinny_gemm_v2_kernel<ES_FP8, MT, DS, 1, 1, OutT, EPI>), dim3(gx, 1), dim3(kV2Waves * 64), 0, st, p, 16,
                        ntiles, (float*)nullptr, ep);
   else
-    hipLaunchKernelGGL((skinny_gemm_v2_kernel<ES_FP8, MT, DS, 1, 4, OutT, EPI>), dim3(gx, 1), dim3(kV2Waves * 64), 0, st, p, 16,
-                       ntiles, (float*)nullptr, ep);
+    hipLaunchKernelGGL((skinny_gemm_v2_kernel<ES_FP8, MT, DS, 1, (MT >= 4 ? 2 : 4), OutT, EPI>), dim3(gx, 1), dim3(kV2Waves * 64), 0, st,
+                       p, 16, ntiles, (float*)nullptr, ep);
   SGL_HIP_LAUNCH_CHECK();
   return SGL_MI355_OK;
 }
 
 template <int EPI>
 int run_epi(SkinnyParams& p, const EpiParams& ep, int out_dtype, hipStream_t st, const char* who) {
-  SGL_CHECK(p.M > 0 && p.M <= 32, "%s: needs 0 < M <= 32 (got %d)", who, p.M);
+  SGL_CHECK(p.M > 0 && p.M <= 64, "%s: needs 0 < M <= 64 (got %d)", who, p.M);
   SGL_CHECK(p.kbytes % 64 == 0 && p.kbytes <= 4096, "%s: K=%d must be a multiple of 64 and <= 4096 (single k-range)", who, p.kbytes);
   SGL_CHECK(p.N % 16 == 0 && (int64_t)p.N * p.w_stride < 0xFFFFFFF0ll, "%s: N=%d must be a multiple of 16", who, p.N);
   SGL_CHECK(out_dtype == SGL_BF16 || out_dtype == SGL_F16, "%s: out_dtype must be bf16 or f16", who);
@@ -594,9 +613,14 @@ int run_epi(SkinnyParams& p, const EpiParams& ep, int out_dtype, hipStream_t st,
     if (ds == 4) { SGL_EPI_CASE(1, 4); }
     SGL_EPI_CASE(1, 2);
   }
-  if (ds == 8) { SGL_EPI_CASE(2, 8); }
-  if (ds == 4) { SGL_EPI_CASE(2, 4); }
-  SGL_EPI_CASE(2, 2);
+  if (p.M <= 32) {
+    if (ds == 8) { SGL_EPI_CASE(2, 8); }
+    if (ds == 4) { SGL_EPI_CASE(2, 4); }
+    SGL_EPI_CASE(2, 2);
+  }
+  if (ds == 8) { SGL_EPI_CASE(4, 8); }
+  if (ds == 4) { SGL_EPI_CASE(4, 4); }
+  SGL_EPI_CASE(4, 2);
 #undef SGL_EPI_CASE
 }
 }  // namespace

@@ -187,7 +187,7 @@ class LlamaForCausalLM(nn.Module):
     def _fused_decode_ok(self, forward_batch) -> bool:
         return (self.fused_decode and forward_batch.forward_mode.is_decode()
                 and self.quant_config is not None and self.quant_config.get_name() == "w8a8_fp8"
-                and forward_batch.batch_size <= 32 and self.cfg.hidden_size <= 8192)
+                and forward_batch.batch_size <= 64 and self.cfg.hidden_size <= 8192)
 
     def _fused_weights(self, layer):
         """Row-interleaved copies of the qkv / gate_up weights for the fused GEMM epilogues (built once; K <= 4096,

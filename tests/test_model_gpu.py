@@ -102,6 +102,29 @@ def test_fused_and_graph_decode_are_bit_identical(pkg):
     assert torch.equal(outs["plain"], outs["graph"])
 
 
+def test_fused_decode_bit_identical_at_batch_40(pkg):
+    """32 < batch <= 64: the MT = 4 instantiations of the weight-streaming GEMM and its fused epilogues."""
+    from ltp_sglang_amd.srt.model_executor.synthetic_llama import LlamaShape, SyntheticModelRunner
+
+    cfg = LlamaShape(hidden_size=1024, num_attention_heads=8, num_key_value_heads=2, head_dim=128, num_hidden_layers=2,
+                     intermediate_size=3584, vocab_size=4096, max_position_embeddings=512)
+    outs = {}
+    for mode in ("plain", "fused"):
+        runner = SyntheticModelRunner(cfg, "w8a8_fp8", max_running_requests=48, context_len=128, max_total_tokens=4096, device=DEV, seed=5)
+        runner.model.fused_decode = runner.model.fused_extend = mode != "plain"
+        g = torch.Generator().manual_seed(2)
+        ids = [torch.randint(0, cfg.vocab_size, (int(n),), generator=g).to(DEV) for n in torch.randint(1, 40, (40,), generator=g)]
+        logits, state = runner.extend(ids)
+        seq = [logits.clone()]
+        nxt = torch.argmax(logits.float(), dim=-1)
+        for _ in range(2):
+            logits = runner.decode(state, nxt)
+            seq.append(logits.clone())
+            nxt = torch.argmax(logits.float(), dim=-1)
+        outs[mode] = torch.stack(seq)
+    assert torch.equal(outs["plain"], outs["fused"])
+
+
 def test_shared_prefix_hit_path_matches_full_prefill(pkg):
     """BASELINE config 3 in miniature (RadixAttention prefix sharing): request 0 is prefilled in full and inserted into
     the native radix tree; the other requests match their shared prefix there and run extend attention over

@@ -340,6 +340,18 @@ def test_awq_linear_method_fused_matches_unfused(sk, pkg):
     assert meth.apply(layer, big).shape == (80, n)
 
 
+@pytest.mark.parametrize("m,n,k,out,bias", [(33, 256, 4096, "bf16", True), (48, 6144, 4096, "bf16", False), (64, 4096, 14336, "bf16", True),
+                                            (64, 136, 1024, "f16", False), (40, 512, 3584, "f16", True)])
+def test_fp8_scaled_mm_m33_to_64_weight_streaming_kernel(m, n, k, out, bias, sk):
+    # 32 < M <= 64: the X-stationary kernel with four 16-row X tiles in registers (K > 4096: 4 KiB k-ranges through slabs)
+    case = dict(m=m, n=n, k=k, bias=bias, out=out)
+    c = _cases.build_gemm_case(case, seed=m + n)
+    b = c["bias"].to(DEV) if bias else None
+    o = sk.fp8_scaled_mm(c["a"].to(DEV), c["w"].to(DEV).t(), c["sa"].to(DEV), c["sb"].to(DEV), c["out_dtype"], b)
+    ref = oq.scaled_mm(c["a"], c["w"].t(), c["sa"], c["sb"], c["out_dtype"], c["bias"] if bias else None)
+    torch.testing.assert_close(o.cpu().float(), ref.float(), rtol=1.6e-2, atol=0.3)
+
+
 # ---------------------------------------------------------------- tiled GEMM at prefill-sized M
 @pytest.mark.parametrize("tile_mode", [1, 2, 3, 4])
 @pytest.mark.parametrize("m,n,k,out", [(256, 384, 4096, "bf16"), (1000, 136, 1024, "bf16"), (129, 6144, 512, "f16"),
