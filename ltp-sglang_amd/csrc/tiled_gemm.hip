@@ -473,8 +473,8 @@ int launch(GemmParams& p, hipStream_t st, float* workspace = nullptr, int64_t wo
   // CU is all there is): split K over blockIdx.y so every CU streams a share of W; raw sums meet in f32 slabs.
   const int tiles = p.tiles_m * p.tiles_n, nk = (p.kbytes + BKB - 1) / BKB, cus = tg_cus();
   int splits = 1;
-  if (workspace != nullptr && tiles * 2 <= cus && p.N % 4 == 0) {
-    splits = cus / tiles;
+  if (workspace != nullptr && tiles < cus && p.N % 4 == 0) {
+    splits = (2 * cus) / tiles;  // two resident workgroups per CU
     if (splits > 8) splits = 8;
     if (splits > nk / 4) splits = nk / 4;  // at least 4 slices (512 B of K) per workgroup
     while (splits > 1 && (int64_t)splits * p.M * p.N > workspace_floats) --splits;

@@ -187,7 +187,7 @@ class LlamaForCausalLM(nn.Module):
     def _fused_decode_ok(self, forward_batch) -> bool:
         return (self.fused_decode and forward_batch.forward_mode.is_decode()
                 and self.quant_config is not None and self.quant_config.get_name() == "w8a8_fp8"
-                and forward_batch.batch_size <= 64 and self.cfg.hidden_size <= 8192)
+                and self.cfg.hidden_size <= 8192)
 
     def _fused_weights(self, layer):
         """Row-interleaved copies of the qkv / gate_up weights for the fused GEMM epilogues (built once; K <= 4096,
@@ -241,7 +241,7 @@ class LlamaForCausalLM(nn.Module):
                 _, xq, xs = K.fused_add_rmsnorm_quant_fp8(None, residual, ln1.weight.data, ln1.variance_epsilon, slabs=slabs,
                                                           slab_sx=slab_sx, slab_sw=slab_sw, dtype=self.dtype)
             lid = attn.attn.layer_id
-            fw = self._fused_weights(layer)
+            fw = self._fused_weights(layer) if m <= 64 else None   # the GEMM epilogue fusions are weight-streaming (M <= 64) kernels
             kv8 = pool.dtype == torch.float8_e4m3fn   # fp8 KV cache: the pool write converts, so it is its own kernel
             if fw is not None and not kv8:   # qkv GEMM with the RoPE + KV-write epilogue
                 q = K.fp8_qkv_rope_set_kv(xq, xs.view(-1), fw["qkv_w"], fw["qkv_s"], fw["qkv_b"], positions,
@@ -272,7 +272,7 @@ class LlamaForCausalLM(nn.Module):
                 gate_up = K.fp8_scaled_mm(hq2, mlp.gate_up_proj.weight, hs2.view(-1), mlp.gate_up_proj.weight_scale.view(-1), self.dtype)
                 aq, asc = K.silu_and_mul_quant_fp8(gate_up)
             wd = mlp.down_proj.weight  # [K, N] column-major view of the [N, K] parameter
-            if tp == 1:
+            if tp == 1 and m <= 64:
                 slabs = K.fp8_linear_slabs(aq, wd.t(), m, wd.shape[1], wd.shape[0])
                 slab_sx, slab_sw = asc.view(-1), mlp.down_proj.weight_scale.view(-1)
             else:
