@@ -3,8 +3,8 @@
     rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d DIR -o pmc -- python3 bench.py ...
     python3 tools/pmc_mfma.py DIR > profiles/roundN_pmc_mfma.json
 
-SQ_VALU_MFMA_BUSY_CYCLES is summed over every SIMD of the device (MI355X: 256 CUs x 4); GRBM_GUI_ACTIVE is the dispatch's
-busy time in shader-engine clocks.  utilisation = MFMA_BUSY / (GUI_ACTIVE * 1024).  The file also carries the expected busy
+SQ_VALU_MFMA_BUSY_CYCLES is summed over every SIMD of the device (MI355X: 256 CUs x 4); GRBM_GUI_ACTIVE comes back summed over
+the 8 XCDs (checked: its value / 8 / the dispatch's wall time = 2.14 GHz).  utilisation = MFMA_BUSY / (GUI_ACTIVE / 8 * 1024).  The file also carries the expected busy
 cycles of the fp8 GEMM from its instruction count (one v_mfma_scale_f32_16x16x128 = 8 passes x 4 clocks on one SIMD) as a
 cross-check of the counter's unit."""
 import csv
@@ -30,7 +30,7 @@ def main():
                     continue
                 rows[key][r.get("Dispatch_Id")][r["Counter_Name"]] = float(r["Counter_Value"])
     out = {"source": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE (own pass) around bench.py --no-graph",
-           "normalisation": "utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 1024 SIMDs)", "kernels": {}}
+           "normalisation": "utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs)", "kernels": {}}
     for key, disp in sorted(rows.items()):
         busy = [v.get("SQ_VALU_MFMA_BUSY_CYCLES") for v in disp.values() if "SQ_VALU_MFMA_BUSY_CYCLES" in v and "GRBM_GUI_ACTIVE" in v]
         act = [v.get("GRBM_GUI_ACTIVE") for v in disp.values() if "SQ_VALU_MFMA_BUSY_CYCLES" in v and "GRBM_GUI_ACTIVE" in v]
@@ -38,7 +38,7 @@ def main():
             continue
         tb, ta = sum(busy), sum(act)
         out["kernels"][key] = {"dispatches": len(busy), "mfma_busy_cycles_per_dispatch": tb / len(busy),
-                               "gui_active_cycles_per_dispatch": ta / len(act), "mfma_utilisation": tb / (ta * 1024.0)}
+                               "gui_active_cycles_per_dispatch": ta / len(act), "mfma_utilisation": tb / (ta / 8.0 * 1024.0)}
     json.dump(out, sys.stdout, indent=1)
     print()
 
