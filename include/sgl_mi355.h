@@ -159,7 +159,8 @@ int sgl_mi355_skinny_gemm_slabs(const void* x, int64_t x_stride_elems, const voi
 /* Test hook: route every skinny GEMM through the generic (any-K) kernel instead of the X-stationary one. */
 int sgl_mi355_skinny_gemm_force_generic(int on);
 /* Test hook for sgl_mi355_fp8_gemm's tile choice: 0 = by shape, 1 = always 128x128 tiles, 2 = 256x256 tiles whenever K is
-  * a multiple of 128 (8 waves), 3 = the same tile with 4 waves of 128x128 outputs (accumulators in AGPRs). */
+  * a multiple of 128 (8 waves), 3 = the same tile with 4 waves of 128x128 outputs (accumulators in AGPRs), 4 = register-staged 256x256, 5 = the 4-stage
+  * streaming 128x128 tile (default for M <= 256); 100 + g = scheduling group height g of the 256x256 kernel. */
 int sgl_mi355_fp8_gemm_force_tile(int mode);
 /* Tiled MFMA GEMM for M > 64 with the same contract as sgl_mi355_skinny_gemm's fp8 case:
  * fp8_scaled_mm, sgl-kernel/csrc/gemm/fp8_gemm_kernel.cu:1071-1146 (CUTLASS tile dispatch :303-440,739-796). */

@@ -409,6 +409,136 @@ __global__ __launch_bounds__(NWV * 64, 1) void fp8_gemm256_kernel(const GemmPara
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// fp8 "streaming" tile for decode-sized M (64 < M <= 256, the continuous-batching regime): the weights are read once and
+// that read is the whole cost, so what matters is bytes in flight per CU, not MFMA rate.  128x128 tile, 128-byte K slices,
+// LDS-DMA into a FOUR-deep ring of 32 KiB stages (three slices in flight while one is computed: a counted s_waitcnt, never
+// vmcnt(0), in the loop), 8 waves (2 along M x 4 along N, 64 x 32 outputs each), block-scaled MFMA, split-K over
+// blockIdx.y with f32 slabs when the launch has fewer tiles than CUs.  Same LDS image, swizzle and fragment order as the
+// 256x256 kernel.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int S_BM = 128, S_BN = 128, S_STAGES = 4;
+constexpr int S_OPB = 128 * BKB;  // 16 KiB per operand and stage
+
+template <typename OutT>
+__global__ __launch_bounds__(512, 1) void fp8_gemm128s_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [4 stages][W 16 KiB | X 16 KiB]
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int bid = blockIdx.x;
+  const int q = nwg / 8, r8 = nwg % 8, xcd = bid % 8;
+  const int wgid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + bid / 8;
+  const int tm = wgid / p.tiles_n, tn = wgid - tm * p.tiles_n;
+  const int m0 = tm * S_BM, n0 = tn * S_BN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = (w >> 2) * 64, wn = (w & 3) * 32;
+  const int a = lane & 15, g = lane >> 4;
+
+  // staging: wave w fills rows 16 w .. 16 w + 15 of both operands, 8 rows per instruction (see the 256x256 kernel)
+  const auto wrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (unsigned)((int64_t)p.N * p.w_stride), 0x00020000);
+  const auto xrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (unsigned)((int64_t)p.M * p.x_stride), 0x00020000);
+  unsigned wvo[2], xvo[2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par) {
+    const int rl = 16 * w + (lane >> 3);
+    const int chunk = (lane & 7) ^ (((lane >> 4) + 4 * par) & 7);
+    wvo[par] = (unsigned)((int64_t)(n0 + rl) * p.w_stride) + chunk * 16;
+    xvo[par] = (unsigned)((int64_t)(m0 + rl) * p.x_stride) + chunk * 16;
+  }
+  const int nk_all = p.kbytes / BKB;
+  const int kt0 = p.slabs ? (int)blockIdx.y * p.kt_per : 0;
+  const int nk = (p.slabs ? min(nk_all, kt0 + p.kt_per) : nk_all) - kt0;  // slices of this workgroup
+  auto stage = [&](int i) {  // slice kt0 + min(i, nk - 1) -> stage i % 4 (past the end: a harmless re-stage, branch free)
+    auto* wb = (__attribute__((address_space(3))) char*)(smem + (i % S_STAGES) * 2 * S_OPB + (16 * w) * BKB);
+    const int off = (kt0 + min(i, nk - 1)) * BKB;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, wb + t * 8 * BKB, 16, wvo[t], (int)(t * 8 * p.w_stride) + off, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, wb + S_OPB + t * 8 * BKB, 16, xvo[t], (int)(t * 8 * p.x_stride) + off, 0, 0);
+    }
+  };
+
+  f32x4_t acc[2][4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  stage(0);
+  stage(1);
+  stage(2);
+  for (int i = 0; i < nk; ++i) {
+    // slice i has landed once at most the two younger stages (8 instructions of this wave) are outstanding; the barrier
+    // makes every wave's pieces visible and proves nobody still reads the stage that slice i + 3 is about to overwrite
+    asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    stage(i + 3);
+    const char* wa = smem + (i % S_STAGES) * 2 * S_OPB;
+    const char* xa = wa + S_OPB;
+    u32x4_t wf[2][2], xf[4][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) wf[j][h] = *(const u32x4_t*)(wa + lds_off(wn + 16 * j + a, 4 * h + g));
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) xf[ii][h] = *(const u32x4_t*)(xa + lds_off(wm + 16 * ii + a, 4 * h + g));
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) mfma_mx(wf[j][0], wf[j][1], xf[ii][0], xf[ii][1], acc[j][ii]);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may be in flight when the workgroup ends
+
+  // ---- epilogue: acc[j][i][r] -> row m0+wm+16i+a, col n0+wn+16j+4g+r ----
+  if (p.slabs) {
+    float* sl = p.slabs + (int64_t)blockIdx.y * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + wm + 16 * i + a;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn + 16 * j + 4 * g;
+        if (n + 3 < p.N) *(f32x4_t*)(sl + (int64_t)m * p.N + n) = acc[j][i];  // (N % 4 == 0 in slab mode)
+      }
+    }
+    return;
+  }
+  const bool vec_ok = (p.y_stride % 4 == 0) && (((uintptr_t)p.y & 7) == 0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm + 16 * i + a;
+    if (m >= p.M) continue;
+    const float sxv = p.sx ? p.sx[m] : 1.0f;
+    OutT* yrow = (OutT*)p.y + (int64_t)m * p.y_stride;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn + 16 * j + 4 * g;
+      if (n >= p.N) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int nn = min(n + r, p.N - 1);
+        const float swv = p.sw ? p.sw[nn] : 1.0f;
+        const float bv = p.bias ? (float)((const OutT*)p.bias)[nn] : 0.0f;
+        v[r] = acc[j][i][r];
+        if (p.sx) v[r] *= sxv;
+        v[r] = v[r] * swv + bv;
+      }
+      if (vec_ok && n + 3 < p.N) {
+        typedef OutT o4_t __attribute__((ext_vector_type(4)));
+        const o4_t o = {(OutT)v[0], (OutT)v[1], (OutT)v[2], (OutT)v[3]};
+        *(o4_t*)(yrow + n) = o;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n + r < p.N) yrow[n + r] = (OutT)v[r];
+      }
+    }
+  }
+}
+
 int tg_cus() {
   static int cus = 0;
   if (cus == 0) {
@@ -476,7 +606,7 @@ int launch(GemmParams& p, hipStream_t st, float* workspace = nullptr, int64_t wo
   if (workspace != nullptr && tiles < cus && p.N % 4 == 0) {
     splits = (2 * cus) / tiles;  // two resident workgroups per CU
     if (splits > 8) splits = 8;
-    if (splits > nk / 4) splits = nk / 4;  // at least 4 slices (512 B of K) per workgroup
+    if (splits > nk / 8) splits = nk / 8;  // at least 8 slices (1 KiB of K) per workgroup: more splits only move the cost into slabs
     while (splits > 1 && (int64_t)splits * p.M * p.N > workspace_floats) --splits;
   }
   if (splits > 1) {
@@ -496,6 +626,45 @@ int launch(GemmParams& p, hipStream_t st, float* workspace = nullptr, int64_t wo
   p.kt_per = 0;
   hipLaunchKernelGGL((tiled_gemm_kernel<ES, OutT>), dim3(tiles), dim3(256), smem, st, p);
   SGL_HIP_LAUNCH_CHECK();
+  return SGL_MI355_OK;
+}
+
+template <typename OutT>
+int launch128s(GemmParams& p, hipStream_t st, float* workspace, int64_t workspace_floats) {
+  constexpr int smem = S_STAGES * 2 * S_OPB;  // 128 KiB
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)fp8_gemm128s_kernel<OutT>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  p.tiles_m = (p.M + S_BM - 1) / S_BM;
+  p.tiles_n = (p.N + S_BN - 1) / S_BN;
+  const int tiles = p.tiles_m * p.tiles_n, nk = p.kbytes / BKB, cus = tg_cus();
+  int splits = 1;
+  if (workspace != nullptr && tiles < cus && p.N % 4 == 0) {
+    splits = cus / tiles;                  // one 128 KiB workgroup per CU
+    if (splits > nk / 8) splits = nk / 8;  // at least 8 slices (1 KiB of K) per workgroup: more splits only move the cost into slabs
+    if (splits < 1) splits = 1;
+    while (splits > 1 && (int64_t)splits * p.M * p.N > workspace_floats) --splits;
+  }
+  if (splits > 1) {
+    p.kt_per = (nk + splits - 1) / splits;
+    splits = (nk + p.kt_per - 1) / p.kt_per;
+    p.slabs = workspace;
+  } else {
+    splits = 1;
+    p.kt_per = nk;
+    p.slabs = nullptr;
+  }
+  hipLaunchKernelGGL((fp8_gemm128s_kernel<OutT>), dim3(tiles, splits), dim3(512), smem, st, p);
+  SGL_HIP_LAUNCH_CHECK();
+  if (splits > 1) {
+    const int64_t items = (int64_t)p.M * (p.N / 4);
+    const unsigned blocks = (unsigned)((items + 255) / 256 > 4096 ? 4096 : (items + 255) / 256);
+    hipLaunchKernelGGL((tiled_splitk_reduce_kernel<OutT>), dim3(blocks), dim3(256), 0, st, workspace, splits, p.sx, p.sw,
+                       (const OutT*)p.bias, (OutT*)p.y, p.y_stride, p.M, p.N);
+    SGL_HIP_LAUNCH_CHECK();
+  }
   return SGL_MI355_OK;
 }
 
@@ -523,6 +692,10 @@ int run(const void* x, int64_t xs, const void* w, int64_t ws, void* y, int64_t y
     const int64_t tiles256 = (int64_t)((M + T2 - 1) / T2) * ((N + T2 - 1) / T2);
     const bool can256 = p.kbytes % BKB == 0 && p.kbytes >= BKB && (int64_t)N * p.w_stride < 0xFFFFFFF0ll &&
                         (int64_t)M * p.x_stride < 0xFFFFFFF0ll;  // 32-bit buffer offsets
+    // decode-sized M: the streaming tile (weights read once; bytes in flight decide)
+    if (can256 && (g_tiled_force == 5 || (g_tiled_force == 0 && M <= 256)))
+      return out_dtype == SGL_BF16 ? launch128s<__bf16>(p, st, workspace, workspace_floats)
+                                   : launch128s<_Float16>(p, st, workspace, workspace_floats);
     if (can256 && g_tiled_force == 4) return out_dtype == SGL_BF16 ? launch256<__bf16, 8, false>(p, st) : launch256<_Float16, 8, false>(p, st);
     if (can256 && g_tiled_force == 3) return out_dtype == SGL_BF16 ? launch256<__bf16, 4>(p, st) : launch256<_Float16, 4>(p, st);
     if (can256 && g_tiled_force != 1 && (g_tiled_force == 2 || tiles256 >= tg_cus()))

@@ -353,12 +353,12 @@ def test_fp8_scaled_mm_m33_to_64_weight_streaming_kernel(m, n, k, out, bias, sk)
 
 
 # ---------------------------------------------------------------- tiled GEMM at prefill-sized M
-@pytest.mark.parametrize("tile_mode", [1, 2, 3, 4])
+@pytest.mark.parametrize("tile_mode", [1, 2, 3, 4, 5])
 @pytest.mark.parametrize("m,n,k,out", [(256, 384, 4096, "bf16"), (1000, 136, 1024, "bf16"), (129, 6144, 512, "f16"),
                                        (515, 776, 1152, "bf16"), (768, 136, 256, "f16"),
                                        (128, 1024, 8192, "bf16"), (200, 520, 4096, "f16")])  # few tiles: the split-K path
 def test_fp8_scaled_mm_large_m_vs_oracle(m, n, k, out, tile_mode, sk):
-    # tile_mode 1: 128x128 tiles; 2 / 3: the 256x256 LDS-DMA kernel with 8 / 4 waves, 4: its register-staged form (ragged M / N edges, odd K-slice counts)
+    # tile_mode 1: 128x128 tiles; 2 / 3: the 256x256 LDS-DMA kernel with 8 / 4 waves, 4: its register-staged form, 5: the 4-stage streaming 128x128 tile (with split-K when the workspace allows) (ragged M / N edges, odd K-slice counts)
     from ltp_sglang_amd import _cabi
     case = dict(m=m, n=n, k=k, bias=True, out=out)
     c = _cases.build_gemm_case(case, seed=m)
@@ -380,7 +380,7 @@ def test_fp8_gemm_tile_kernels_agree(sk):
     w = torch.randint(-2, 3, (n, k), generator=g).float().to(torch.float8_e4m3fn).to(DEV)
     sa, sb = torch.ones(m, device=DEV), torch.ones(n, device=DEV)
     outs = []
-    for mode in (1, 2, 3, 4):
+    for mode in (1, 2, 3, 4, 5):
         _cabi.check(_cabi.lib.sgl_mi355_fp8_gemm_force_tile(mode))
         try:
             outs.append(sk.fp8_scaled_mm(a, w.t(), sa, sb, torch.float16))
