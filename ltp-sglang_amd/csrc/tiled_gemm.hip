@@ -227,7 +227,9 @@ __device__ __forceinline__ void glds16(const char* g, char* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <typename OutT, int NWV, bool DMA = true>  // NWV = 8: waves 2 (M) x 4 (N), 128 x 64 outputs each; 4: 2 x 2, 128 x 128 each
+// ES: TG_FP8 (block-scaled MFMA over the whole 128-byte slice) or TG_BF16 / TG_F16 (two 16x16x32 k-steps per slice: the
+// same LDS reads, chunk 4 h + g being exactly k-step h's fragment)
+template <typename OutT, int NWV, bool DMA = true, int ES = TG_FP8>  // NWV = 8: waves 2 (M) x 4 (N), 128 x 64 outputs each; 4: 2 x 2
 __global__ __launch_bounds__(NWV * 64, 1) void fp8_gemm256_kernel(const GemmParams p) {
   constexpr int WCOLS = NWV == 8 ? 4 : 2;     // waves along N
   constexpr int JN = 256 / WCOLS / 16;        // 16-column W fragments per wave
@@ -325,7 +327,14 @@ __global__ __launch_bounds__(NWV * 64, 1) void fp8_gemm256_kernel(const GemmPara
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < JN; ++j) mfma_mx(wf[ws][j][0], wf[ws][j][1], xf[slot][i][0], xf[slot][i][1], acc[j][2 * grp + i]);
+      for (int j = 0; j < JN; ++j) {
+        if constexpr (ES == TG_FP8) {
+          mfma_mx(wf[ws][j][0], wf[ws][j][1], xf[slot][i][0], xf[slot][i][1], acc[j][2 * grp + i]);
+        } else {
+          mfma_chunk<ES>(wf[ws][j][0], xf[slot][i][0], acc[j][2 * grp + i]);
+          mfma_chunk<ES>(wf[ws][j][1], xf[slot][i][1], acc[j][2 * grp + i]);
+        }
+      }
   };
   if constexpr (DMA) {
     stage(0, 0);
@@ -551,18 +560,18 @@ int tg_cus() {
 int g_tiled_group_m = 4;
 int g_tiled_force = 0;  // test hook: 1 = always the 128x128 kernel, 2 = the 256x256 kernel whenever its shape rules allow
 
-template <typename OutT, int NWV, bool DMA = true>
+template <typename OutT, int NWV, bool DMA = true, int ES = TG_FP8>
 int launch256(GemmParams& p, hipStream_t st) {
   constexpr int smem = 2 * 2 * OPB;  // 128 KiB
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)fp8_gemm256_kernel<OutT, NWV, DMA>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)fp8_gemm256_kernel<OutT, NWV, DMA, ES>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
   p.tiles_m = (p.M + T2 - 1) / T2;
   p.tiles_n = (p.N + T2 - 1) / T2;
   p.group_m = g_tiled_group_m;
-  hipLaunchKernelGGL((fp8_gemm256_kernel<OutT, NWV, DMA>), dim3(p.tiles_m * p.tiles_n), dim3(NWV * 64), smem, st, p);
+  hipLaunchKernelGGL((fp8_gemm256_kernel<OutT, NWV, DMA, ES>), dim3(p.tiles_m * p.tiles_n), dim3(NWV * 64), smem, st, p);
   SGL_HIP_LAUNCH_CHECK();
   return SGL_MI355_OK;
 }
@@ -702,6 +711,16 @@ int run(const void* x, int64_t xs, const void* w, int64_t ws, void* y, int64_t y
       return out_dtype == SGL_BF16 ? launch256<__bf16, 8>(p, st) : launch256<_Float16, 8>(p, st);
     return out_dtype == SGL_BF16 ? launch<TG_FP8, __bf16>(p, st, workspace, workspace_floats)
                                  : launch<TG_FP8, _Float16>(p, st, workspace, workspace_floats);
+  }
+  {  // 16-bit inputs: the 256x256 LDS-DMA kernel when there is at least one tile per CU and K is whole 128-byte slices
+    const int64_t tiles256 = (int64_t)((M + T2 - 1) / T2) * ((N + T2 - 1) / T2);
+    const bool can256 = p.kbytes % BKB == 0 && p.kbytes >= BKB && (int64_t)N * p.w_stride < 0xFFFFFFF0ll &&
+                        (int64_t)M * p.x_stride < 0xFFFFFFF0ll;
+    if (can256 && g_tiled_force != 1 && (g_tiled_force == 2 || tiles256 >= tg_cus())) {
+      if (in_dtype == SGL_BF16)
+        return out_dtype == SGL_BF16 ? launch256<__bf16, 8, true, TG_BF16>(p, st) : launch256<_Float16, 8, true, TG_BF16>(p, st);
+      return out_dtype == SGL_BF16 ? launch256<__bf16, 8, true, TG_F16>(p, st) : launch256<_Float16, 8, true, TG_F16>(p, st);
+    }
   }
   if (in_dtype == SGL_BF16)
     return out_dtype == SGL_BF16 ? launch<TG_BF16, __bf16>(p, st, workspace, workspace_floats)

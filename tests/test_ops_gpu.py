@@ -390,7 +390,7 @@ def test_fp8_gemm_tile_kernels_agree(sk):
     assert all(torch.equal(o, ref) for o in outs)
 
 
-@pytest.mark.parametrize("shape", [(300, 200, 1032), (130, 256, 4096)])   # the second: few tiles -> split-K
+@pytest.mark.parametrize("shape", [(300, 200, 1032), (130, 256, 4096), (4100, 4096, 1024)])   # few tiles -> split-K; 256x256 LDS-DMA kernel
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_dense_gemm_large_m(dtype, shape, sk):
     g = torch.Generator().manual_seed(9)
