@@ -63,12 +63,13 @@ def _worker(rank, world, port, q, feed):
     dist.destroy_process_group()
 
 
-def test_tp2_fused_path_matches_plain_and_tp1(pkg):
+@pytest.mark.parametrize("world", [2, 4])   # 4: the 2 kv heads are replicated across rank pairs (llama.py:118-133)
+def test_tp_fused_path_matches_plain_and_tp1(world, pkg):
     tp1, feed = _run_model(True)          # this process: no process group -> tp 1
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, feed)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, feed)) for r in range(world)]
     for p in procs:
         p.start()
     plain, fused = (torch.from_numpy(x) for x in q.get(timeout=300))
