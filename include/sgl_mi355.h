@@ -58,6 +58,11 @@ int sgl_mi355_decode_attention(const void* q, int64_t q_stride_t, const void* k_
  * rows are converted exactly to the q dtype on the way into LDS, K_true = K_fp8 * k_scale, V_true = V_fp8 * v_scale
  * (RadixAttention.k_scale / v_scale, radix_attention.py:73-76; the Triton backend leaves both at 1). */
 
+/* merge_state / merge_state_v2 (sgl-kernel/csrc/attention/merge_attn_states.cu:32-105; python attention.py:12-52): LSE-weighted
+ * merge of two attention partials v [n, h, d] (bf16 / f16 / f32) with s f32 [n, h]; s_merged may be NULL. */
+int sgl_mi355_merge_state(const void* v_a, const float* s_a, const void* v_b, const float* s_b, void* v_merged, float* s_merged,
+                          int64_t num_tokens, int num_heads, int head_size, int dtype, void* stream);
+
 /* Measurement hook: 1 (default) = every wave owns one (request, kv head, split) unit; 0 = the first design, a
  * 4-wave workgroup sharing one split with an LDS merge. */
 int sgl_mi355_decode_attention_set_mode(int mode);

@@ -311,3 +311,64 @@ extern "C" int sgl_mi355_transpose_2d(void* out, const void* in, int rows, int c
   SGL_HIP_LAUNCH_CHECK();
   return SGL_MI355_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------
+// merge_state / merge_state_v2 (sgl-kernel/csrc/attention/merge_attn_states.cu:32-105, python attention.py:12-52):
+// LSE-weighted merge of two attention partials (cascade "shared prefix once, private suffix per request" decode):
+//   m = max(sa, sb) (+inf -> -inf first); wa = e^(sa-m), wb = e^(sb-m); v = va * wa/(wa+wb) + vb * wb/(wa+wb);
+//   s = log(wa + wb) + m.   v [n, h, d] in bf16 / f16 / f32, s f32 [n, h].  One 16-byte pack per thread.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+template <typename T>
+__global__ __launch_bounds__(128) void merge_state_kernel(const T* va, const float* sa, const T* vb, const float* sb, T* vo,
+                                                          float* so, int64_t nh, int d) {
+  constexpr int PACK = 16 / sizeof(T);
+  const int tph = d / PACK;
+  const int64_t gid = (int64_t)blockIdx.x * 128 + threadIdx.x;
+  if (gid >= nh * tph) return;
+  const int64_t th = gid / tph;
+  const int pk = (int)(gid - th * tph);
+  float p = sa[th], q = sb[th];
+  p = isinf(p) ? -INFINITY : p;
+  q = isinf(q) ? -INFINITY : q;
+  const float m = fmaxf(p, q);
+  const float pe = expf(p - m), qe = expf(q - m);
+  const float se = pe + qe;
+  const float ps = pe / se, qs = qe / se;
+  struct P { T v[PACK]; };
+  const P a = *(const P*)(va + th * d + pk * PACK), b = *(const P*)(vb + th * d + pk * PACK);
+  P o;
+#pragma unroll
+  for (int i = 0; i < PACK; ++i) o.v[i] = (T)((float)a.v[i] * ps + ((float)b.v[i] * qs));
+  *(P*)(vo + th * d + pk * PACK) = o;
+  if (so != nullptr && pk == 0) so[th] = logf(se) + m;
+}
+}  // namespace
+
+extern "C" int sgl_mi355_merge_state(const void* v_a, const float* s_a, const void* v_b, const float* s_b, void* v_merged,
+                                     float* s_merged, int64_t num_tokens, int num_heads, int head_size, int dtype,
+                                     void* stream) {
+  SGL_CHECK(num_tokens >= 0 && num_heads > 0 && head_size > 0, "merge_state: bad shape");
+  if (num_tokens == 0) return SGL_MI355_OK;
+  SGL_CHECK(v_a && s_a && v_b && s_b && v_merged, "merge_state: null pointer");
+  SGL_CHECK(dtype == SGL_BF16 || dtype == SGL_F16 || dtype == SGL_F32, "merge_state: dtype must be bf16, f16 or f32");
+  const int pack = dtype == SGL_F32 ? 4 : 8;
+  SGL_CHECK(head_size % pack == 0, "headsize must be multiple of pack_size: %d", pack);
+  SGL_CHECK(((uintptr_t)v_a % 16) == 0 && ((uintptr_t)v_b % 16) == 0 && ((uintptr_t)v_merged % 16) == 0,
+            "merge_state: tensors must be 16-byte aligned");
+  const int64_t nh = num_tokens * num_heads, threads = nh * (head_size / pack);
+  const dim3 grid((unsigned)((threads + 127) / 128));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SGL_BF16)
+    hipLaunchKernelGGL((merge_state_kernel<__bf16>), grid, dim3(128), 0, st, (const __bf16*)v_a, s_a, (const __bf16*)v_b, s_b,
+                       (__bf16*)v_merged, s_merged, nh, head_size);
+  else if (dtype == SGL_F16)
+    hipLaunchKernelGGL((merge_state_kernel<_Float16>), grid, dim3(128), 0, st, (const _Float16*)v_a, s_a, (const _Float16*)v_b,
+                       s_b, (_Float16*)v_merged, s_merged, nh, head_size);
+  else
+    hipLaunchKernelGGL((merge_state_kernel<float>), grid, dim3(128), 0, st, (const float*)v_a, s_a, (const float*)v_b, s_b,
+                       (float*)v_merged, s_merged, nh, head_size);
+  SGL_HIP_LAUNCH_CHECK();
+  return SGL_MI355_OK;
+}

@@ -12,7 +12,7 @@
 All of them launch the hand-written HIP kernels through the C-ABI on torch's current
 stream; there is no fallback.
 """
-from typing import Optional
+from typing import Optional, Tuple
 
 import torch
 
@@ -162,3 +162,22 @@ def extend_attention(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer,
             float(logit_cap), 1, dtype_code(q_extend.dtype), dtype_code(k_buffer.dtype), 1.0, 1.0, current_stream(),
         )
     )
+
+
+def merge_state(v_a: torch.Tensor, s_a: torch.Tensor, v_b: torch.Tensor, s_b: torch.Tensor,
+                v_merged: Optional[torch.Tensor] = None, s_merged: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """LSE-weighted merge of two attention partials (sgl_kernel.merge_state, attention.py:12-28): v [n, h, d], s [n, h]."""
+    _require_cuda(v_a, s_a, v_b, s_b)
+    s_a, s_b = s_a.to(torch.float32).contiguous(), s_b.to(torch.float32).contiguous()
+    assert v_a.shape == v_b.shape and v_a.dim() == 3 and v_a.is_contiguous() and v_b.is_contiguous() and v_a.dtype == v_b.dtype
+    if v_merged is None:
+        v_merged = torch.empty_like(v_a)
+    if s_merged is None:
+        s_merged = torch.empty_like(s_a)
+    n, h, d = v_a.shape
+    check(lib.sgl_mi355_merge_state(ptr(v_a), ptr(s_a), ptr(v_b), ptr(s_b), ptr(v_merged), ptr(s_merged), n, h, d,
+                                    dtype_code(v_a.dtype), current_stream()))
+    return v_merged, s_merged
+
+
+merge_state_v2 = merge_state  # one kernel serves both reference entry points (attention.py:31-52)

@@ -116,3 +116,16 @@ def extend_attention_f64(
         out[pos : pos + ext] = torch.einsum("hqn,nhd->qhd", p, vals)
         pos += ext
     return out
+
+
+def merge_state(v_a, s_a, v_b, s_b):
+    """merge_state_torch, sgl-kernel/tests/test_merge_state_v2.py:101-135 (the reference's own torch restatement)."""
+    p, s = s_a.float().clone(), s_b.float().clone()
+    p[p == torch.inf] = -torch.inf
+    s[s == torch.inf] = -torch.inf
+    m = torch.maximum(p, s)
+    pe, se_ = torch.exp(p - m), torch.exp(s - m)
+    tot = pe + se_
+    out_lse = torch.log(tot) + m
+    out = v_a * (pe / tot).unsqueeze(2) + v_b * (se_ / tot).unsqueeze(2)
+    return out, out_lse

@@ -142,3 +142,25 @@ def test_decode_baseline_shape_properties(pkg):
     for b in (0, 13, 31):
         ref = oa.decode_attention_f64(q[b : b + 1], k, v, req_to_token, torch.tensor([b]), torch.tensor([seq]), d ** -0.5)
         assert (outs[1][b].double() - ref[0]).abs().max().item() <= 2e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("n,h,d", [(1, 1, 64), (37, 8, 128), (512, 32, 128), (5, 3, 96)])
+def test_merge_state_vs_reference_restatement(dtype, n, h, d, pkg):
+    """sgl_kernel.merge_state / merge_state_v2 against the reference's own torch restatement (test_merge_state_v2.py:101-135),
+    with the +inf -> -inf rule and one-sided -inf rows; tolerance = the reference test's (1e-3 float, 1e-2 half)."""
+    from ltp_sglang_amd import sgl_kernel
+
+    g = torch.Generator().manual_seed(n * 131 + h)
+    va, vb = torch.randn(n, h, d, generator=g).to(dtype), torch.randn(n, h, d, generator=g).to(dtype)
+    sa, sb = torch.randn(n, h, generator=g) * 3, torch.randn(n, h, generator=g) * 3
+    sa.view(-1)[0] = float("inf")            # treated as -inf
+    if n * h > 2:
+        sb.view(-1)[1] = float("-inf")       # one empty side
+    vo, so = sgl_kernel.merge_state(va.to("cuda:0"), sa.to("cuda:0"), vb.to("cuda:0"), sb.to("cuda:0"))
+    vo2, so2 = sgl_kernel.merge_state_v2(va.to("cuda:0"), sa.to("cuda:0"), vb.to("cuda:0"), sb.to("cuda:0"))
+    rv, rs = oa.merge_state(va.float(), sa.clone(), vb.float(), sb.clone())
+    tol = 1e-3 if dtype == torch.float32 else 1e-2
+    torch.testing.assert_close(vo.cpu().float(), rv, rtol=tol, atol=tol)   # (bf16 output rounding alone is 2^-9 relative)
+    assert torch.allclose(so.cpu(), rs, rtol=1e-5, atol=1e-5)
+    assert torch.equal(vo, vo2) and torch.equal(so, so2)
