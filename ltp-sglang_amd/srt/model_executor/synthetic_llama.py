@@ -477,7 +477,8 @@ class SyntheticModelRunner:
                 self.model(buf.input_ids, buf.positions, fb)
         torch.cuda.current_stream().wait_stream(stream)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=stream):
+        # thread_local: the RCCL watchdog thread of torch.distributed may touch the device while this thread captures (TP > 1)
+        with torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
             buf.logits = self.model(buf.input_ids, buf.positions, fb)
         self._graphs[bs] = (graph, buf)
 
