@@ -167,3 +167,43 @@ def test_shared_prefix_hit_path_matches_full_prefill(pkg):
     nxt = torch.argmax(l_hit.float(), dim=-1)
     d1 = runner.decode(st_hit, nxt)
     assert torch.isfinite(d1.float()).all()
+
+
+def test_headline_shapes_fused_equals_plain_two_layers(pkg):
+    """The exact kernel instantiations of the headline bench (Llama-3-8B dims, batch 32 x 2048, two layers): the fused /
+    graph decode step and the fused prefill must give the same logits, bit for bit, as the per-op path."""
+    from ltp_sglang_amd.srt.model_executor.synthetic_llama import LlamaShape, SyntheticModelRunner
+
+    cfg = LlamaShape.llama3_8b()
+    cfg.num_hidden_layers = 2
+    cfg.vocab_size = 32000
+    bs, seq = 32, 2048
+    g = torch.Generator().manual_seed(0)
+    ids = [torch.randint(0, 10000, (seq,), generator=g).to(DEV) for _ in range(bs)]
+    outs = {}
+    for mode in ("plain", "graph"):
+        runner = SyntheticModelRunner(cfg, "w8a8_fp8", max_running_requests=bs, context_len=seq + 16, max_total_tokens=bs * (seq + 8) + 64,
+                                      device=DEV, seed=0)
+        runner.model.fused_decode = runner.model.fused_extend = mode != "plain"
+        logits = []
+        states = []
+        for c0 in range(0, bs, 8):
+            l, st = runner.extend(ids[c0:c0 + 8])
+            logits.append(l)
+            states.append(st)
+        from types import SimpleNamespace
+        state = SimpleNamespace(req_pool_indices=torch.cat([s.req_pool_indices for s in states]),
+                                seq_lens=torch.cat([s.seq_lens for s in states]), seq_lens_cpu=sum([s.seq_lens_cpu for s in states], []))
+        seqs = [torch.cat(logits).clone()]
+        nxt = torch.argmax(seqs[0].float(), dim=-1)
+        if mode == "graph":
+            runner.capture_decode_graph(bs)
+        for _ in range(2):
+            l = (runner.decode_graph if mode == "graph" else runner.decode)(state, nxt)
+            seqs.append(l.clone())
+            nxt = torch.argmax(l.float(), dim=-1)
+        outs[mode] = torch.stack(seqs)
+        del runner
+        torch.cuda.empty_cache()
+    assert torch.isfinite(outs["plain"].float()).all()
+    assert torch.equal(outs["plain"], outs["graph"])
