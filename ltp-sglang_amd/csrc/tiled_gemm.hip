@@ -9,6 +9,7 @@
 // swizzle so the ds_read_b128 fragment reads are bank-conflict free, XCD-aware bijective block remap so the
 // workgroups that share an X row panel run on the same XCD (one L2).
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void fp8_gemm256_kernel(const GemmPara
   // MFMA group are fetched while the current group runs, and the barrier sits before the LAST group, so that its wait,
   // the re-staging of the buffer just drained and the first fragment reads of slice kt + 1 all hide behind 8-16 MFMAs.
   constexpr int NG = 4;                 // MFMA groups per slice: 2 X row-tiles (32 rows) x JN column tiles each
-  u32x4_t wf[2][JN][2], xf[2][2][2];    // W fragments double-buffered across slices, X fragments across groups
+  u32x4_t wf[DMA ? 1 : 2][JN][2], xf[3][2][2];  // X fragments in a 3-slot rotation (LDS-DMA path: one W fragment set)
   auto load_w = [&](int buf, int ws) {
     const char* wa = smem + buf * 2 * OPB;
 #pragma unroll
@@ -342,27 +343,38 @@ __global__ __launch_bounds__(NWV * 64, 1) void fp8_gemm256_kernel(const GemmPara
     stage(min(1, nk - 1), 1);
     load_w(0, 0);
     load_x(0, 0, 0);
-    // one slice; `ws` (which W fragment set it computes with) alternates, so the loop is unrolled by two
-    auto slice = [&](int kt, int buf, int ws) {
-#pragma unroll
-      for (int grp = 0; grp < NG - 1; ++grp) {
-        load_x(buf, grp + 1, (grp + 1) & 1);
-        mma(grp, grp & 1, ws);
-      }
+    // One slice = 4 MFMA groups g0..g3 (2 X row tiles x JN column tiles each).  X fragments rotate through three slots so
+    // that TWO groups (16 MFMAs per wave) are already in registers when the slice's single barrier is reached: the
+    // barrier wait, the re-staging of the drained buffer and the first fragment reads of the next slice all hide behind
+    // them.  Slot roles advance by one per slice and the W fragment set alternates: six static variants, picked by kt % 6.
+    auto slice = [&](int kt, int buf, auto r_) {
+      constexpr int R = decltype(r_)::value;
+      constexpr int S0 = R, S1 = (R + 1) % 3, S2 = (R + 2) % 3;  // g0 in S0 on entry; g1 -> S1, g2 -> S2, g3 -> S0
+      load_x(buf, 1, S1);
+      mma(0, S0, 0);
+      load_x(buf, 2, S2);
+      mma(1, S1, 0);
+      load_x(buf, 3, S0);
       TL_STAMP(0);  // (stamps only where the wave drains lgkmcnt anyway: an s_memtime elsewhere serialises the LDS reads)
       __syncthreads();  // slice kt + 1 has landed for every wave (vmcnt) and nobody reads buf any more (lgkmcnt)
       TL_STAMP(1);
-      load_w(buf ^ 1, ws ^ 1);          // next slice's first fragments: in flight under the last MFMA group and the staging
-      load_x(buf ^ 1, 0, 0);            // (after the last slice these read a re-staged copy and are never used)
-      mma(NG - 1, (NG - 1) & 1, ws);
+      load_x(buf ^ 1, 0, S1);           // next slice's g0 -> S1 = its S0 (after the last slice: a re-staged copy, never used)
       stage(min(kt + 2, nk - 1), buf);  // branch free: the last two iterations re-stage the final slice into drained buffers
+      mma(2, S2, 0);
+      mma(3, S0, 0);
+      load_w(buf ^ 1, 0);               // the W fragments are free once the slice's last MFMA has issued
     };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
     int kt = 0;
-    for (; kt + 1 < nk; kt += 2) {
-      slice(kt, 0, 0);
-      slice(kt + 1, 1, 1);
+    for (; kt + 2 < nk; kt += 3) {
+      slice(kt, kt & 1, I0{});
+      slice(kt + 1, (kt + 1) & 1, I1{});
+      slice(kt + 2, kt & 1, I2{});
     }
-    if (kt < nk) slice(kt, 0, 0);
+    if (kt < nk) slice(kt, kt & 1, I0{});
+    if (kt + 1 < nk) slice(kt + 1, (kt + 1) & 1, I1{});
   } else {
     stage(0, 0);
     commit(0);
