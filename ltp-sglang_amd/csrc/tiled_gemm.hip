@@ -325,6 +325,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void fp8_gemm256_kernel(const GemmPara
       for (int h = 0; h < 2; ++h) xf[slot][i][h] = *(const u32x4_t*)(xa + lds_off(wm + 32 * grp + 16 * i + a, 4 * h + g));
   };
   auto mma = [&](int grp, int slot, int ws) {
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -336,6 +337,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void fp8_gemm256_kernel(const GemmPara
           mfma_chunk<ES>(wf[ws][j][1], xf[slot][i][1], acc[j][2 * grp + i]);
         }
       }
+    __builtin_amdgcn_s_setprio(0);
   };
   if constexpr (DMA) {
     stage(0, 0);
