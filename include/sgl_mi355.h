@@ -58,6 +58,19 @@ int sgl_mi355_decode_attention(const void* q, int64_t q_stride_t, const void* k_
  * rows are converted exactly to the q dtype on the way into LDS, K_true = K_fp8 * k_scale, V_true = V_fp8 * v_scale
  * (RadixAttention.k_scale / v_scale, radix_attention.py:73-76; the Triton backend leaves both at 1). */
 
+/* decode_attention_fwd (stage 1) with stage 2 done IN THE SAME LAUNCH: the last workgroup of each request to finish merges the
+ * request's splits (decode_attention.py:492-552), writes the merged row (out_o, optional) and its per-token fp8 quantisation
+ * (out_q e4m3 [batch, Hq*Dv] + out_s f32 [batch], optional; sgl_per_token_quant_fp8) -- the decode step's
+ * attention -> o_proj hand-off in one kernel.  merge_counters: int32 [batch], zero on entry, left zero.  Results are
+ * bit-identical to sgl_mi355_decode_attention(o = NULL) + sgl_mi355_decode_merge_quant_fp8.  head_dim 64 / 128. */
+int sgl_mi355_decode_attention_merge_quant(const void* q, int64_t q_stride_t, const void* k_buffer, const void* v_buffer,
+                                           int64_t k_stride_t, int64_t k_stride_h, int64_t v_stride_t, int64_t v_stride_h,
+                                           const int32_t* kv_indptr, const int32_t* kv_indices, float* attn_logits,
+                                           float* attn_lse, const int32_t* num_kv_splits, int max_kv_splits, int batch,
+                                           int num_q_heads, int num_kv_heads, int head_dim, int v_head_dim, float sm_scale,
+                                           float logit_cap, int dtype, int kv_dtype, float k_scale, float v_scale,
+                                           int32_t* merge_counters, void* out_o, void* out_q, float* out_s, void* stream);
+
 /* merge_state / merge_state_v2 (sgl-kernel/csrc/attention/merge_attn_states.cu:32-105; python attention.py:12-52): LSE-weighted
  * merge of two attention partials v [n, h, d] (bf16 / f16 / f32) with s f32 [n, h]; s_merged may be NULL. */
 int sgl_mi355_merge_state(const void* v_a, const float* s_a, const void* v_b, const float* s_b, void* v_merged, float* s_merged,

@@ -14,7 +14,9 @@ objs=()
 for src in "$HERE"/*.hip; do
   obj="$HERE/.obj/$(basename "${src%.hip}").o"
   objs+=("$obj")
-  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/common.h" -nt "$obj" ]; then
+  stale=0
+  for h in "$HERE"/*.h; do [ "$h" -nt "$obj" ] && stale=1; done
+  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$stale" = 1 ]; then
     $HIPCC $FLAGS -c "$src" -o "$obj" &
     pids+=($!)
   fi

@@ -24,7 +24,7 @@
 //  * partial results use the reference's own scratch layout (attn_logits f32
 //    [bs, Hq, max_splits, Dv] holding acc/l, attn_lse f32 [bs, Hq, max_splits] holding
 //    m + log(l)) and stage 2 merges the splits by LSE exactly like _fwd_kernel_stage2.
-#include "common.h"
+#include "row_helpers.h"
 
 namespace {
 
@@ -52,6 +52,11 @@ struct DecodeParams {
   float sm_scale, logit_cap;
   int kv_fp8;             // K/V pool rows are e4m3fn bytes (kv_cache_dtype fp8_e4m3, memory_pool.py:385-395), else the q dtype
   float k_scale, v_scale;  // K_true = K_fp8 * k_scale, V_true = V_fp8 * v_scale (radix_attention.py:73-76); 1 for 16-bit pools
+  // in-launch stage 2 (MODE 0): the last workgroup of a request to finish merges its splits and quantises the row
+  int32_t* merge_cnt;  // [bs], zero on entry, left zero; NULL = off
+  void* mq_o;          // optional T [bs, Hq * Dv]
+  void* mq_q;          // optional e4m3 [bs, Hq * Dv] with mq_s f32 [bs]
+  float* mq_s;
 };
 
 constexpr int kTile = 32;  // tokens per wave tile == reference _MIN_BLOCK_KV (decode_attention.py:35)
@@ -80,6 +85,37 @@ __device__ __forceinline__ float softcap_log2(float s_scaled, float cap) {
   const float y = s_scaled / cap;
   const float t = 2.0f / (1.0f + __expf(-2.0f * y)) - 1.0f;
   return cap * t * kLog2e;
+}
+
+// In-launch stage 2 (cross-workgroup hand-off in its counter form): every workgroup of request b publishes its split
+// partial -- WRITE-THROUGH (sc1) stores, so no release fence (a release per workgroup writes back the XCD's L2 and made the
+// launch 35 us slower); every wave drains vmcnt, barrier, then lane 0 draws a ticket -- and the workgroup that draws the
+// last ticket acquires (agent scope: ONE cache invalidate per request), merges all splits of the request, rounds, optionally
+// quantises per token (the op sequence stage 2 -> sgl_per_token_quant_fp8) and puts the counter back to zero.  Correct for
+// any placement of the request's workgroups over CUs / XCDs; workgroup-scope fences or an L1-only invalidate would not be.
+template <typename T>
+__device__ __forceinline__ void arrive_and_merge(const DecodeParams& p, int b, int seq_len, int nsplit, int hchunks, char* smem) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int* flag = (int*)smem;  // (the LDS of the cross-wave merge is free again)
+  if (threadIdx.x == 0) {
+    const int total = p.hkv * hchunks * nsplit;
+    const int old = __hip_atomic_fetch_add(p.merge_cnt + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *flag = (old == total - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (*flag == 0) return;
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  float* red = (float*)smem + 4;
+  if (p.hq * p.dv <= 256 * 8 * 4)
+    merge_quant_row<T, 4>(b, p.attn_logits, p.attn_lse, seq_len, nsplit, p.max_kv_splits, p.hq, p.dv, (T*)p.mq_o, (uint8_t*)p.mq_q, p.mq_s, red);
+  else
+    merge_quant_row<T, 8>(b, p.attn_logits, p.attn_lse, seq_len, nsplit, p.max_kv_splits, p.hq, p.dv, (T*)p.mq_o, (uint8_t*)p.mq_q, p.mq_s, red);
+  if (threadIdx.x == 0) __hip_atomic_store(p.merge_cnt + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // 16 e4m3 bytes -> 16 T (exact: every e4m3 value is representable in bf16 and f16)
@@ -153,7 +189,12 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attn_stage1(const DecodePar
   const int per = split_len(seq_len, nsplit);
   const int start = split * per;
   const int end = min(start + per, seq_len);
-  if (start >= end) return;
+  if (start >= end) {
+    if constexpr (MODE == 0) {  // an empty split still counts as arrived for the in-launch merge (uniform per workgroup)
+      if (p.merge_cnt) arrive_and_merge<T>(p, b, seq_len, nsplit, hchunks, smem);
+    }
+    return;
+  }
 
   const int a = lane & 15;  // MFMA n index: q head within the chunk
   const int g = lane >> 4;  // MFMA k/m group
@@ -356,9 +397,16 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attn_stage1(const DecodePar
       val += red_acc[(ww * 16 + h) * D + d] * sc;
     }
     const int64_t slot = ((int64_t)b * p.hq + (h0 + h)) * p.max_kv_splits + split;
-    p.attn_logits[slot * D + d] = val / L * p.v_scale;
-    if (d == 0) p.attn_lse[slot] = M * kLn2 + __logf(L);
+    const float ov = val / L * p.v_scale, lv = M * kLn2 + __logf(L);
+    if (p.merge_cnt) {  // in-launch merge: the partial is PUBLISHED -- write-through (sc1) stores, no release fence needed
+      __hip_atomic_store(p.attn_logits + slot * D + d, ov, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (d == 0) __hip_atomic_store(p.attn_lse + slot, lv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      p.attn_logits[slot * D + d] = ov;
+      if (d == 0) p.attn_lse[slot] = lv;
+    }
   }
+  if (p.merge_cnt) arrive_and_merge<T>(p, b, seq_len, nsplit, hchunks, smem);
 }
 
 // Any-head-dim fallback (D, Dv <= 256, not multiples of 32 allowed): one wave per
@@ -512,13 +560,14 @@ extern "C" int sgl_mi355_decode_attention_set_mode(int mode) {
   return SGL_MI355_OK;
 }
 
-extern "C" int sgl_mi355_decode_attention(
+static int decode_entry(
     const void* q, int64_t q_stride_t, const void* k_buffer, const void* v_buffer, int64_t k_stride_t,
     int64_t k_stride_h, int64_t v_stride_t, int64_t v_stride_h, void* o, int64_t o_stride_t, const int32_t* kv_indptr,
     const int32_t* kv_indices, const int32_t* req_to_token, int64_t req_to_token_stride, const int64_t* req_pool_indices,
     const int64_t* seq_lens, float* attn_logits, float* attn_lse, const int32_t* num_kv_splits, int max_kv_splits,
     int batch, int num_q_heads, int num_kv_heads, int head_dim, int v_head_dim, float sm_scale, float logit_cap,
-    int dtype, int kv_dtype, float k_scale, float v_scale, void* stream) {
+    int dtype, int kv_dtype, float k_scale, float v_scale, int32_t* merge_cnt, void* mq_o, void* mq_q, float* mq_s,
+    void* stream) {
   SGL_CHECK(batch >= 0, "decode_attention: negative batch %d", batch);
   if (batch == 0) return SGL_MI355_OK;
   SGL_CHECK(q && k_buffer && v_buffer, "decode_attention: null tensor pointer");  // o == NULL: split partials only
@@ -558,6 +607,42 @@ extern "C" int sgl_mi355_decode_attention(
   p.sm_scale = sm_scale; p.logit_cap = logit_cap;
   p.kv_fp8 = kv8 ? 1 : 0;
   p.k_scale = kv8 ? k_scale : 1.0f; p.v_scale = kv8 ? v_scale : 1.0f;
+  p.merge_cnt = merge_cnt; p.mq_o = mq_o; p.mq_q = mq_q; p.mq_s = mq_s;
+  if (merge_cnt != nullptr) {
+    SGL_CHECK(head_dim == v_head_dim && (head_dim == 128 || head_dim == 64) && g_decode_mode == 0,
+              "decode_attention_merge_quant: needs the MFMA kernel (head_dim 64 / 128) in its workgroup-per-split mode");
+    SGL_CHECK((mq_o || mq_q) && (!mq_q || mq_s) && (num_q_heads * v_head_dim) % 8 == 0 && num_q_heads * v_head_dim <= 16384,
+              "decode_attention_merge_quant: bad outputs or Hq*Dv=%d", num_q_heads * v_head_dim);
+  }
   hipStream_t st = (hipStream_t)stream;
   return dtype == SGL_BF16 ? launch_all<__bf16>(p, head_dim, st) : launch_all<_Float16>(p, head_dim, st);
+}
+
+extern "C" int sgl_mi355_decode_attention(
+    const void* q, int64_t q_stride_t, const void* k_buffer, const void* v_buffer, int64_t k_stride_t,
+    int64_t k_stride_h, int64_t v_stride_t, int64_t v_stride_h, void* o, int64_t o_stride_t, const int32_t* kv_indptr,
+    const int32_t* kv_indices, const int32_t* req_to_token, int64_t req_to_token_stride, const int64_t* req_pool_indices,
+    const int64_t* seq_lens, float* attn_logits, float* attn_lse, const int32_t* num_kv_splits, int max_kv_splits,
+    int batch, int num_q_heads, int num_kv_heads, int head_dim, int v_head_dim, float sm_scale, float logit_cap,
+    int dtype, int kv_dtype, float k_scale, float v_scale, void* stream) {
+  return decode_entry(q, q_stride_t, k_buffer, v_buffer, k_stride_t, k_stride_h, v_stride_t, v_stride_h, o, o_stride_t, kv_indptr,
+                      kv_indices, req_to_token, req_to_token_stride, req_pool_indices, seq_lens, attn_logits, attn_lse,
+                      num_kv_splits, max_kv_splits, batch, num_q_heads, num_kv_heads, head_dim, v_head_dim, sm_scale, logit_cap,
+                      dtype, kv_dtype, k_scale, v_scale, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+// Stage 1 with the in-launch stage 2: the last workgroup of each request merges its splits (out_o, optional) and quantises
+// the merged row per token (out_q / out_s, optional) -- decode_attention_fwd + sgl_per_token_quant_fp8 in ONE launch.
+// merge_counters: int32 [batch], zero on entry (they are left zero).
+extern "C" int sgl_mi355_decode_attention_merge_quant(
+    const void* q, int64_t q_stride_t, const void* k_buffer, const void* v_buffer, int64_t k_stride_t,
+    int64_t k_stride_h, int64_t v_stride_t, int64_t v_stride_h, const int32_t* kv_indptr, const int32_t* kv_indices,
+    float* attn_logits, float* attn_lse, const int32_t* num_kv_splits, int max_kv_splits, int batch, int num_q_heads,
+    int num_kv_heads, int head_dim, int v_head_dim, float sm_scale, float logit_cap, int dtype, int kv_dtype, float k_scale,
+    float v_scale, int32_t* merge_counters, void* out_o, void* out_q, float* out_s, void* stream) {
+  SGL_CHECK(merge_counters != nullptr && kv_indptr != nullptr, "decode_attention_merge_quant: null pointer");
+  return decode_entry(q, q_stride_t, k_buffer, v_buffer, k_stride_t, k_stride_h, v_stride_t, v_stride_h, nullptr, 0, kv_indptr,
+                      kv_indices, nullptr, 0, nullptr, nullptr, attn_logits, attn_lse, num_kv_splits, max_kv_splits, batch,
+                      num_q_heads, num_kv_heads, head_dim, v_head_dim, sm_scale, logit_cap, dtype, kv_dtype, k_scale, v_scale,
+                      merge_counters, out_o, out_q, out_s, stream);
 }

@@ -10,86 +10,9 @@
 //   decode_merge_quant_fp8      = decode stage-2 LSE merge -> sgl_per_token_quant_fp8
 //       (decode_attention.py:492-552)
 // All HBM/L2-bound byte work: one 256-thread workgroup per token, 16-byte accesses.
-#include "common.h"
+#include "row_helpers.h"
 
 namespace {
-
-constexpr float kFp8Max = 448.0f;
-
-template <typename T>
-struct V8 {
-  T v[8];
-};
-template <typename T>
-__device__ __forceinline__ V8<T> ld8(const T* p) {
-  return __builtin_bit_cast(V8<T>, *(const u32x4_t*)p);
-}
-template <typename T>
-__device__ __forceinline__ void st8(T* p, const V8<T>& x) {
-  *(u32x4_t*)p = __builtin_bit_cast(u32x4_t, x);
-}
-
-// f32 -> T -> f32 through the bit pattern (see elementwise.hip: the rounding point must really happen)
-template <typename T>
-__device__ __forceinline__ float round_via(float x) {
-  asm volatile("" : "+v"(x));  // x must exist as an f32 first: no v_fma_mix* single-rounding shortcut (the reference rounds twice)
-  const T t = (T)x;
-  const uint16_t u = __builtin_bit_cast(uint16_t, t);
-  uint16_t v;
-  asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "v"(u));
-  return (float)__builtin_bit_cast(T, v);
-}
-
-__device__ __forceinline__ u32x2_t pack8_fp8(const float (&f)[8]) {
-  int lo = 0, hi = 0;
-  lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
-  lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
-  hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
-  hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
-  return u32x2_t{(uint32_t)lo, (uint32_t)hi};
-}
-
-__device__ __forceinline__ float clamp448(float v) { return fmaxf(fminf(v, kFp8Max), -kFp8Max); }
-
-__device__ __forceinline__ float block_sum(float v, float* red) {
-  v = wave_reduce_sum(v);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  return red[0] + red[1] + red[2] + red[3];
-}
-__device__ __forceinline__ float block_max(float v, float* red) {
-  v = wave_reduce_max(v);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-}
-
-// per-token fp8 quantisation of the row held in vals (already rounded to T), exactly per_token_quant_fp8.cu
-template <int MAXV>
-__device__ __forceinline__ void quant_row(const float (&vals)[MAXV][8], int nvec, uint8_t* qrow, float* srow, float* red) {
-  float amax = 0.f;
-#pragma unroll
-  for (int it = 0; it < MAXV; ++it)
-    if ((int)threadIdx.x + it * 256 < nvec)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(vals[it][j]));
-  amax = block_max(amax, red);
-  const float scale = amax / kFp8Max;
-  if (threadIdx.x == 0) *srow = scale;
-  const float inv = (scale == 0.f) ? 0.f : 1.0f / scale;
-#pragma unroll
-  for (int it = 0; it < MAXV; ++it) {
-    const int i = threadIdx.x + it * 256;
-    if (i < nvec) {
-      float f[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) f[j] = clamp448(vals[it][j] * inv);
-      *(u32x2_t*)(qrow + i * 8) = pack8_fp8(f);
-    }
-  }
-}
 
 template <typename T, int MAXV, bool SLABS = true>  // SLABS = false drops the split-K registers: 4x the occupancy at prefill-sized M
 __global__ __launch_bounds__(256) void add_rmsnorm_quant_kernel(const T* x, const float* slabs_, int nslabs,
@@ -289,42 +212,7 @@ __global__ __launch_bounds__(256) void decode_merge_quant_kernel(const float* at
   const int b = blockIdx.x;
   const int seq_len = kv_indptr ? kv_indptr[b + 1] - kv_indptr[b] : (int)seq_lens[b];
   const int nsplit = max(1, min(num_kv_splits[b], max_kv_splits));
-  const int per0 = (seq_len + nsplit - 1) / nsplit;
-  const int per = (per0 + 31) / 32 * 32;
-  const int row_elems = hq * dv, nvec = row_elems / 8;
-  float vals[MAXV][8];
-#pragma unroll
-  for (int it = 0; it < MAXV; ++it) {
-    const int i = threadIdx.x + it * 256;
-    if (i < nvec) {
-      const int e0 = i * 8, h = e0 / dv, d0 = e0 - h * dv;
-      const int64_t slot0 = ((int64_t)b * hq + h) * max_kv_splits;
-      LseMerge mg;
-      float acc[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-      for (int sI = 0; sI < nsplit; ++sI) {
-        if (sI * per < seq_len) {
-          mg.begin(attn_lse[slot0 + sI]);
-          const float* lp = attn_logits + (slot0 + sI) * dv + d0;
-          const f32x4_t a0 = *(const f32x4_t*)lp, a1 = *(const f32x4_t*)(lp + 4);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            acc[j] = mg.acc(acc[j], a0[j]);
-            acc[4 + j] = mg.acc(acc[4 + j], a1[j]);
-          }
-        }
-      }
-      V8<T> o;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        vals[it][j] = round_via<T>(mg.finish(acc[j]));
-        o.v[j] = (T)vals[it][j];
-      }
-      if (out_o) st8(out_o + (int64_t)b * row_elems + e0, o);
-    }
-  }
-  if (out_q) quant_row<MAXV>(vals, nvec, out_q + (int64_t)b * row_elems, out_s + b, red);
+  merge_quant_row<T, MAXV>(b, attn_logits, attn_lse, seq_len, nsplit, max_kv_splits, hq, dv, out_o, out_q, out_s, red);
 }
 
 // vectorised greedy argmax: first index of the row maximum

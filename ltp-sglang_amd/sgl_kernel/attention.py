@@ -164,6 +164,29 @@ def extend_attention(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer,
     )
 
 
+def decode_attention_merge_quant(q, k_buffer, v_buffer, kv_indptr, kv_indices, attn_logits, attn_lse, num_kv_splits, max_kv_splits,
+                                 sm_scale, merge_counters, logit_cap=0.0, k_scale=1.0, v_scale=1.0, want_o=False, want_quant=True):
+    """decode_attention_fwd + the stage-2 merge + sgl_per_token_quant_fp8 of the merged rows in ONE launch (the last workgroup
+    of each request to finish does the merge).  merge_counters: int32 [>= bs], zero on entry, left zero.
+    Returns (o or None, o_q fp8 [bs, Hq*Dv] or None, o_scale f32 [bs, 1] or None)."""
+    _require_cuda(q, k_buffer, v_buffer, kv_indptr, kv_indices, attn_logits, attn_lse, num_kv_splits, merge_counters)
+    bs, hq, d = q.shape
+    hkv, dv = v_buffer.shape[1], v_buffer.shape[2]
+    assert merge_counters.dtype == torch.int32 and merge_counters.numel() >= bs and max_kv_splits == attn_logits.shape[2]
+    assert q.stride(2) == 1 and q.stride(1) == d and attn_logits.is_contiguous() and attn_lse.is_contiguous()
+    kst, ksh = _row_strides(k_buffer)
+    vst, vsh = _row_strides(v_buffer)
+    o = torch.empty((bs, hq * dv), dtype=q.dtype, device=q.device) if want_o else None
+    oq = torch.empty((bs, hq * dv), dtype=torch.float8_e4m3fn, device=q.device) if want_quant else None
+    osc = torch.empty((bs, 1), dtype=torch.float32, device=q.device) if want_quant else None
+    check(lib.sgl_mi355_decode_attention_merge_quant(
+        ptr(q), q.stride(0), ptr(k_buffer), ptr(v_buffer), kst, ksh, vst, vsh, ptr(kv_indptr), ptr(kv_indices), ptr(attn_logits),
+        ptr(attn_lse), ptr(num_kv_splits), int(max_kv_splits), bs, hq, hkv, d, dv, float(sm_scale), float(logit_cap),
+        dtype_code(q.dtype), dtype_code(k_buffer.dtype), float(k_scale), float(v_scale), ptr(merge_counters), ptr(o), ptr(oq),
+        ptr(osc), current_stream()))
+    return o, oq, osc
+
+
 def merge_state(v_a: torch.Tensor, s_a: torch.Tensor, v_b: torch.Tensor, s_b: torch.Tensor,
                 v_merged: Optional[torch.Tensor] = None, s_merged: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """LSE-weighted merge of two attention partials (sgl_kernel.merge_state, attention.py:12-28): v [n, h, d], s [n, h]."""

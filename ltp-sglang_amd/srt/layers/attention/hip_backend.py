@@ -69,6 +69,9 @@ class HipAttnBackend(AttentionBackend):
         self.device_core_count = lib.sgl_mi355_device_cu_count(int(gpu_id))  # 256 on MI355X
         self.forward_metadata: Optional[ForwardMetadata] = None
         self._graph = None
+        # counters of the in-launch stage-2 merge (one per request slot; allocated eagerly so graph capture never allocates)
+        self.max_bs_hint = int(model_runner.req_to_token_pool.size)
+        self._merge_counters = torch.zeros(self.max_bs_hint, dtype=torch.int32, device=self.device)
 
     # ------------------------------------------------------------------ metadata
     def _decode_metadata(self, bs, req_pool_indices, seq_lens, seq_lens_sum, kv_indices=None, scratch=None):
@@ -194,6 +197,22 @@ class HipAttnBackend(AttentionBackend):
             layer.scaling, layer.logit_cap, layer.k_scale_float or 1.0, layer.v_scale_float or 1.0,
         )
         return md
+
+    def forward_decode_merged_quant(self, q, layer, forward_batch, want_o=False):
+        """Stage 1 + in-launch stage 2 + per-token fp8 quantisation of the merged rows (the attention -> o_proj hand-off of the
+        w8a8 decode step in one kernel).  Returns (o or None, o_q, o_scale)."""
+        self._check_layer(layer)
+        md = self.forward_metadata
+        if self._merge_counters is None or self._merge_counters.device != q.device:
+            self._merge_counters = torch.zeros(max(self.max_bs_hint, q.shape[0]), dtype=torch.int32, device=q.device)
+        if self._merge_counters.numel() < q.shape[0]:
+            self._merge_counters = torch.zeros(q.shape[0], dtype=torch.int32, device=q.device)
+        return K.decode_attention_merge_quant(
+            q.reshape(-1, layer.tp_q_head_num, layer.qk_head_dim),
+            forward_batch.token_to_kv_pool.get_key_buffer(layer.layer_id),
+            forward_batch.token_to_kv_pool.get_value_buffer(layer.layer_id),
+            md.kv_indptr, md.kv_indices, md.attn_logits, md.attn_lse, md.num_kv_splits, self.max_kv_splits, layer.scaling,
+            self._merge_counters, layer.logit_cap, layer.k_scale_float or 1.0, layer.v_scale_float or 1.0, want_o=want_o)
 
     def support_triton(self):
         return False  # the host helpers use this build's HIP index kernels, never Triton

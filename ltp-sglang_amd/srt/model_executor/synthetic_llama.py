@@ -133,6 +133,7 @@ class LlamaForCausalLM(nn.Module):
         self.cfg, self.dtype = cfg, dtype
         self.fused_decode = True
         self.fused_extend = True
+        self.fused_attn_merge = True   # decode: stage-2 merge + quant by the last-arriving workgroup of each request
         self.fused_epilogues = True
         qc = None
         if quantization is not None:
@@ -257,9 +258,12 @@ class LlamaForCausalLM(nn.Module):
                 else:
                     K.rope_set_kv(positions, q, k, v, attn.head_dim, attn.rotary_emb.cos_sin_cache, True,
                                   pool.get_key_buffer(lid), pool.get_value_buffer(lid), forward_batch.out_cache_loc)
-            md = backend.forward_decode_partial(q, attn.attn, forward_batch)
-            _, oq, osc = K.decode_merge_quant_fp8(md.attn_logits, md.attn_lse, md.kv_indptr, md.num_kv_splits,
-                                                  backend.max_kv_splits, self.dtype)
+            if self.fused_attn_merge and attn.head_dim in (64, 128):
+                _, oq, osc = backend.forward_decode_merged_quant(q, attn.attn, forward_batch)   # stage 2 inside the launch
+            else:
+                md = backend.forward_decode_partial(q, attn.attn, forward_batch)
+                _, oq, osc = K.decode_merge_quant_fp8(md.attn_logits, md.attn_lse, md.kv_indptr, md.num_kv_splits,
+                                                      backend.max_kv_splits, self.dtype)
             attn_out = K.fp8_scaled_mm(oq, attn.o_proj.weight, osc.view(-1), attn.o_proj.weight_scale.view(-1), self.dtype)
             if tp > 1:
                 attn_out = tensor_model_parallel_all_reduce(attn_out)

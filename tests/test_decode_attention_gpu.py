@@ -164,3 +164,39 @@ def test_merge_state_vs_reference_restatement(dtype, n, h, d, pkg):
     torch.testing.assert_close(vo.cpu().float(), rv, rtol=tol, atol=tol)   # (bf16 output rounding alone is 2^-9 relative)
     assert torch.allclose(so.cpu(), rs, rtol=1e-5, atol=1e-5)
     assert torch.equal(vo, vo2) and torch.equal(so, so2)
+
+
+@pytest.mark.parametrize("dtype,d,kv8", [("bf16", 128, False), ("f16", 64, False), ("bf16", 128, True)])
+def test_in_launch_merge_quant_bit_identical_to_two_kernels(dtype, d, kv8, pkg):
+    """decode_attention_merge_quant (stage 2 by the last-arriving workgroup of each request) == stage 1 + decode_merge_quant_fp8,
+    bit for bit, over ragged lengths / split counts incl. splits that receive no token; run 20 times back to back on the same
+    counters (they must come back to zero) and scratch buffers (stale lines of the previous run must not be read)."""
+    from ltp_sglang_amd import sgl_kernel
+
+    case = dict(name="mq", kind="decode", dtype=dtype, hq=16, hkv=4, d=d, seq=[1, 33, 257, 64, 700, 5, 1024, 96])
+    c = _cases.build_attn_case(case, seed=21)
+    dev = torch.device("cuda:0")
+    bs, hq = c["bs"], c["hq"]
+    kv_indptr, kv_indices = _kv_meta(c)
+    kb, vb = c["k_buffer"], c["v_buffer"]
+    if kv8:
+        kb, vb = kb.to(torch.float8_e4m3fn), vb.to(torch.float8_e4m3fn)
+    kb, vb = kb.to(dev), vb.to(dev)
+    max_splits = 8
+    splits = torch.tensor([1, 8, 5, 2, 8, 3, 4, 8], dtype=torch.int32, device=dev)   # 33 tokens / 8 splits: empty splits
+    counters = torch.zeros(bs, dtype=torch.int32, device=dev)
+    ip, ii = kv_indptr.to(dev), kv_indices.to(dev)
+    la = torch.empty(bs, hq, max_splits, d, dtype=torch.float32, device=dev)
+    lb = torch.empty_like(la)
+    sa = torch.empty(bs, hq, max_splits, dtype=torch.float32, device=dev)
+    sb = torch.empty_like(sa)
+    g = torch.Generator().manual_seed(5)
+    for it in range(20):
+        q = torch.randn(bs, hq, d, generator=g).to(c["dtype"]).to(dev)
+        sgl_kernel.decode_attention_fwd(q, kb, vb, None, ip, ii, la, sa, splits, max_splits, c["scaling"])
+        o_ref, q_ref, s_ref = sgl_kernel.decode_merge_quant_fp8(la, sa, ip, splits, max_splits, c["dtype"], want_o=True)
+        o, oq, osc = sgl_kernel.decode_attention_merge_quant(q, kb, vb, ip, ii, lb, sb, splits, max_splits, c["scaling"], counters,
+                                                             want_o=True)
+        assert torch.equal(o, o_ref), it
+        assert torch.equal(oq.view(torch.uint8), q_ref.view(torch.uint8)) and torch.equal(osc, s_ref), it
+        assert int(counters.abs().sum()) == 0
