@@ -171,6 +171,8 @@ int sgl_mi355_skinny_gemm(const void* x, int64_t x_stride_elems, const void* w, 
 int sgl_mi355_skinny_gemm_num_kranges(int M, int N, int K, int in_dtype);
 /* Producer half of the launch-boundary split-K reduce: raw f32 partial sums [kranges, M, N], scales left to the consumer
  * (sgl_mi355_fused_add_rmsnorm_quant_fp8 with slabs != NULL). fp8, M <= 64. */
+/* how many slabs the next function writes (the same k-range partition as sgl_mi355_skinny_gemm's, so both sum identically) */
+int sgl_mi355_skinny_gemm_slabs_count(int M, int K);
 int sgl_mi355_skinny_gemm_slabs(const void* x, int64_t x_stride_elems, const void* w, int64_t w_stride_elems, float* slabs,
                                 int M, int N, int K, int in_dtype, void* stream);
 

@@ -444,7 +444,10 @@ inline int v2_kranges(const SkinnyParams& p, int* ds_out) {
   int ds;
   if (p.kbytes <= 1024) ds = 2;
   else if (p.kbytes <= 2048) ds = 4;
-  else ds = (p.kbytes <= 4096 || p.M > 32) ? 8 : 16;  // (MT = 4 keeps 128 VGPRs of X fragments: 512 B of K per wave at most)
+  // 1 KiB of K per wave only where it makes ONE k-range (4 KiB < K <= 8 KiB, M <= 32: no slabs at all); beyond that more, smaller
+  // k-ranges halve the X bytes every workgroup stages (K = 14336: 4 ranges of 4 KiB instead of 2 of 8 KiB, 17.0 -> 14.5 us).
+  // MT = 4 keeps 128 VGPRs of X fragments: 512 B of K per wave at most.
+  else ds = (p.kbytes <= 4096 || p.M > 32 || p.kbytes > 8192) ? 8 : 16;
   if (p.kbytes % 64 != 0) return 0;
   *ds_out = ds;
   const int range = kV2Waves * ds * 64;
@@ -523,8 +526,15 @@ extern "C" int sgl_mi355_skinny_gemm_num_kranges(int M, int N, int K, int in_dty
   if (M > 64 || g_skinny_force_v1) return 0;
   const int kbytes = K * (in_dtype == SGL_FP8_E4M3 ? 1 : 2);
   if (kbytes % 64 != 0 || kbytes <= 4096) return kbytes % 64 == 0 ? 1 : 0;
-  const int range = M > 32 ? 4096 : 8192;  // K bytes one workgroup covers
+  const int range = (M > 32 || kbytes > 8192) ? 4096 : 8192;  // K bytes one workgroup covers
   return (kbytes + range - 1) / range;
+}
+
+// number of f32 [M, N] slabs sgl_mi355_skinny_gemm_slabs writes for this K (fp8)
+extern "C" int sgl_mi355_skinny_gemm_slabs_count(int M, int K) {
+  const int ds = K <= 1024 ? 2 : (K <= 2048 ? 4 : ((K <= 4096 || M > 32 || K > 8192) ? 8 : 16));
+  const int range = kV2Waves * ds * 64;
+  return (K + range - 1) / range;
 }
 
 extern "C" int sgl_mi355_skinny_gemm(const void* x, int64_t x_stride_elems, const void* w, int64_t w_stride_elems, void* y,
@@ -574,7 +584,7 @@ extern "C" int sgl_mi355_skinny_gemm_slabs(const void* x, int64_t x_stride_elems
   p.y = nullptr; p.y_stride = 0;
   p.sx = nullptr; p.sw = nullptr; p.bias = nullptr;  // slab mode never reads scales or bias
   p.M = M; p.N = N; p.K = K; p.kbytes = K;
-  const int ds = K <= 1024 ? 2 : (K <= 2048 ? 4 : ((K <= 4096 || M > 32) ? 8 : 16));
+  const int ds = K <= 1024 ? 2 : (K <= 2048 ? 4 : ((K <= 4096 || M > 32 || K > 8192) ? 8 : 16));  // = sgl_mi355_skinny_gemm's choice
   const int range = kV2Waves * ds * 64;
   const int kranges = (K + range - 1) / range;
   hipStream_t st = (hipStream_t)stream;

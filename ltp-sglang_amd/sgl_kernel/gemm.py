@@ -169,9 +169,7 @@ def fp8_linear_slabs(x_q: torch.Tensor, weight_nk: torch.Tensor, m: int, n: int,
     """Raw f32 split-K partial sums [S, M, N] of x_q[M,K] @ weight_nk[N,K]^T (no scales): the producer half of the
     launch-boundary split-K reduce; the consumer (fused_add_rmsnorm_quant_fp8 with ``slabs=``) applies the scales."""
     _cuda(x_q, weight_nk)
-    kr = lib.sgl_mi355_skinny_gemm_num_kranges(m, n, k, dtype_code(x_q.dtype))
-    if kr < 1:
-        raise RuntimeError("fp8_linear_slabs: shape not supported by the split-K kernel")
+    kr = lib.sgl_mi355_skinny_gemm_slabs_count(m, k)
     if out is None:
         out = torch.empty((kr, m, n), dtype=torch.float32, device=x_q.device)
     check(lib.sgl_mi355_skinny_gemm_slabs(ptr(x_q), x_q.stride(0), ptr(weight_nk), weight_nk.stride(0), ptr(out), m, n, k,

@@ -450,7 +450,7 @@ def test_fused_rmsnorm_from_splitk_slabs_bit_exact(sk, pkg):
     s1 = torch.empty(32, 1, dtype=torch.float32, device=DEV)
     sk.sgl_per_token_quant_fp8(y, q1, s1)
     slabs = sk.fp8_linear_slabs(a, wt, 32, 512, 14336)
-    assert slabs.shape[0] == 2
+    assert slabs.shape[0] == 4   # K = 14336: four 4 KiB k-ranges, the same partition fp8_scaled_mm sums over
     r2 = res.clone()
     y2, q2, s2 = sk.fused_add_rmsnorm_quant_fp8(None, r2, nw, 1e-5, slabs=slabs, slab_sx=sa, slab_sw=sb, want_norm=True)
     assert torch.equal(r1, r2) and torch.equal(y, y2) and torch.equal(s1, s2) and torch.equal(q1.view(torch.uint8), q2.view(torch.uint8))
