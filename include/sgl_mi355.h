@@ -227,7 +227,7 @@ int sgl_mi355_fused_add_rmsnorm_quant_fp8(const void* x, const float* slabs, int
  * (8 gate rows, 8 up rows).  act [M, N/2]. */
 int sgl_mi355_fp8_gemm_silu_mul(const void* x, int64_t x_stride_elems, const void* w_interleaved, int64_t w_stride_elems,
                                 void* act, int64_t act_stride_elems, const float* scales_x,
-                                const float* scales_w_interleaved, int M, int N, int K, int out_dtype, void* stream);
+                                const float* scales_w_interleaved, int M, int N, int K, int out_dtype, int tile_rows, void* stream);
 /* qkv_proj (fp8_scaled_mm) + neox RoPE (rotary_embedding.py:49-72) + set_kv_buffer (memory_pool.py:401-407) in one launch
  * (models/llama.py:180-191); rows interleaved inside every q/k head so rotation pairs share a 16-row tile. */
 int sgl_mi355_fp8_qkv_rope_set_kv(const void* x, int64_t x_stride_elems, const void* w_interleaved, int64_t w_stride_elems,
@@ -235,7 +235,8 @@ int sgl_mi355_fp8_qkv_rope_set_kv(const void* x, int64_t x_stride_elems, const v
                                   const float* scales_w_interleaved, const void* bias_interleaved,
                                   const int64_t* positions, const float* cos_sin_cache, const int64_t* loc, void* k_buffer,
                                   void* v_buffer, int64_t k_slot_stride, int64_t v_slot_stride, int M, int num_q_heads,
-                                  int num_kv_heads, int head_dim, int K, int out_dtype, void* stream);
+                                  int num_kv_heads, int head_dim, int K, int out_dtype, int tile_rows,
+                                  void* stream);
 /* silu_and_mul (activation.py:60-63) -> sgl_per_token_quant_fp8 */
 int sgl_mi355_silu_and_mul_quant_fp8(const void* x, void* out_q, float* out_s, int tokens, int d, int dtype, void* stream);
 /* rotary_embedding (rotary_embedding.py:138-165) on q, k in place -> set_kv_buffer (memory_pool.py:369-407) of (k, v) */

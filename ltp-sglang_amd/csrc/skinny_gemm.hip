@@ -371,22 +371,24 @@ __global__ __launch_bounds__(NWV * 64, 1) void skinny_gemm_v2_kernel(const Skinn
             if (live) ((OutT*)p.y)[(int64_t)em * p.y_stride + n0 + en] = (OutT)v;
           } else {
             const float vr = rnd_to<OutT>(v);             // the GEMM's own output rounding
-            const float pr = __shfl_xor(vr, 8, WAVE);     // the partner column of the same row m
+            const int H = rpt >> 1;                       // rows of each half of an interleaved tile (8, or 4 for 8-row tiles)
+            const float pr = __shfl_xor(vr, H, WAVE);     // the partner column of the same row m
+            const bool lo = (en & H) == 0;                // first half of the tile (gate / rotation-pair index i)
             if constexpr (EPI == EPI_SILU) {
-              if (live && en < 8) {
+              if (live && lo) {
                 const float sg = rnd_to<OutT>(vr / (1.0f + expf(-vr)));
                 ((OutT*)p.y)[(int64_t)em * p.y_stride + (n0 >> 1) + en] = (OutT)rnd_to<OutT>(sg * pr);
               }
             } else {
-              const int head = n0 >> 7, u = (n0 & 127) >> 4;
+              const int head = n0 >> 7, u = (n0 & 127) / rpt;
               if (live) {
                 if (head < ep.hq + ep.hkv) {
-                  const int i = 8 * u + (en & 7);
+                  const int i = H * u + (en & (H - 1));
                   const float* cs = ep.cos_sin + ep_pos[e] * 128;
                   const float c = rnd_to<OutT>(cs[i]), sn = rnd_to<OutT>(cs[64 + i]);
-                  const float x1 = en < 8 ? vr : pr, x2 = en < 8 ? pr : vr;
-                  const float o = en < 8 ? rnd_to<OutT>(x1 * c) - rnd_to<OutT>(x2 * sn) : rnd_to<OutT>(x2 * c) + rnd_to<OutT>(x1 * sn);
-                  const int col = i + (en < 8 ? 0 : 64);
+                  const float x1 = lo ? vr : pr, x2 = lo ? pr : vr;
+                  const float o = lo ? rnd_to<OutT>(x1 * c) - rnd_to<OutT>(x2 * sn) : rnd_to<OutT>(x2 * c) + rnd_to<OutT>(x1 * sn);
+                  const int col = i + (lo ? 0 : 64);
                   if (head < ep.hq)
                     ((OutT*)p.y)[(int64_t)em * p.y_stride + head * 128 + col] = (OutT)o;
                   else
@@ -595,29 +597,30 @@ extern "C" int sgl_mi355_skinny_gemm_slabs(const void* x, int64_t x_stride_elems
 
 namespace {
 template <int MT, int DS, typename OutT, int EPI>
-int launch_v2_epi(const SkinnyParams& p, const EpiParams& ep, hipStream_t st) {
+int launch_v2_epi(const SkinnyParams& p, const EpiParams& ep, int rpt, hipStream_t st) {
   const int cus = v2_cus();
-  const int ntiles = p.N / 16;
+  const int ntiles = p.N / rpt;
   const int gx = ntiles < cus ? ntiles : cus;
   if (ntiles <= gx)
-    hipLaunchKernelGGL((skinny_gemm_v2_kernel<ES_FP8, MT, DS, 1, 1, OutT, EPI>), dim3(gx, 1), dim3(kV2Waves * 64), 0, st, p, 16,
+    hipLaunchKernelGGL((skinny_gemm_v2_kernel<ES_FP8, MT, DS, 1, 1, OutT, EPI>), dim3(gx, 1), dim3(kV2Waves * 64), 0, st, p, rpt,
                        ntiles, (float*)nullptr, ep);
   else
     hipLaunchKernelGGL((skinny_gemm_v2_kernel<ES_FP8, MT, DS, 1, (MT >= 4 ? 2 : 4), OutT, EPI>), dim3(gx, 1), dim3(kV2Waves * 64), 0, st,
-                       p, 16, ntiles, (float*)nullptr, ep);
+                       p, rpt, ntiles, (float*)nullptr, ep);
   SGL_HIP_LAUNCH_CHECK();
   return SGL_MI355_OK;
 }
 
 template <int EPI>
-int run_epi(SkinnyParams& p, const EpiParams& ep, int out_dtype, hipStream_t st, const char* who) {
+int run_epi(SkinnyParams& p, const EpiParams& ep, int out_dtype, int tile_rows, hipStream_t st, const char* who) {
+  SGL_CHECK(tile_rows == 16 || tile_rows == 8, "%s: tile_rows must be 16 or 8 (got %d)", who, tile_rows);
   SGL_CHECK(p.M > 0 && p.M <= 64, "%s: needs 0 < M <= 64 (got %d)", who, p.M);
   SGL_CHECK(p.kbytes % 64 == 0 && p.kbytes <= 4096, "%s: K=%d must be a multiple of 64 and <= 4096 (single k-range)", who, p.kbytes);
   SGL_CHECK(p.N % 16 == 0 && (int64_t)p.N * p.w_stride < 0xFFFFFFF0ll, "%s: N=%d must be a multiple of 16", who, p.N);
   SGL_CHECK(out_dtype == SGL_BF16 || out_dtype == SGL_F16, "%s: out_dtype must be bf16 or f16", who);
   const int ds = p.kbytes <= 1024 ? 2 : (p.kbytes <= 2048 ? 4 : 8);
 #define SGL_EPI_CASE(MTv, DSv)                                                                                          \
-  return out_dtype == SGL_BF16 ? launch_v2_epi<MTv, DSv, __bf16, EPI>(p, ep, st) : launch_v2_epi<MTv, DSv, _Float16, EPI>(p, ep, st)
+  return out_dtype == SGL_BF16 ? launch_v2_epi<MTv, DSv, __bf16, EPI>(p, ep, tile_rows, st) : launch_v2_epi<MTv, DSv, _Float16, EPI>(p, ep, tile_rows, st)
   if (p.M <= 16) {
     if (ds == 8) { SGL_EPI_CASE(1, 8); }
     if (ds == 4) { SGL_EPI_CASE(1, 4); }
@@ -636,11 +639,12 @@ int run_epi(SkinnyParams& p, const EpiParams& ep, int out_dtype, hipStream_t st,
 }  // namespace
 
 // act[M, N/2] = T(T(silu(g)) * u) with [g | u] = fp8_scaled_mm(x, w_interleaved) -- gate_up_proj + SiluAndMul in one launch.
-// w_interleaved [N, K] / scales_w [N]: tile t of 16 rows = gate rows 8t..8t+7 then up rows 8t..8t+7.
+// w_interleaved [N, K] / scales_w [N]: tile t of tile_rows = 2 H rows (16 or 8) = gate rows H t .. H t + H - 1 then the up rows
+// of the same indices.  8-row tiles balance the workgroups when N / 16 is between one and a few times the CU count.
 extern "C" int sgl_mi355_fp8_gemm_silu_mul(const void* x, int64_t x_stride_elems, const void* w_interleaved,
                                            int64_t w_stride_elems, void* act, int64_t act_stride_elems,
                                            const float* scales_x, const float* scales_w_interleaved, int M, int N, int K,
-                                           int out_dtype, void* stream) {
+                                           int out_dtype, int tile_rows, void* stream) {
   SGL_CHECK(x && w_interleaved && act && scales_x && scales_w_interleaved, "fp8_gemm_silu_mul: null pointer");
   SGL_CHECK(((uintptr_t)x % 16) == 0 && ((uintptr_t)w_interleaved % 16) == 0 && x_stride_elems % 16 == 0 && w_stride_elems % 16 == 0,
             "fp8_gemm_silu_mul: rows must be 16-byte aligned");
@@ -648,11 +652,11 @@ extern "C" int sgl_mi355_fp8_gemm_silu_mul(const void* x, int64_t x_stride_elems
   p.x = (const char*)x; p.x_stride = x_stride_elems; p.w = (const char*)w_interleaved; p.w_stride = w_stride_elems;
   p.y = act; p.y_stride = act_stride_elems; p.sx = scales_x; p.sw = scales_w_interleaved; p.bias = nullptr;
   p.M = M; p.N = N; p.K = K; p.kbytes = K;
-  return run_epi<EPI_SILU>(p, EpiParams{}, out_dtype, (hipStream_t)stream, "fp8_gemm_silu_mul");
+  return run_epi<EPI_SILU>(p, EpiParams{}, out_dtype, tile_rows, (hipStream_t)stream, "fp8_gemm_silu_mul");
 }
 
 // qkv_proj + neox rotary embedding + set_kv_buffer in one launch.  w_interleaved / scales / bias rows: inside every q and k
-// head (128 rows) tile u = rows 8u..8u+7 then rows 64+8u..64+8u+7; v heads in natural order.  q (rotated) -> q_out
+// head (128 rows) tile u of tile_rows = 2 H rows = rows H u .. H u + H - 1 then rows 64 + H u ..; v heads in natural order.  q (rotated) -> q_out
 // [M, Hq*128]; k (rotated) and v -> pool rows loc[m] of k_buffer / v_buffer ([slots, Hkv, 128], strides in elements).
 extern "C" int sgl_mi355_fp8_qkv_rope_set_kv(const void* x, int64_t x_stride_elems, const void* w_interleaved,
                                              int64_t w_stride_elems, void* q_out, int64_t q_stride_elems,
@@ -660,7 +664,8 @@ extern "C" int sgl_mi355_fp8_qkv_rope_set_kv(const void* x, int64_t x_stride_ele
                                              const void* bias_interleaved, const int64_t* positions,
                                              const float* cos_sin_cache, const int64_t* loc, void* k_buffer, void* v_buffer,
                                              int64_t k_slot_stride, int64_t v_slot_stride, int M, int num_q_heads,
-                                             int num_kv_heads, int head_dim, int K, int out_dtype, void* stream) {
+                                             int num_kv_heads, int head_dim, int K, int out_dtype, int tile_rows,
+                                             void* stream) {
   SGL_CHECK(x && w_interleaved && q_out && scales_x && scales_w_interleaved && positions && cos_sin_cache && loc && k_buffer && v_buffer,
             "fp8_qkv_rope_set_kv: null pointer");
   SGL_CHECK(head_dim == 128, "fp8_qkv_rope_set_kv: head_dim (= rotary_dim) must be 128, got %d", head_dim);
@@ -673,5 +678,5 @@ extern "C" int sgl_mi355_fp8_qkv_rope_set_kv(const void* x, int64_t x_stride_ele
   EpiParams ep;
   ep.positions = positions; ep.cos_sin = cos_sin_cache; ep.loc = loc; ep.k_buf = k_buffer; ep.v_buf = v_buffer;
   ep.k_slot_stride = k_slot_stride; ep.v_slot_stride = v_slot_stride; ep.hq = num_q_heads; ep.hkv = num_kv_heads;
-  return run_epi<EPI_ROPE>(p, ep, out_dtype, (hipStream_t)stream, "fp8_qkv_rope_set_kv");
+  return run_epi<EPI_ROPE>(p, ep, out_dtype, tile_rows, (hipStream_t)stream, "fp8_qkv_rope_set_kv");
 }

@@ -16,6 +16,7 @@ from .elementwise import (
 )
 from .fused import (
     decode_merge_quant_fp8,
+    balanced_tile_rows,
     fp8_gemm_silu_mul,
     fp8_qkv_rope_set_kv,
     fused_add_rmsnorm_quant_fp8,

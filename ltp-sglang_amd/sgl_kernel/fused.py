@@ -64,36 +64,37 @@ def decode_merge_quant_fp8(attn_logits, attn_lse, kv_indptr, num_kv_splits, max_
     return out_o, out_q, out_s
 
 
-def interleave_gate_up_rows(t: torch.Tensor) -> torch.Tensor:
-    """[2I, ...] (gate rows then up rows) -> 16-row tiles of (8 gate rows, 8 up rows); for weights, scales, biases."""
-    two_i = t.shape[0]
-    assert two_i % 16 == 0
+def interleave_gate_up_rows(t: torch.Tensor, tile_rows: int = 16) -> torch.Tensor:
+    """[2I, ...] (gate rows then up rows) -> tiles of tile_rows = 2H rows: (H gate rows, H up rows); weights, scales, biases."""
+    two_i, h = t.shape[0], tile_rows // 2
+    assert two_i % tile_rows == 0 and tile_rows in (8, 16)
     rest = t.shape[1:]
-    return t.reshape(2, two_i // 16, 8, *rest).transpose(0, 1).reshape(two_i, *rest).contiguous()
+    return t.reshape(2, two_i // tile_rows, h, *rest).transpose(0, 1).reshape(two_i, *rest).contiguous()
 
 
-def interleave_rope_rows(t: torch.Tensor, num_q_heads: int, num_kv_heads: int, head_dim: int = 128) -> torch.Tensor:
-    """[(Hq + 2 Hkv) * 128, ...] -> inside every q/k head, 16-row tiles of (rows 8u..8u+7, rows 64+8u..64+8u+7)."""
-    assert head_dim == 128
+def interleave_rope_rows(t: torch.Tensor, num_q_heads: int, num_kv_heads: int, head_dim: int = 128, tile_rows: int = 16) -> torch.Tensor:
+    """[(Hq + 2 Hkv) * 128, ...] -> inside every q/k head, tiles of tile_rows = 2H rows: (rows Hu..Hu+H-1, rows 64+Hu..)."""
+    assert head_dim == 128 and tile_rows in (8, 16)
     rest = t.shape[1:]
+    h = tile_rows // 2
     nrope = (num_q_heads + num_kv_heads) * head_dim
-    qk = t[:nrope].reshape(num_q_heads + num_kv_heads, 2, 8, 8, *rest).transpose(1, 2).reshape(nrope, *rest)
+    qk = t[:nrope].reshape(num_q_heads + num_kv_heads, 2, 64 // h, h, *rest).transpose(1, 2).reshape(nrope, *rest)
     return torch.cat([qk, t[nrope:]], dim=0).contiguous()
 
 
-def fp8_gemm_silu_mul(x_q, x_s, w_interleaved_nk, w_s_interleaved, out_dtype):
+def fp8_gemm_silu_mul(x_q, x_s, w_interleaved_nk, w_s_interleaved, out_dtype, tile_rows: int = 16):
     """act [M, I] = SiluAndMul(fp8_scaled_mm(x_q, W)) with W's rows interleaved by interleave_gate_up_rows."""
     m, k = x_q.shape
     n = w_interleaved_nk.shape[0]
     act = torch.empty((m, n // 2), dtype=out_dtype, device=x_q.device)
     check(lib.sgl_mi355_fp8_gemm_silu_mul(ptr(x_q), x_q.stride(0), ptr(w_interleaved_nk), w_interleaved_nk.stride(0), ptr(act),
                                           act.stride(0), ptr(x_s), ptr(w_s_interleaved), m, n, k, dtype_code(out_dtype),
-                                          current_stream()))
+                                          int(tile_rows), current_stream()))
     return act
 
 
 def fp8_qkv_rope_set_kv(x_q, x_s, w_interleaved_nk, w_s_interleaved, bias_interleaved, positions, cos_sin_cache, loc, k_buffer,
-                        v_buffer, num_q_heads, num_kv_heads, head_dim, out_dtype):
+                        v_buffer, num_q_heads, num_kv_heads, head_dim, out_dtype, tile_rows: int = 16):
     """q [M, Hq*D] (rotated); rotated k and v are written to pool rows ``loc`` of k_buffer / v_buffer."""
     m, k = x_q.shape
     q = torch.empty((m, num_q_heads * head_dim), dtype=out_dtype, device=x_q.device)
@@ -102,5 +103,14 @@ def fp8_qkv_rope_set_kv(x_q, x_s, w_interleaved_nk, w_s_interleaved, bias_interl
                                             q.stride(0), ptr(x_s), ptr(w_s_interleaved), ptr(bias_interleaved), ptr(positions),
                                             ptr(cos_sin_cache), ptr(loc), ptr(k_buffer), ptr(v_buffer), k_buffer.stride(0),
                                             v_buffer.stride(0), m, num_q_heads, num_kv_heads, head_dim, k,
-                                            dtype_code(out_dtype), current_stream()))
+                                            dtype_code(out_dtype), int(tile_rows), current_stream()))
     return q
+
+
+def balanced_tile_rows(n_rows: int) -> int:
+    """16-row tiles, or 8-row tiles when 16-row tiles would leave the last round of the persistent workgroups mostly idle (the
+    rule of the plain skinny GEMM's launcher): e.g. qkv_proj of Llama-3-8B, 384 tiles on 256 CUs."""
+    cus = lib.sgl_mi355_device_cu_count(torch.cuda.current_device())
+    t16 = n_rows // 16
+    rounds = -(-t16 // cus)
+    return 8 if (rounds < 4 and t16 % cus != 0 and (t16 % cus) < (3 * cus) // 4 and n_rows % 8 == 0) else 16

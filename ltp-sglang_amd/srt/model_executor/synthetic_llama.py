@@ -207,12 +207,14 @@ class LlamaForCausalLM(nn.Module):
         qw = attn.qkv_proj.weight.t()        # [N, K] fp8 (the parameter is the [K, N] view)
         gw = mlp.gate_up_proj.weight.t()
         as_u8 = lambda w: w.contiguous().view(torch.uint8)
+        tq, tg = K.balanced_tile_rows(qw.shape[0]), K.balanced_tile_rows(gw.shape[0])   # 16- or 8-row tiles (workgroup balance)
         layer._fused_w = dict(
-            qkv_w=K.interleave_rope_rows(as_u8(qw), hq, hkv).view(torch.float8_e4m3fn),
-            qkv_s=K.interleave_rope_rows(attn.qkv_proj.weight_scale.view(-1), hq, hkv),
-            qkv_b=None if attn.qkv_proj.bias is None else K.interleave_rope_rows(attn.qkv_proj.bias.data, hq, hkv),
-            gu_w=K.interleave_gate_up_rows(as_u8(gw)).view(torch.float8_e4m3fn),
-            gu_s=K.interleave_gate_up_rows(mlp.gate_up_proj.weight_scale.view(-1)),
+            qkv_w=K.interleave_rope_rows(as_u8(qw), hq, hkv, 128, tq).view(torch.float8_e4m3fn),
+            qkv_s=K.interleave_rope_rows(attn.qkv_proj.weight_scale.view(-1), hq, hkv, 128, tq),
+            qkv_b=None if attn.qkv_proj.bias is None else K.interleave_rope_rows(attn.qkv_proj.bias.data, hq, hkv, 128, tq),
+            gu_w=K.interleave_gate_up_rows(as_u8(gw), tg).view(torch.float8_e4m3fn),
+            gu_s=K.interleave_gate_up_rows(mlp.gate_up_proj.weight_scale.view(-1), tg),
+            qkv_tile=tq, gu_tile=tg,
         )
         return layer._fused_w
 
@@ -247,7 +249,8 @@ class LlamaForCausalLM(nn.Module):
             if fw is not None and not kv8:   # qkv GEMM with the RoPE + KV-write epilogue
                 q = K.fp8_qkv_rope_set_kv(xq, xs.view(-1), fw["qkv_w"], fw["qkv_s"], fw["qkv_b"], positions,
                                           attn.rotary_emb.cos_sin_cache, forward_batch.out_cache_loc, pool.get_key_buffer(lid),
-                                          pool.get_value_buffer(lid), attn.num_heads, attn.num_kv_heads, attn.head_dim, self.dtype)
+                                          pool.get_value_buffer(lid), attn.num_heads, attn.num_kv_heads, attn.head_dim, self.dtype,
+                                          fw["qkv_tile"])
             else:
                 qkv = K.fp8_scaled_mm(xq, attn.qkv_proj.weight, xs.view(-1), attn.qkv_proj.weight_scale.view(-1), self.dtype,
                                       attn.qkv_proj.bias)
@@ -270,7 +273,7 @@ class LlamaForCausalLM(nn.Module):
             ln2 = layer.post_attention_layernorm
             _, hq2, hs2 = K.fused_add_rmsnorm_quant_fp8(attn_out, residual, ln2.weight.data, ln2.variance_epsilon)
             if fw is not None:   # gate_up GEMM with the SiluAndMul epilogue, then the per-token quantisation
-                act = K.fp8_gemm_silu_mul(hq2, hs2.view(-1), fw["gu_w"], fw["gu_s"], self.dtype)
+                act = K.fp8_gemm_silu_mul(hq2, hs2.view(-1), fw["gu_w"], fw["gu_s"], self.dtype, fw["gu_tile"])
                 aq, asc = K.sglang_per_token_quant_fp8(act)
             else:
                 gate_up = K.fp8_scaled_mm(hq2, mlp.gate_up_proj.weight, hs2.view(-1), mlp.gate_up_proj.weight_scale.view(-1), self.dtype)

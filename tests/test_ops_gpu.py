@@ -509,19 +509,21 @@ def test_decode_merge_quant_bit_exact(sk):
     assert torch.equal(o2, o.view(bs, -1)) and torch.equal(s1, s2) and torch.equal(q1.view(torch.uint8), q2.view(torch.uint8))
 
 
-def test_fp8_gemm_silu_mul_bit_exact(sk):
+@pytest.mark.parametrize("tile_rows", [16, 8])
+def test_fp8_gemm_silu_mul_bit_exact(tile_rows, sk):
     """gate_up GEMM with the SiluAndMul epilogue (interleaved weight rows) == fp8_scaled_mm -> silu_and_mul."""
     m, i_dim, k = 32, 1408, 4096
     c = _cases.build_gemm_case(dict(m=m, n=2 * i_dim, k=k, bias=False, out="bf16"), seed=21)
     a, wt, sa, sb = c["a"].to(DEV), c["w"].to(DEV), c["sa"].to(DEV) * 3, c["sb"].to(DEV) * 3
     ref = sk.silu_and_mul(sk.fp8_scaled_mm(a, wt.t(), sa, sb, torch.bfloat16))
-    wi = sk.interleave_gate_up_rows(wt.view(torch.uint8)).view(torch.float8_e4m3fn)
-    got = sk.fp8_gemm_silu_mul(a, sa, wi, sk.interleave_gate_up_rows(sb), torch.bfloat16)
+    wi = sk.interleave_gate_up_rows(wt.view(torch.uint8), tile_rows).view(torch.float8_e4m3fn)
+    got = sk.fp8_gemm_silu_mul(a, sa, wi, sk.interleave_gate_up_rows(sb, tile_rows), torch.bfloat16, tile_rows)
     assert torch.equal(got, ref)
 
 
-@pytest.mark.parametrize("m,hq,hkv,bias", [(32, 8, 2, False), (5, 4, 4, True), (17, 28, 4, True)])
-def test_fp8_qkv_rope_set_kv_bit_exact(m, hq, hkv, bias, sk):
+@pytest.mark.parametrize("tile_rows", [16, 8])
+@pytest.mark.parametrize("m,hq,hkv,bias", [(32, 8, 2, False), (5, 4, 4, True), (17, 28, 4, True), (48, 32, 8, False)])
+def test_fp8_qkv_rope_set_kv_bit_exact(m, hq, hkv, bias, tile_rows, sk):
     """qkv GEMM with the RoPE + KV-write epilogue == fp8_scaled_mm -> rope -> set_kv_buffer (K = 3584 covers the K tail)."""
     d, k = 128, 3584
     n = (hq + 2 * hkv) * d
@@ -539,8 +541,9 @@ def test_fp8_qkv_rope_set_kv_bit_exact(m, hq, hkv, bias, sk):
     vb1 = torch.zeros_like(kb1)
     sk.rope_set_kv(positions, q, kk, vv, d, cache, True, kb1, vb1, loc)
     # fused
-    wi = sk.interleave_rope_rows(wt.view(torch.uint8), hq, hkv).view(torch.float8_e4m3fn)
+    il = lambda t: sk.interleave_rope_rows(t, hq, hkv, d, tile_rows)
+    wi = il(wt.view(torch.uint8)).view(torch.float8_e4m3fn)
     kb2, vb2 = torch.zeros_like(kb1), torch.zeros_like(kb1)
-    q2 = sk.fp8_qkv_rope_set_kv(a, sa, wi, sk.interleave_rope_rows(sb, hq, hkv), None if bvec is None else sk.interleave_rope_rows(bvec, hq, hkv),
-                                positions, cache, loc, kb2, vb2, hq, hkv, d, torch.bfloat16)
+    q2 = sk.fp8_qkv_rope_set_kv(a, sa, wi, il(sb), None if bvec is None else il(bvec), positions, cache, loc, kb2, vb2, hq, hkv, d,
+                                torch.bfloat16, tile_rows)
     assert torch.equal(q2, q.contiguous()) and torch.equal(kb1, kb2) and torch.equal(vb1, vb2)
