@@ -30,9 +30,22 @@ struct SkinnyParams {
   const void* bias;  // [N] in the output dtype, or null
   int M, N, K;
   int kbytes;  // K * element size
+#ifdef SGL_SKINNY_TIMELINE
+  long long* tl;  // tools/microbench/skinny_timeline.hip: s_memtime stamps [workgroup][wave][8]
+#endif
 };
 
 enum { ES_FP8 = 0, ES_BF16 = 1, ES_F16 = 2 };
+
+#ifdef SGL_SKINNY_TIMELINE
+#define SK_STAMP(i)                                                                  \
+  do {                                                                               \
+    const long long t_ = (long long)__builtin_amdgcn_s_memtime();                    \
+    if (lane == 0) p.tl[((int64_t)blockIdx.x * 8 + w) * 8 + (i)] = t_;               \
+  } while (0)
+#else
+#define SK_STAMP(i)
+#endif
 
 template <int ES>
 struct MfmaOp;
@@ -233,6 +246,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void skinny_gemm_v2_kernel(const Skinn
   const int a = lane & 15, g = lane >> 4;
   const u32x4_t zero4 = {0u, 0u, 0u, 0u};
   char* wl = wimg + w * IMG;
+  SK_STAMP(0);  // kernel entry
   const int lc = lane % LPR, lr = lane / LPR;  // staging: 16-byte chunk lc of row lr + RPI * i
   const int kr = blockIdx.y;
   const int koff = kr * (NWV * kw) + w * kw + lc * 16;  // this lane's byte offset inside a row
@@ -268,12 +282,15 @@ __global__ __launch_bounds__(NWV * 64, 1) void skinny_gemm_v2_kernel(const Skinn
   // At most two 16-row tiles of X are staged per round trip (register budget at MT = 4). ----
   constexpr int XG = MT >= 2 ? 2 : 1;
   u32x4_t xr[XG][DS];
+  // every workgroup needs the same X at the same moment: walking its rows in the same order makes all CUs hammer one L2
+  // channel at a time (the X staging of this kernel ran at 18 B/clk/CU); each workgroup starts at a different row instead
+  const int xrot = blockIdx.x + blockIdx.y;
   auto load_x = [&](int mt0) {
 #pragma unroll
     for (int q = 0; q < XG; ++q)
 #pragma unroll
       for (int i = 0; i < DS; ++i) {
-        const int m = (mt0 + q) * 16 + lr + RPI * i;
+        const int m = (mt0 + q) * 16 + lr + RPI * ((i + xrot) & (DS - 1));
         const u32x4_t v = *(const u32x4_t*)(p.x + (int64_t)min(m, p.M - 1) * p.x_stride + (kok ? koff : 0));
         xr[q][i] = (m < p.M && kok) ? v : zero4;
       }
@@ -301,7 +318,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void skinny_gemm_v2_kernel(const Skinn
     for (int q = 0; q < XG; ++q) {
 #pragma unroll
       for (int i = 0; i < DS; ++i) {
-        const int row = lr + RPI * i;
+        const int row = lr + RPI * ((i + xrot) & (DS - 1));
         *(u32x4_t*)(wl + row * kw + (((lc ^ row) & (LPR - 1)) << 4)) = xr[q][i];
       }
 #pragma unroll
@@ -310,6 +327,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void skinny_gemm_v2_kernel(const Skinn
     }
   }
   const int arow = (rpt == 16) ? a : (a & 7);
+  SK_STAMP(1);  // X fragments built
 
   for (int j0 = 0; j0 < cnt; j0 += TPP) {
     // epilogue operands of this phase's tiles (fetched now, consumed after the phase's MFMAs)
@@ -349,7 +367,9 @@ __global__ __launch_bounds__(NWV * 64, 1) void skinny_gemm_v2_kernel(const Skinn
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[jj][w][mt * 16 + 4 * g + r][a] = acc[mt][r];
     }
+    SK_STAMP(2);  // this phase's MFMAs issued, partial sums in LDS
     __syncthreads();
+    SK_STAMP(3);  // barrier passed
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
       const int em = em0 + e * NWV * 4;
@@ -402,6 +422,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void skinny_gemm_v2_kernel(const Skinn
         }
       }
     }
+    SK_STAMP(4);  // outputs stored
     if (TPP > 1) __syncthreads();  // the next phase overwrites red
   }
 }
