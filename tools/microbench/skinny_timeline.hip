@@ -48,6 +48,22 @@ int main() {
     }
     printf("K bytes per wave %4d, %d k-range(s): %.2f us per launch (back-to-back launches, not graph)\n", ds * 64, kr, best * 1e3);
   }
+  // fewer, fatter workgroups: the X broadcast (workgroups x 128 KiB through L2) shrinks, each workgroup streams more tiles
+  for (int gx : {256, 128, 64}) {
+    float best = 1e9;
+    for (int rep = 0; rep < 5; ++rep) {
+      hipEventRecord(e0);
+      for (int l = 0; l < L; ++l) {
+        p.w = w + (size_t)l * N * K;
+        if (gx == 256) hipLaunchKernelGGL((skinny_gemm_v2_kernel<ES_FP8, 2, 8, 1, 1, __bf16>), dim3(gx, 1), dim3(512), 0, 0, p, 16, N / 16, (float*)nullptr, EpiParams{});
+        else hipLaunchKernelGGL((skinny_gemm_v2_kernel<ES_FP8, 2, 8, 1, 4, __bf16>), dim3(gx, 1), dim3(512), 0, 0, p, 16, N / 16, (float*)nullptr, EpiParams{});
+      }
+      hipEventRecord(e1); hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      if (ms / L < best) best = ms / L;
+    }
+    printf("%3d workgroups (%d tiles each): %.2f us per launch\n", gx, N / 16 / gx, best * 1e3);
+  }
   long long last = 0;
   for (int i = 0; i < 256 * 8; ++i) if (h[i * 8 + 4] > last) last = h[i * 8 + 4];
   printf("last store stamp: %lld ticks after the first entry (100 MHz ticks if s_memtime is the constant clock)\n", last - t0);
