@@ -83,10 +83,21 @@ int main() {
   run<256, 1, 1>(k, v, idx8, 65536 * 8, 256, out, "256B rows, K only ");
   run<256, 1, 2>(k, v, idx8, 65536 * 8, 256, out, "256B rows, K+V    ");
   run<256, 2, 2>(k, v, idx8, 65536 * 8, 256, out, "256B rows, K+V    ");
+  run<256, 1, 2>(k, v, idx8, 65536 * 8, 256, out, "256B rows, K+V    ", 256);   // 1 workgroup per CU: 64 KiB in flight per CU
+  run<256, 1, 2>(k, v, idx8, 65536 * 8, 256, out, "256B rows, K+V    ", 384);
+  run<256, 2, 2>(k, v, idx8, 65536 * 8, 256, out, "256B rows, K+V    ", 256);
   run<256, 1, 2>(k, v, idx8, 65536 * 8, 256, out, "256B rows, K+V    ", 1024);
   run<256, 1, 2>(k, v, idx8, 65536 * 8, 256, out, "256B rows, K+V    ", 2048);
   run<1024, 1, 1>(k, v, idx, 65536, 2048, out, "1KiB of 2KiB rows K");
   run<1024, 1, 2>(k, v, idx, 65536, 2048, out, "1KiB of 2KiB rows ");
+  // K|V of one (slot, head) adjacent: 512-B gather units in one buffer (half the rows so the ids stay inside the pool)
+  {
+    std::vector<int> perm4(65536 * 4);
+    for (int i = 0; i < 65536; ++i) for (int h = 0; h < 4; ++h) perm4[h * 65536 + i] = perm[i] * 4 + h;
+    int* idx4; hipMalloc(&idx4, perm4.size() * 4); hipMemcpy(idx4, perm4.data(), perm4.size() * 4, hipMemcpyHostToDevice);
+    run<512, 1, 1>(k, v, idx4, 65536 * 4, 512, out, "512B rows (K|V)   ");
+    run<256, 1, 2>(k, v, idx8, 65536 * 4, 256, out, "256B rows, K+V half");
+  }
   // sequential (sorted) indices for reference
   std::vector<int> seq8(65536 * 8); for (size_t i = 0; i < seq8.size(); ++i) seq8[i] = (int)i + 8;
   hipMemcpy(idx8, seq8.data(), seq8.size() * 4, hipMemcpyHostToDevice);
