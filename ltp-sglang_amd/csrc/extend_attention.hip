@@ -71,7 +71,7 @@ __device__ __forceinline__ u32x4_t cvt8_fp8(const u32x2_t& in) {
   return out;
 }
 
-template <typename T, int D, bool KV8 = false>
+template <typename T, int D, bool KV8 = false, bool CAP = false>  // CAP: logit soft-capping (its own instantiation)
 __global__ __launch_bounds__(256, 2) void extend_attn_kernel(const ExtendParams p) {
   using Tr = ElemTraits<T>;
   using vec8 = typename Tr::vec8;
@@ -213,7 +213,6 @@ __global__ __launch_bounds__(256, 2) void extend_attn_kernel(const ExtendParams 
     for (int n = 0; n < NT; ++n) acc[qt][n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   const float scale_log2 = p.sm_scale * kLog2e;
-  const bool use_cap = p.logit_cap > 0.0f;
 
   if (ntiles > 0) {
     issue(0);
@@ -261,38 +260,49 @@ __global__ __launch_bounds__(256, 2) void extend_attn_kernel(const ExtendParams 
           s[qt][tt] = c;
         }
       }
-      // ---- online softmax per query tile ----
+      // ---- scale (or soft-cap) every score; then ONE wave-uniform branch masks the ragged last tile of a phase and the causal
+      // diagonal (tested per score, the flags cut this loop into ~70 basic blocks and nothing was scheduled across them) ----
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            s[qt][tt][r] = CAP ? softcap2(s[qt][tt][r] * tsm, p.logit_cap) : s[qt][tt][r] * tlog2;
+      if (need_mask) {
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+          for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int key = kbase + 16 * tt + 4 * g + r;
+              bool ok = key < klimit;
+              if (!in_prefix && p.is_causal) ok = ok && (key <= qpos[qt]);
+              s[qt][tt][r] = ok ? s[qt][tt][r] : -INFINITY;
+            }
+      }
+      // ---- online softmax per query tile (branch-free: a row that has seen no key yet keeps m = -inf, l = 0, acc = 0
+      // through the clamped maximum: exp2(-inf - m_safe) = 0 for its scores and for its rescale factor) ----
       vec8 pf[2][2];
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt) {
         float mt = -INFINITY;
 #pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
+        for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float v = use_cap ? softcap2(s[qt][tt][r] * tsm, p.logit_cap) : s[qt][tt][r] * tlog2;
-            if (need_mask) {  // wave-uniform: only the ragged last tile of a phase and the causal diagonal pay for masking
-              const int key = kbase + 16 * tt + 4 * g + r;
-              bool ok = key < klimit;
-              if (!in_prefix && p.is_causal) ok = ok && (key <= qpos[qt]);
-              v = ok ? v : -INFINITY;
-            }
-            s[qt][tt][r] = v;
-            mt = fmaxf(mt, v);
-          }
-        }
+          for (int r = 0; r < 4; ++r) mt = fmaxf(mt, s[qt][tt][r]);
         mt = fmaxf(mt, __shfl_xor(mt, 16, WAVE));
         mt = fmaxf(mt, __shfl_xor(mt, 32, WAVE));
         const float m_new = fmaxf(m_i[qt], mt);
-        const bool dead = need_mask && m_new == -INFINITY;  // row has seen no key yet (impossible in an unmasked tile)
-        const float alpha = dead ? 1.0f : __builtin_amdgcn_exp2f(m_i[qt] - m_new);
+        const float m_safe = fmaxf(m_new, -1e30f);
+        const float alpha = __builtin_amdgcn_exp2f(m_i[qt] - m_safe);
         float lsum = 0.f;
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            float pv = __builtin_amdgcn_exp2f(s[qt][tt][r] - m_new);
-            if (need_mask) pv = dead ? 0.0f : pv;
+            const float pv = __builtin_amdgcn_exp2f(s[qt][tt][r] - m_safe);
             lsum += pv;
             // PV k-step u = tt / 2 takes keys 32 u + {4 g + j, 16 + 4 g + j}: element index 4 (tt & 1) + r
             pf[qt][tt >> 1][4 * (tt & 1) + r] = Tr::from_f32(KV8 ? pv * pvs : pv);
@@ -433,12 +443,15 @@ __global__ __launch_bounds__(64) void extend_attn_generic(const ExtendParams p, 
   }
 }
 
-template <typename T, int D, bool KV8>
+template <typename T, int D, bool KV8, bool CAP = false>
 int launch_mfma(ExtendParams& p, int max_len_extend, hipStream_t st) {
+  if constexpr (!CAP) {
+    if (p.logit_cap > 0.0f) return launch_mfma<T, D, KV8, true>(p, max_len_extend, st);
+  }
   constexpr int smem = 2 * 2 * kKT * D * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)extend_attn_kernel<T, D, KV8>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)extend_attn_kernel<T, D, KV8, CAP>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
   // head slots per workgroup: smallest power of two >= min(group, 8); positions per workgroup = 128 / slots
@@ -456,7 +469,7 @@ int launch_mfma(ExtendParams& p, int max_len_extend, hipStream_t st) {
     snprintf(g_sgl_mi355_err, sizeof(g_sgl_mi355_err), "extend_attention: grid too large");
     return SGL_MI355_EINVAL;
   }
-  hipLaunchKernelGGL((extend_attn_kernel<T, D, KV8>), dim3((unsigned)nblocks), dim3(256), smem, st, p);
+  hipLaunchKernelGGL((extend_attn_kernel<T, D, KV8, CAP>), dim3((unsigned)nblocks), dim3(256), smem, st, p);
   SGL_HIP_LAUNCH_CHECK();
   return SGL_MI355_OK;
 }
