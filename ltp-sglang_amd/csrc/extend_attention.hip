@@ -260,15 +260,17 @@ __global__ __launch_bounds__(256, 2) void extend_attn_kernel(const ExtendParams 
           s[qt][tt] = c;
         }
       }
-      // ---- scale (or soft-cap) every score; then ONE wave-uniform branch masks the ragged last tile of a phase and the causal
-      // diagonal (tested per score, the flags cut this loop into ~70 basic blocks and nothing was scheduled across them) ----
+      // ---- soft-cap every score (CAP; otherwise the scale is folded into the exponent below); then ONE wave-uniform branch
+      // masks the ragged last tile of a phase and the causal diagonal (tested per score, the flags cut this loop into ~70
+      // basic blocks and nothing was scheduled across them) ----
+      if constexpr (CAP) {
 #pragma unroll
-      for (int qt = 0; qt < 2; ++qt)
+        for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
-        for (int tt = 0; tt < 4; ++tt)
+          for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            s[qt][tt][r] = CAP ? softcap2(s[qt][tt][r] * tsm, p.logit_cap) : s[qt][tt][r] * tlog2;
+            for (int r = 0; r < 4; ++r) s[qt][tt][r] = softcap2(s[qt][tt][r] * tsm, p.logit_cap);
+      }
       if (need_mask) {
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
@@ -282,19 +284,20 @@ __global__ __launch_bounds__(256, 2) void extend_attn_kernel(const ExtendParams 
               s[qt][tt][r] = ok ? s[qt][tt][r] : -INFINITY;
             }
       }
-      // ---- online softmax per query tile (branch-free: a row that has seen no key yet keeps m = -inf, l = 0, acc = 0
-      // through the clamped maximum: exp2(-inf - m_safe) = 0 for its scores and for its rescale factor) ----
+      // ---- online softmax per query tile, branch-free (m_i in log2 units; the score scale is folded into the exponent's fma;
+      // a row that has seen no key yet keeps m = -inf, l = 0, acc = 0 through the clamped maximum) ----
+      const float cs = CAP ? 1.0f : tlog2;  // x = s * cs (sm_scale * log2 e > 0; soft-capped scores are already in log2 units)
       vec8 pf[2][2];
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt) {
-        float mt = -INFINITY;
+        float m = -INFINITY;
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) mt = fmaxf(mt, s[qt][tt][r]);
-        mt = fmaxf(mt, __shfl_xor(mt, 16, WAVE));
-        mt = fmaxf(mt, __shfl_xor(mt, 32, WAVE));
-        const float m_new = fmaxf(m_i[qt], mt);
+          for (int r = 0; r < 4; ++r) m = fmaxf(m, s[qt][tt][r]);
+        m = fmaxf(m, __shfl_xor(m, 16, WAVE));
+        m = fmaxf(m, __shfl_xor(m, 32, WAVE));
+        const float m_new = fmaxf(m_i[qt], m * cs);
         const float m_safe = fmaxf(m_new, -1e30f);
         const float alpha = __builtin_amdgcn_exp2f(m_i[qt] - m_safe);
         float lsum = 0.f;
@@ -302,7 +305,7 @@ __global__ __launch_bounds__(256, 2) void extend_attn_kernel(const ExtendParams 
         for (int tt = 0; tt < 4; ++tt) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float pv = __builtin_amdgcn_exp2f(s[qt][tt][r] - m_safe);
+            const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qt][tt][r], cs, -m_safe));
             lsum += pv;
             // PV k-step u = tt / 2 takes keys 32 u + {4 g + j, 16 + 4 g + j}: element index 4 (tt & 1) + r
             pf[qt][tt >> 1][4 * (tt & 1) + r] = Tr::from_f32(KV8 ? pv * pvs : pv);
