@@ -299,23 +299,34 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attn_stage1(const DecodePar
         s[tt] = Tr::mfma16(kf, qf[ks], s[tt]);
       }
     }
-    // ---- online softmax; lane (a,g) holds head a, tokens 16*tt + 4*g + r ----
+    // ---- online softmax; lane (a,g) holds head a, tokens 16*tt + 4*g + r.  One wave-uniform branch for the logit cap (tested
+    // per score it cut the loop body into a dozen basic blocks); the score scale is folded into the exponent's fma. ----
     float x[2][4];
+    if (use_cap) {
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[tt][r] = softcap_log2(s[tt][r] * sm_scale, p.logit_cap);
+    } else {
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[tt][r] = s[tt][r];
+    }
+    const float cs = use_cap ? 1.0f : scale_log2;  // the exponent is x * cs - m (cs > 0)
     float mt = -INFINITY;
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int tok = tok0 + 16 * tt + 4 * g + r;
-        float v = use_cap ? softcap_log2(s[tt][r] * sm_scale, p.logit_cap) : s[tt][r] * scale_log2;
-        v = (tok < end) ? v : -INFINITY;
-        x[tt][r] = v;
-        mt = fmaxf(mt, v);
+        x[tt][r] = (tok < end) ? x[tt][r] : -INFINITY;
+        mt = fmaxf(mt, x[tt][r]);
       }
     }
     mt = fmaxf(mt, __shfl_xor(mt, 16, WAVE));
     mt = fmaxf(mt, __shfl_xor(mt, 32, WAVE));
-    const float m_new = fmaxf(m_i, mt);  // finite: every tile holds >= 1 valid token
+    const float m_new = fmaxf(m_i, mt * cs);  // finite: every tile holds >= 1 valid token
     const float alpha = __builtin_amdgcn_exp2f(m_i - m_new);
     float lsum = 0.0f;
     vec8 pf;
@@ -323,7 +334,7 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attn_stage1(const DecodePar
     for (int tt = 0; tt < 2; ++tt) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float pv = __builtin_amdgcn_exp2f(x[tt][r] - m_new);
+        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(x[tt][r], cs, -m_new));
         lsum += pv;
         pf[4 * tt + r] = Tr::from_f32(pv);  // P is rounded to the V dtype before PV (decode_attention.py:373)
       }
