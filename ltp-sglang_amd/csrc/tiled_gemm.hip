@@ -228,6 +228,68 @@ __device__ __forceinline__ void glds16(const char* g, char* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// Fused scale / bias epilogue of the transposed-accumulator kernels: acc[j][i][r] -> row mrow0 + 16 i, col ncol0 + 16 j + r.
+// Every operand (NI row scales, NJ x 4 column scales and biases) is loaded up front with ONE wave-uniform branch per optional
+// pointer; the value loop is then branch-free arithmetic + stores.  (With the pointers tested and the scales loaded per value,
+// the epilogue compiled into several hundred basic blocks of one dependent L2 load each -- with one workgroup per CU nothing
+// overlaps it, and it cost about as much as a third of a K = 4096 main loop.)  Same arithmetic as before: x * 1.0f is exact.
+template <typename OutT, int NI, int NJ>
+__device__ __forceinline__ void epilogue_scaled(const GemmParams& p, const f32x4_t (&acc)[NJ][NI], int mrow0, int ncol0) {
+  float sxv[NI], swv[NJ][4], bv[NJ][4];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) sxv[i] = 1.0f;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      swv[j][r] = 1.0f;
+      bv[j][r] = 0.0f;
+    }
+  if (p.sx) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) sxv[i] = p.sx[min(mrow0 + 16 * i, p.M - 1)];
+  }
+  if (p.sw) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) swv[j][r] = p.sw[min(ncol0 + 16 * j + r, p.N - 1)];
+  }
+  if (p.bias) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bv[j][r] = (float)((const OutT*)p.bias)[min(ncol0 + 16 * j + r, p.N - 1)];
+  }
+  const bool vec_ok = (p.y_stride % 4 == 0) && (((uintptr_t)p.y & 7) == 0);
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int m = mrow0 + 16 * i;
+    OutT* yrow = (OutT*)p.y + (int64_t)min(m, p.M - 1) * p.y_stride;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int n = ncol0 + 16 * j;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = acc[j][i][r] * sxv[i];
+        v[r] = v[r] * swv[j][r] + bv[j][r];
+      }
+      if (m < p.M && n < p.N) {
+        if (vec_ok && n + 3 < p.N) {
+          typedef OutT o4_t __attribute__((ext_vector_type(4)));
+          const o4_t o = {(OutT)v[0], (OutT)v[1], (OutT)v[2], (OutT)v[3]};
+          *(o4_t*)(yrow + n) = o;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (n + r < p.N) yrow[n + r] = (OutT)v[r];
+        }
+      }
+    }
+  }
+}
+
 // ES: TG_FP8 (block-scaled MFMA over the whole 128-byte slice) or TG_BF16 / TG_F16 (two 16x16x32 k-steps per slice: the
 // same LDS reads, chunk 4 h + g being exactly k-step h's fragment)
 template <typename OutT, int NWV, bool DMA = true, int ES = TG_FP8>  // NWV = 8: waves 2 (M) x 4 (N), 128 x 64 outputs each; 4: 2 x 2
@@ -398,38 +460,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void fp8_gemm256_kernel(const GemmPara
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may be in flight when the workgroup ends
 
   // ---- epilogue: acc[j][i][r] -> row m0+wm+16i+a, col n0+wn+16j+4g+r ----
-  const bool vec_ok = (p.y_stride % 4 == 0) && (((uintptr_t)p.y & 7) == 0);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int m = m0 + wm + 16 * i + a;
-    if (m >= p.M) continue;
-    const float sxv = p.sx ? p.sx[m] : 1.0f;
-    OutT* yrow = (OutT*)p.y + (int64_t)m * p.y_stride;
-#pragma unroll
-    for (int j = 0; j < JN; ++j) {
-      const int n = n0 + wn + 16 * j + 4 * g;
-      if (n >= p.N) continue;
-      float v[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int nn = min(n + r, p.N - 1);
-        const float swv = p.sw ? p.sw[nn] : 1.0f;
-        const float bv = p.bias ? (float)((const OutT*)p.bias)[nn] : 0.0f;
-        v[r] = acc[j][i][r];
-        if (p.sx) v[r] *= sxv;
-        v[r] = v[r] * swv + bv;
-      }
-      if (vec_ok && n + 3 < p.N) {
-        typedef OutT o4_t __attribute__((ext_vector_type(4)));
-        const o4_t o = {(OutT)v[0], (OutT)v[1], (OutT)v[2], (OutT)v[3]};
-        *(o4_t*)(yrow + n) = o;
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (n + r < p.N) yrow[n + r] = (OutT)v[r];
-      }
-    }
-  }
+  epilogue_scaled<OutT, 8, JN>(p, acc, m0 + wm + a, n0 + wn + 4 * g);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -528,38 +559,7 @@ __global__ __launch_bounds__(512, 1) void fp8_gemm128s_kernel(const GemmParams p
     }
     return;
   }
-  const bool vec_ok = (p.y_stride % 4 == 0) && (((uintptr_t)p.y & 7) == 0);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm + 16 * i + a;
-    if (m >= p.M) continue;
-    const float sxv = p.sx ? p.sx[m] : 1.0f;
-    OutT* yrow = (OutT*)p.y + (int64_t)m * p.y_stride;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = n0 + wn + 16 * j + 4 * g;
-      if (n >= p.N) continue;
-      float v[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int nn = min(n + r, p.N - 1);
-        const float swv = p.sw ? p.sw[nn] : 1.0f;
-        const float bv = p.bias ? (float)((const OutT*)p.bias)[nn] : 0.0f;
-        v[r] = acc[j][i][r];
-        if (p.sx) v[r] *= sxv;
-        v[r] = v[r] * swv + bv;
-      }
-      if (vec_ok && n + 3 < p.N) {
-        typedef OutT o4_t __attribute__((ext_vector_type(4)));
-        const o4_t o = {(OutT)v[0], (OutT)v[1], (OutT)v[2], (OutT)v[3]};
-        *(o4_t*)(yrow + n) = o;
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (n + r < p.N) yrow[n + r] = (OutT)v[r];
-      }
-    }
-  }
+  epilogue_scaled<OutT, 4, 2>(p, acc, m0 + wm + a, n0 + wn + 4 * g);
 }
 
 int tg_cus() {
