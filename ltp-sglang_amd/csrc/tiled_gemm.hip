@@ -290,6 +290,69 @@ __device__ __forceinline__ void epilogue_scaled(const GemmParams& p, const f32x4
   }
 }
 
+// The same epilogue with the output tile staged through LDS (256x256 kernel, LDS free after the main loop): every wave packs
+// its 128 x 64 outputs into a private 16 KiB [128][64] image (16-byte chunks XOR-swizzled by the row) and writes them back as
+// whole 128-byte rows, 8 rows per store instruction.  Straight from the accumulator layout a store instruction touches 16 rows x 32 bytes; with every CU in
+// its epilogue at the same moment those partial-line writes took 6-9 us per tile (measured by compiling the epilogue out),
+// as much as 4-6 K slices of MFMA work.  Needs N % 8 == 0 and 16-byte aligned output rows; otherwise epilogue_scaled.
+constexpr int kEpiRowB = 128;  // bytes per staged row: 64 outputs of 2 bytes (8 waves x 16 KiB = the kernel's 128 KiB of LDS)
+template <typename OutT, int NI, int NJ>
+__device__ __forceinline__ void epilogue_scaled_lds(const GemmParams& p, const f32x4_t (&acc)[NJ][NI], int mrow_base, int ncol_base,
+                                                    char* wave_lds, int lane) {
+  static_assert(NJ == 4 && NI == 8, "one wave = 128 rows x 64 columns");
+  const int a = lane & 15, g = lane >> 4;
+  float sxv[NI], swv[NJ][4], bv[NJ][4];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) sxv[i] = 1.0f;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      swv[j][r] = 1.0f;
+      bv[j][r] = 0.0f;
+    }
+  if (p.sx) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) sxv[i] = p.sx[min(mrow_base + a + 16 * i, p.M - 1)];
+  }
+  if (p.sw) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) swv[j][r] = p.sw[min(ncol_base + 4 * g + 16 * j + r, p.N - 1)];
+  }
+  if (p.bias) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bv[j][r] = (float)((const OutT*)p.bias)[min(ncol_base + 4 * g + 16 * j + r, p.N - 1)];
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      typedef OutT o4_t __attribute__((ext_vector_type(4)));
+      o4_t o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[j][i][r] * sxv[i];
+        v = v * swv[j][r] + bv[j][r];
+        o[r] = (OutT)v;
+      }
+      *(o4_t*)(wave_lds + (16 * i + a) * kEpiRowB + (((2 * j + (g >> 1)) ^ (a & 7)) << 4) + ((g & 1) << 3)) = o;
+    }
+  // (same-wave LDS operations are ordered: no barrier between the image's writes and reads)
+  const int rsub = lane >> 3, c16 = lane & 7;  // 8 lanes cover one 128-byte row
+  const bool col_ok = ncol_base + 8 * c16 + 7 < p.N;
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const int row = 8 * it + rsub;
+    const u32x4_t v = *(const u32x4_t*)(wave_lds + row * kEpiRowB + ((c16 ^ (row & 7)) << 4));
+    const int m = mrow_base + row;
+    if (m < p.M && col_ok) *(u32x4_t*)((OutT*)p.y + (int64_t)m * p.y_stride + ncol_base + 8 * c16) = v;
+  }
+}
+
 // ES: TG_FP8 (block-scaled MFMA over the whole 128-byte slice) or TG_BF16 / TG_F16 (two 16x16x32 k-steps per slice: the
 // same LDS reads, chunk 4 h + g being exactly k-step h's fragment)
 template <typename OutT, int NWV, bool DMA = true, int ES = TG_FP8>  // NWV = 8: waves 2 (M) x 4 (N), 128 x 64 outputs each; 4: 2 x 2
@@ -460,6 +523,13 @@ __global__ __launch_bounds__(NWV * 64, 1) void fp8_gemm256_kernel(const GemmPara
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may be in flight when the workgroup ends
 
   // ---- epilogue: acc[j][i][r] -> row m0+wm+16i+a, col n0+wn+16j+4g+r ----
+  if constexpr (NWV == 8) {
+    if (p.N % 8 == 0 && p.y_stride % 8 == 0 && ((uintptr_t)p.y & 15) == 0) {
+      __syncthreads();  // every wave is past its last fragment read and every staged slice has landed: the LDS is free
+      epilogue_scaled_lds<OutT, 8, JN>(p, acc, m0 + wm, n0 + wn, smem + w * (128 * kEpiRowB), lane);
+      return;
+    }
+  }
   epilogue_scaled<OutT, 8, JN>(p, acc, m0 + wm + a, n0 + wn + 4 * g);
 }
 
