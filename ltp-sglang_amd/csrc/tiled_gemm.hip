@@ -28,6 +28,7 @@ struct GemmParams {
   int group_m;  // row tiles per scheduling group (256x256 kernel)
   float* slabs;  // split-K (128x128 kernel, blockIdx.y = K range of `kt_per` slices): raw f32 sums [splits][M][N], else NULL
   int kt_per;
+  int stagger_q, stagger_cus;  // 256x256 kernel: start stagger of each CU's first workgroup (quantum in 1024-cycle units; CU count)
 #ifdef SGL_GEMM_TIMELINE
   long long* tl;  // tools/microbench/gemm256_timeline.hip: s_memtime stamps of workgroup 0, slices 8..11
 #endif
@@ -378,6 +379,14 @@ __global__ __launch_bounds__(NWV * 64, 1) void fp8_gemm256_kernel(const GemmPara
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = (w / WCOLS) * 128, wn = (w % WCOLS) * (16 * JN);
+  // Phase stagger: tiles of one launch take the same time on every CU, so without it all 256 CUs reach their epilogues together
+  // and the burst of 256 x 128 KiB of output is write-bandwidth bound (5-6 us per tile with the MFMA pipes idle).  The first
+  // workgroup of every CU starts up to p.stagger_us late; the workgroups that follow on that CU inherit its phase.
+  if (p.stagger_q > 0 && (int)blockIdx.x < p.stagger_cus) {
+    const int mask = (p.stagger_q & 64) ? 31 : 15;
+    const int steps = ((blockIdx.x >> 3) & mask) * (p.stagger_q & 63);  // units of 64 x 8 cycles
+    for (int t = 0; t < steps; ++t) __builtin_amdgcn_s_sleep(8);
+  }
   const int a = lane & 15, g = lane >> 4;
 
   // LDS-DMA staging (buffer_load ... lds): wave w fills rows RPW w .. RPW w + RPW - 1 of both operands, 8 rows (1 KiB) per
@@ -642,6 +651,7 @@ int tg_cus() {
   return cus;
 }
 int g_tiled_group_m = 4;
+int g_tiled_stagger = 1;  // x 1024 cycles per step, 16 steps: CUs spread over ~6.5 us
 int g_tiled_force = 0;  // test hook: 1 = always the 128x128 kernel, 2 = the 256x256 kernel whenever its shape rules allow
 
 template <typename OutT, int NWV, bool DMA = true, int ES = TG_FP8>
@@ -655,6 +665,8 @@ int launch256(GemmParams& p, hipStream_t st) {
   p.tiles_m = (p.M + T2 - 1) / T2;
   p.tiles_n = (p.N + T2 - 1) / T2;
   p.group_m = g_tiled_group_m;
+  p.stagger_cus = tg_cus();
+  p.stagger_q = (p.tiles_m * p.tiles_n >= 2 * p.stagger_cus) ? g_tiled_stagger : 0;  // needs a second round to pay off
   hipLaunchKernelGGL((fp8_gemm256_kernel<OutT, NWV, DMA, ES>), dim3(p.tiles_m * p.tiles_n), dim3(NWV * 64), smem, st, p);
   SGL_HIP_LAUNCH_CHECK();
   return SGL_MI355_OK;
@@ -816,6 +828,10 @@ int run(const void* x, int64_t xs, const void* w, int64_t ws, void* y, int64_t y
 }  // namespace
 
 extern "C" int sgl_mi355_fp8_gemm_force_tile(int mode) {
+  if (mode >= 1000) {  // measurement hook: 1000 + q sets the start-stagger quantum of the 256x256 kernel (0 = off)
+    g_tiled_stagger = mode - 1000;
+    return SGL_MI355_OK;
+  }
   if (mode >= 100) {  // measurement hook: 100 + GM sets the scheduling group height of the 256x256 kernel
     g_tiled_group_m = mode - 100 > 0 ? mode - 100 : 1;
     return SGL_MI355_OK;
