@@ -112,6 +112,13 @@ int sgl_mi355_write_req_to_token(int32_t* req_to_token, int64_t req_to_token_str
                                  int req_pool_indices_is64, const void* pre_lens, int pre_is64, const void* seq_lens,
                                  int seq_is64, const void* extend_lens, int ext_is64, const int64_t* out_cache_loc,
                                  int batch, void* stream);
+/* Graph-replayed decode step, host side in ONE launch: prepare_for_decode (schedule_batch.py:1560-1590: req_to_token[req,
+ * seq_len] = out_cache_loc, seq_lens += 1 in place) + replay_prepare's copies into the graph's static input buffers
+ * (cuda_graph_runner.py:700-760; positions = clamp(seq_lens - 1, 0), forward_batch_info.py:958-960). */
+int sgl_mi355_decode_prepare(const int64_t* req_pool_indices, int64_t* seq_lens, const int64_t* out_cache_loc,
+                             const int64_t* next_ids, int32_t* req_to_token, int64_t req_to_token_stride,
+                             int64_t* buf_input_ids, int64_t* buf_req_pool_indices, int64_t* buf_seq_lens,
+                             int64_t* buf_out_cache_loc, int64_t* buf_positions, int batch, void* stream);
 /* get_last_loc_triton / get_last_loc_torch, managers/schedule_batch.py:1958-2028 */
 int sgl_mi355_get_last_loc(const int32_t* req_to_token, int64_t req_to_token_stride, const void* req_pool_indices,
                            int req_pool_indices_is64, const void* prefix_lens, int prefix_is64, void* result,

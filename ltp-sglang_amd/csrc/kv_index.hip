@@ -257,6 +257,44 @@ extern "C" int sgl_mi355_write_req_to_token(int32_t* req_to_token, int64_t req_t
   return SGL_MI355_OK;
 }
 
+// One launch for the per-step host work of a graph-replayed decode batch: prepare_for_decode (schedule_batch.py:1560-1590:
+// req_to_token[req, seq_len] = new slot, seq_lens += 1) followed by replay_prepare's copies into the graph's static buffers
+// (cuda_graph_runner.py:700-760: input_ids, req_pool_indices, seq_lens, out_cache_loc, positions = seq_lens - 1).
+namespace {
+__global__ __launch_bounds__(256) void decode_prepare_kernel(const int64_t* req_pool_indices, int64_t* seq_lens,
+                                                             const int64_t* out_cache_loc, const int64_t* next_ids,
+                                                             int32_t* req_to_token, int64_t r2t_stride, int64_t* b_input_ids,
+                                                             int64_t* b_req_pool_indices, int64_t* b_seq_lens,
+                                                             int64_t* b_out_cache_loc, int64_t* b_positions, int bs) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= bs) return;
+  const int64_t s = seq_lens[i], req = req_pool_indices[i], loc = out_cache_loc[i];
+  req_to_token[req * r2t_stride + s] = (int32_t)loc;
+  seq_lens[i] = s + 1;
+  b_input_ids[i] = next_ids[i];
+  b_req_pool_indices[i] = req;
+  b_seq_lens[i] = s + 1;
+  b_out_cache_loc[i] = loc;
+  b_positions[i] = s > 0 ? s : 0;  // clamp(seq_lens_new - 1, 0), forward_batch_info.py:958-960
+}
+}  // namespace
+
+extern "C" int sgl_mi355_decode_prepare(const int64_t* req_pool_indices, int64_t* seq_lens, const int64_t* out_cache_loc,
+                                        const int64_t* next_ids, int32_t* req_to_token, int64_t req_to_token_stride,
+                                        int64_t* buf_input_ids, int64_t* buf_req_pool_indices, int64_t* buf_seq_lens,
+                                        int64_t* buf_out_cache_loc, int64_t* buf_positions, int batch, void* stream) {
+  SGL_CHECK(batch >= 0, "decode_prepare: negative batch");
+  if (batch == 0) return SGL_MI355_OK;
+  SGL_CHECK(req_pool_indices && seq_lens && out_cache_loc && next_ids && req_to_token && buf_input_ids && buf_req_pool_indices &&
+                buf_seq_lens && buf_out_cache_loc && buf_positions,
+            "decode_prepare: null pointer");
+  hipLaunchKernelGGL(decode_prepare_kernel, dim3((batch + 255) / 256), dim3(256), 0, (hipStream_t)stream, req_pool_indices, seq_lens,
+                     out_cache_loc, next_ids, req_to_token, req_to_token_stride, buf_input_ids, buf_req_pool_indices, buf_seq_lens,
+                     buf_out_cache_loc, buf_positions, batch);
+  SGL_HIP_LAUNCH_CHECK();
+  return SGL_MI355_OK;
+}
+
 extern "C" int sgl_mi355_get_last_loc(const int32_t* req_to_token, int64_t req_to_token_stride,
                                       const void* req_pool_indices, int req_pool_indices_is64, const void* prefix_lens,
                                       int prefix_is64, void* result, int result_is64, int64_t n, void* stream) {

@@ -40,6 +40,7 @@ from .kvcache import (
     compute_position,
     create_kv_indices,
     decode_metadata,
+    decode_prepare,
     get_last_loc,
     set_kv_buffer,
     write_req_to_token,

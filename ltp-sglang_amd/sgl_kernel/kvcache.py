@@ -39,6 +39,20 @@ def write_req_to_token(req_to_token, req_pool_indices, pre_lens, seq_lens, exten
                                            req_pool_indices.numel(), current_stream()))
 
 
+def decode_prepare(req_pool_indices, seq_lens, out_cache_loc, next_ids, req_to_token, buf_input_ids, buf_req_pool_indices,
+                   buf_seq_lens, buf_out_cache_loc, buf_positions) -> None:
+    """One launch for a graph-replayed decode step's host work: req_to_token[req, seq_len] = slot, seq_lens += 1 (in place), and the
+    copies into the graph's static buffers (input_ids, req_pool_indices, seq_lens, out_cache_loc, positions = seq_lens - 1)."""
+    bs = req_pool_indices.numel()
+    for t in (req_pool_indices, seq_lens, out_cache_loc, next_ids, buf_input_ids, buf_req_pool_indices, buf_seq_lens,
+              buf_out_cache_loc, buf_positions):
+        assert t.dtype == torch.int64 and t.is_contiguous() and t.numel() >= bs
+    assert req_to_token.dtype == torch.int32
+    check(lib.sgl_mi355_decode_prepare(ptr(req_pool_indices), ptr(seq_lens), ptr(out_cache_loc), ptr(next_ids), ptr(req_to_token),
+                                       req_to_token.stride(0), ptr(buf_input_ids), ptr(buf_req_pool_indices), ptr(buf_seq_lens),
+                                       ptr(buf_out_cache_loc), ptr(buf_positions), bs, current_stream()))
+
+
 def get_last_loc(req_to_token, req_pool_indices, prefix_lens) -> torch.Tensor:
     result = torch.empty_like(prefix_lens)
     check(lib.sgl_mi355_get_last_loc(ptr(req_to_token), req_to_token.stride(0), ptr(req_pool_indices),

@@ -403,6 +403,8 @@ class SyntheticModelRunner:
         self._graphs = {}
 
     # ---- bench_one_batch-style drivers -------------------------------------------------------------------
+    fused_decode_prepare = True   # decode_graph: one HIP launch for prepare_for_decode + replay_prepare
+
     def clear(self):
         self.req_to_token_pool.clear()
         self.token_to_kv_pool_allocator.clear()
@@ -493,13 +495,25 @@ class SyntheticModelRunner:
     def decode_graph(self, state, next_ids: torch.Tensor):
         bs = len(state.seq_lens_cpu)
         graph, buf = self._graphs[bs]
-        fb = self._prepare_decode(state, next_ids)
-        buf.input_ids.copy_(next_ids)
-        buf.req_pool_indices.copy_(fb.req_pool_indices)
-        buf.seq_lens.copy_(fb.seq_lens)
-        buf.out_cache_loc.copy_(fb.out_cache_loc)
-        buf.positions.copy_(fb.positions)
-        self.attn_backend.init_forward_metadata_replay_cuda_graph(bs, buf.req_pool_indices, buf.seq_lens, fb.seq_lens_sum,
-                                                                  None, ForwardMode.DECODE, None, fb.seq_lens_cpu)
+        if not self.fused_decode_prepare:
+            fb = self._prepare_decode(state, next_ids)
+            buf.input_ids.copy_(next_ids)
+            buf.req_pool_indices.copy_(fb.req_pool_indices)
+            buf.seq_lens.copy_(fb.seq_lens)
+            buf.out_cache_loc.copy_(fb.out_cache_loc)
+            buf.positions.copy_(fb.positions)
+            seq_sum, seq_cpu = fb.seq_lens_sum, fb.seq_lens_cpu
+        else:
+            # the same index work (slot allocation aside) and the copies into the graph's static buffers in ONE launch: a dozen
+            # 5-17 us index / copy kernels per step otherwise sit between two graph replays
+            out_cache_loc = self.token_to_kv_pool_allocator.alloc(bs)
+            if out_cache_loc is None:
+                raise RuntimeError("Decode out of memory. Try to lower your batch size.")
+            K.decode_prepare(state.req_pool_indices, state.seq_lens, out_cache_loc, next_ids, self.req_to_token_pool.req_to_token,
+                             buf.input_ids, buf.req_pool_indices, buf.seq_lens, buf.out_cache_loc, buf.positions)
+            state.seq_lens_cpu = [s + 1 for s in state.seq_lens_cpu]
+            seq_sum, seq_cpu = sum(state.seq_lens_cpu), None
+        self.attn_backend.init_forward_metadata_replay_cuda_graph(bs, buf.req_pool_indices, buf.seq_lens, seq_sum,
+                                                                  None, ForwardMode.DECODE, None, seq_cpu)
         graph.replay()
         return buf.logits

@@ -547,3 +547,26 @@ def test_fp8_qkv_rope_set_kv_bit_exact(m, hq, hkv, bias, tile_rows, sk):
     q2 = sk.fp8_qkv_rope_set_kv(a, sa, wi, il(sb), None if bvec is None else il(bvec), positions, cache, loc, kb2, vb2, hq, hkv, d,
                                 torch.bfloat16, tile_rows)
     assert torch.equal(q2, q.contiguous()) and torch.equal(kb1, kb2) and torch.equal(vb1, vb2)
+
+
+def test_decode_prepare_matches_index_ops(sk):
+    """prepare_for_decode + the graph runner's buffer copies in one launch == the separate index ops (bit-exact)."""
+    g = torch.Generator().manual_seed(11)
+    bs, ctx = 37, 64
+    r2t = torch.zeros(50, ctx, dtype=torch.int32, device=DEV)
+    req = torch.randperm(50, generator=g)[:bs].to(DEV)
+    seq = torch.randint(0, ctx - 1, (bs,), generator=g).to(DEV)
+    seq[0] = 0
+    loc = (torch.randperm(5000, generator=g)[:bs] + 1).to(DEV)
+    ids = torch.randint(0, 32000, (bs,), generator=g).to(DEV)
+    # reference sequence (synthetic_llama._prepare_decode + decode_graph's copies)
+    r2t_ref = r2t.clone()
+    r2t_ref[(req, seq)] = loc.to(torch.int32)
+    seq_ref = seq + 1
+    pos_ref = torch.clamp(seq_ref - 1, min=0)
+    bufs = [torch.full((bs + 3,), -7, dtype=torch.int64, device=DEV) for _ in range(5)]
+    seq2 = seq.clone()
+    sk.decode_prepare(req, seq2, loc, ids, r2t, *bufs)
+    assert torch.equal(r2t, r2t_ref) and torch.equal(seq2, seq_ref)
+    for got, want in zip(bufs, (ids, req, seq_ref, loc, pos_ref)):
+        assert torch.equal(got[:bs], want) and (got[bs:] == -7).all()
