@@ -342,6 +342,23 @@ __global__ __launch_bounds__(NWV * 64, 1) void skinny_gemm_v2_kernel(const Skinn
         braw[jj] = *(const uint16_t*)(biasp + (has_bias ? ne : 0));
       }
     }
+    // EPI_ROPE: the cos / sin pair of every (row, tile) this thread finishes travels with them (loaded after the MFMAs it was
+    // one more dependent L2 round trip at the end of the launch)
+    float csc[EPI == EPI_ROPE ? EPT : 1][EPI == EPI_ROPE ? TPP : 1], css[EPI == EPI_ROPE ? EPT : 1][EPI == EPI_ROPE ? TPP : 1];
+    if constexpr (EPI == EPI_ROPE) {
+      const int H = rpt >> 1;
+#pragma unroll
+      for (int jj = 0; jj < TPP; ++jj) {
+        const int n0 = (blockIdx.x + min(j0 + jj, cnt - 1) * G) * rpt;
+        const int i = H * ((n0 & 127) / rpt) + (en & (H - 1));
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+          const float* cs = ep.cos_sin + ep_pos[e] * 128;
+          csc[e][jj] = cs[i];
+          css[e][jj] = cs[64 + i];
+        }
+      }
+    }
 #pragma unroll
     for (int jj = 0; jj < TPP; ++jj) {
       const int j = j0 + jj;
@@ -404,8 +421,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void skinny_gemm_v2_kernel(const Skinn
               if (live) {
                 if (head < ep.hq + ep.hkv) {
                   const int i = H * u + (en & (H - 1));
-                  const float* cs = ep.cos_sin + ep_pos[e] * 128;
-                  const float c = rnd_to<OutT>(cs[i]), sn = rnd_to<OutT>(cs[64 + i]);
+                  const float c = rnd_to<OutT>(csc[e][jj]), sn = rnd_to<OutT>(css[e][jj]);
                   const float x1 = lo ? vr : pr, x2 = lo ? pr : vr;
                   const float o = lo ? rnd_to<OutT>(x1 * c) - rnd_to<OutT>(x2 * sn) : rnd_to<OutT>(x2 * c) + rnd_to<OutT>(x1 * sn);
                   const int col = i + (lo ? 0 : 64);
