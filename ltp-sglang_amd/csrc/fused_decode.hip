@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void add_rmsnorm_quant_kernel(const T* x, cons
   // Every global load of the kernel is issued up front (inputs were just written by other CUs, so each dependent
   // round trip costs ~2 us here): the norm weight travels with the inputs instead of after the first reduction.
   V8<T> wreg[MAXV], rreg[MAXV], xreg[MAXV];
-  f32x4_t s0[MAXV][2], s1[MAXV][2], swr[MAXV][2];
+  f32x4_t s0[MAXV][2], s1[MAXV][2], s2[MAXV][2], s3[MAXV][2], swr[MAXV][2];  // (four slabs prefetched: K = 14336 makes 4)
   const float sxm = (slabs && slab_sx) ? slab_sx[row] : 1.0f;
   const int ns = slabs ? nslabs : 0;
 #pragma unroll
@@ -43,6 +43,14 @@ __global__ __launch_bounds__(256) void add_rmsnorm_quant_kernel(const T* x, cons
         const float* sq = sp + (int64_t)tokens * hidden;
         s1[it][0] = *(const f32x4_t*)sq;
         s1[it][1] = *(const f32x4_t*)(sq + 4);
+      }
+      if (ns > 3) {
+        const float* sq = sp + 2 * (int64_t)tokens * hidden;
+        s2[it][0] = *(const f32x4_t*)sq;
+        s2[it][1] = *(const f32x4_t*)(sq + 4);
+        const float* sr = sp + 3 * (int64_t)tokens * hidden;
+        s3[it][0] = *(const f32x4_t*)sr;
+        s3[it][1] = *(const f32x4_t*)(sr + 4);
       }
       if (slab_sw) {
         swr[it][0] = *(const f32x4_t*)(slab_sw + ic * 8);
@@ -65,7 +73,13 @@ __global__ __launch_bounds__(256) void add_rmsnorm_quant_kernel(const T* x, cons
         if (ns > 1) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) f[j] += s1[it][j >> 2][j & 3];
-          for (int sI = 2; sI < ns; ++sI) {
+          if (ns > 3) {  // (same order of additions as the loop below)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] += s2[it][j >> 2][j & 3];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] += s3[it][j >> 2][j & 3];
+          }
+          for (int sI = (ns > 3 ? 4 : 2); sI < ns; ++sI) {
             const float* sp = slabs + ((int64_t)sI * tokens + row) * hidden + i * 8;
             const f32x4_t a0 = *(const f32x4_t*)sp, a1 = *(const f32x4_t*)(sp + 4);
 #pragma unroll

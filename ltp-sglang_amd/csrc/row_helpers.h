@@ -104,7 +104,32 @@ __device__ __forceinline__ void merge_quant_row(int b, const float* attn_logits,
       float acc[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-      for (int sI = 0; sI < nsplit; ++sI) {
+      // the first four splits' partials are all requested before the first is consumed (inside the attention launch this
+      // merge is the tail of the last workgroup of the request: one L2 round trip instead of one per split); same order of
+      // arithmetic as the plain loop
+      constexpr int PF = 4;
+      float lse_pf[PF];
+      f32x4_t a0_pf[PF], a1_pf[PF];
+#pragma unroll
+      for (int sI = 0; sI < PF; ++sI) {
+        const int sc = sI < nsplit ? sI : 0;  // clamped: a split that does not exist re-reads split 0 (never used)
+        lse_pf[sI] = attn_lse[slot0 + sc];
+        const float* lp = attn_logits + (slot0 + sc) * dv + d0;
+        a0_pf[sI] = *(const f32x4_t*)lp;
+        a1_pf[sI] = *(const f32x4_t*)(lp + 4);
+      }
+#pragma unroll
+      for (int sI = 0; sI < PF; ++sI) {
+        if (sI < nsplit && sI * per < seq_len) {
+          mg.begin(lse_pf[sI]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            acc[j] = mg.acc(acc[j], a0_pf[sI][j]);
+            acc[4 + j] = mg.acc(acc[4 + j], a1_pf[sI][j]);
+          }
+        }
+      }
+      for (int sI = PF; sI < nsplit; ++sI) {
         if (sI * per < seq_len) {
           mg.begin(attn_lse[slot0 + sI]);
           const float* lp = attn_logits + (slot0 + sI) * dv + d0;
