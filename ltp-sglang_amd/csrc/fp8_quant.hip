@@ -167,8 +167,71 @@ __global__ __launch_bounds__(256) void per_token_group_quant_kernel(const T* __r
   }
 }
 
+// Decode-sized batches (few tokens, one 256-thread workgroup each): the whole row is requested up front and held in registers
+// -- with the two strided loops of the general kernel every 16-byte piece was its own dependent L2 round trip (7 per thread at
+// hidden = 14336, twice), which is all a kernel with 32 workgroups is made of.  Same arithmetic, bit for bit.
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256) void per_token_quant_row_kernel(const T* __restrict__ in, uint8_t* __restrict__ out_q,
+                                                                  float* __restrict__ out_s, int hidden, int64_t in_stride) {
+  __shared__ float red[4];
+  const int tid = threadIdx.x;
+  const int64_t token = blockIdx.x;
+  const T* row = in + token * in_stride;
+  const int nvec = hidden / 8;
+  u32x4_t raw[MAXV];
+#pragma unroll
+  for (int it = 0; it < MAXV; ++it) {
+    const int i = tid + it * 256;
+    raw[it] = *(const u32x4_t*)(row + (i < nvec ? i : 0) * 8);
+  }
+  float vals[MAXV][8];
+  float amax = 0.f;
+#pragma unroll
+  for (int it = 0; it < MAXV; ++it) {
+    struct V8 { T v[8]; };
+    const V8 x = __builtin_bit_cast(V8, raw[it]);
+    const bool on = tid + it * 256 < nvec;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      vals[it][j] = (float)x.v[j];
+      if (on) amax = fmaxf(amax, fabsf(vals[it][j]));
+    }
+  }
+  amax = wave_reduce_max(amax);
+  if ((tid & 63) == 0) red[tid >> 6] = amax;
+  __syncthreads();
+  amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const float scale = amax / kFp8Max;
+  if (tid == 0) out_s[token] = scale;
+  const float inv = (scale == 0.f) ? 0.f : 1.0f / scale;
+  uint8_t* orow = out_q + token * hidden;
+#pragma unroll
+  for (int it = 0; it < MAXV; ++it) {
+    const int i = tid + it * 256;
+    if (i < nvec) {
+      float f[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = clamp448(vals[it][j] * inv);
+      *(u32x2_t*)(orow + i * 8) = pack8_fp8(f);
+    }
+  }
+}
+
 template <typename T>
 int launch_per_token(const void* in, void* q, float* s, int64_t tokens, int64_t hidden, int64_t in_stride, hipStream_t st) {
+  if (tokens <= 512 && hidden <= 256 * 8 * 8 && in_stride % 8 == 0 && ((uintptr_t)in % 16) == 0) {
+    if (hidden <= 256 * 8 * 2)
+      hipLaunchKernelGGL((per_token_quant_row_kernel<T, 2>), dim3((unsigned)tokens), dim3(256), 0, st, (const T*)in, (uint8_t*)q, s,
+                         (int)hidden, in_stride);
+    else if (hidden <= 256 * 8 * 4)
+      hipLaunchKernelGGL((per_token_quant_row_kernel<T, 4>), dim3((unsigned)tokens), dim3(256), 0, st, (const T*)in, (uint8_t*)q, s,
+                         (int)hidden, in_stride);
+    else
+      hipLaunchKernelGGL((per_token_quant_row_kernel<T, 8>), dim3((unsigned)tokens), dim3(256), 0, st, (const T*)in, (uint8_t*)q, s,
+                         (int)hidden, in_stride);
+    SGL_HIP_LAUNCH_CHECK();
+    return SGL_MI355_OK;
+  }
   if (tokens >= 2048) {
     hipLaunchKernelGGL((per_token_quant_kernel<T, 256, 4>), dim3((unsigned)((tokens + 3) / 4)), dim3(256), 0, st,
                        (const T*)in, (uint8_t*)q, s, hidden, tokens, in_stride);
