@@ -63,6 +63,12 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(T* out, const T* x, T* res
   const int nvec = hidden / 8;
   float vals[MAXV][8];
   float ss = 0.f;
+  V8<T> wreg[MAXV];  // the norm weight travels with the inputs (after the reduction it was one more dependent round trip)
+#pragma unroll
+  for (int it = 0; it < MAXV; ++it) {
+    const int i = threadIdx.x + it * 256;
+    wreg[it] = ld8(weight + (i < nvec ? i : 0) * 8);
+  }
 #pragma unroll
   for (int it = 0; it < MAXV; ++it) {
     const int i = threadIdx.x + it * 256;
@@ -92,10 +98,9 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(T* out, const T* x, T* res
   for (int it = 0; it < MAXV; ++it) {
     const int i = threadIdx.x + it * 256;
     if (i < nvec) {
-      const V8<T> w = ld8(weight + i * 8);
       V8<T> o;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) o.v[j] = (T)round_via<T>((vals[it][j] * rs) * (float)w.v[j]);
+      for (int j = 0; j < 8; ++j) o.v[j] = (T)round_via<T>((vals[it][j] * rs) * (float)wreg[it].v[j]);
       st8(orow + i * 8, o);
     }
   }
