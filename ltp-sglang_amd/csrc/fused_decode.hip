@@ -238,12 +238,24 @@ __global__ __launch_bounds__(1024) void argmax_vec_kernel(int64_t* out, const T*
   float best = -INFINITY;
   int64_t bi = 0x7fffffffffffffffLL;
   const int64_t nvec = vocab / 8;
-  for (int64_t i = threadIdx.x; i < nvec; i += 1024) {
-    const V8<T> a = ld8(row + i * 8);
+  // four 16-byte pieces requested per round trip (one workgroup per row: the loop is latency-, not bandwidth-bound)
+  for (int64_t i0 = threadIdx.x; i0 < nvec; i0 += 4 * 1024) {
+    V8<T> a[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float v = (float)a.v[j];
-      if (v > best) { best = v; bi = i * 8 + j; }  // ascending index within the thread: strict > keeps the first
+    for (int q = 0; q < 4; ++q) {
+      const int64_t i = i0 + q * 1024;
+      a[q] = ld8(row + (i < nvec ? i : i0) * 8);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int64_t i = i0 + q * 1024;
+      if (i < nvec) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float v = (float)a[q].v[j];
+          if (v > best) { best = v; bi = i * 8 + j; }  // ascending index within the thread: strict > keeps the first
+        }
+      }
     }
   }
   for (int64_t i = nvec * 8 + threadIdx.x; i < vocab; i += 1024) {
@@ -296,7 +308,11 @@ extern "C" int sgl_mi355_fused_add_rmsnorm_quant_fp8(const void* x, const float*
                      slab_sw, (T*)residual, (const T*)weight, eps, (T*)out_norm, (uint8_t*)out_q, out_s, tokens, hidden)
   DISPATCH_HALF(dtype, {
     if (slabs != nullptr) {
-      SGL_NORM_LAUNCH(4, true);
+      if (hidden <= 4096) {
+        SGL_NORM_LAUNCH(2, true);
+      } else {
+        SGL_NORM_LAUNCH(4, true);
+      }
     } else if (hidden <= 2048) {
       SGL_NORM_LAUNCH(1, false);
     } else if (hidden <= 4096) {
