@@ -160,48 +160,78 @@ __global__ __launch_bounds__(256, 2) void extend_attn_kernel(const ExtendParams 
   const int next_tiles = (ext_end + kKT - 1) / kKT;
   const int ntiles = npre_tiles + next_tiles;
 
-  u32x4_t kreg[NI], vreg[NI];
+  // Staging registers hold RAW loaded data: nothing consumes a load at issue time (zeroing the V rows past the end and the
+  // fp8 -> T conversion happen when the tile is written to LDS, one iteration later), and the prefix slots of tile t + 1 are
+  // fetched one iteration before its rows are issued -- a consumer at issue time puts a full global-memory round trip in
+  // front of every tile's first MFMA.
+  constexpr int RW = KV8 ? 2 : 4;  // dwords per lane and row piece as loaded
+  typedef uint32_t raw_t __attribute__((ext_vector_type(RW)));
+  u32x4_t kreg[NI], vreg[NI];   // extend rows (always 16-bit elements), and 16-bit prefix rows
+  raw_t kraw[NI], vraw[NI];     // fp8 prefix rows (KV8)
+  int idn[NI];                  // pool slots of the next prefix tile's rows
   const u32x4_t zero4 = {0u, 0u, 0u, 0u};
-  auto issue = [&](int t) {
-    if (t < npre_tiles) {
-      const int base = t * kKT;
+  // (16-bit pools: ONE unconditional load site per operand with selected addresses -- loads under a branch make the
+  // wait-count insertion put vmcnt(0) in front of the next tile's first MFMA)
+  const int32_t* idx_dummy = p.qo_indptr ? p.qo_indptr : p.extend_start_loc;  // any readable int32 when there is no prefix row
+  auto load_idx = [&](int t) {
+    const bool pre = t < npre_tiles;
 #pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        const int r = base + rsub + RPI * i;
-        const bool ok = r < pre_len;
-        const int id = ok ? idx_row[r] : 0;
-        u32x4_t vv;
-        if constexpr (KV8) {
-          kreg[i] = cvt8_fp8<T>(*(const u32x2_t*)(kpool + (int64_t)id * kpst));
-          vv = cvt8_fp8<T>(*(const u32x2_t*)(vpool + (int64_t)id * vpst));
-        } else {
-          kreg[i] = *(const u32x4_t*)(kpool + (int64_t)id * kpst);
-          vv = *(const u32x4_t*)(vpool + (int64_t)id * vpst);
+    for (int i = 0; i < NI; ++i) {
+      const int r = t * kKT + rsub + RPI * i;
+      const int32_t* src = pre ? idx_row + min(r, pre_len - 1) : idx_dummy;
+      idn[i] = *src;
+    }
+  };
+  auto issue = [&](int t) {
+    const bool pre = t < npre_tiles;
+    if constexpr (KV8) {
+      if (pre) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          kraw[i] = *(const raw_t*)(kpool + (int64_t)idn[i] * kpst);
+          vraw[i] = *(const raw_t*)(vpool + (int64_t)idn[i] * vpst);
         }
-        vreg[i] = ok ? vv : zero4;
+      } else {
+        const int base = (t - npre_tiles) * kKT;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          const int rr = min(base + rsub + RPI * i, ext_len - 1);
+          kreg[i] = *(const u32x4_t*)(kext + (int64_t)rr * kest);
+          vreg[i] = *(const u32x4_t*)(vext + (int64_t)rr * vest);
+        }
       }
     } else {
       const int base = (t - npre_tiles) * kKT;
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
-        const int r = base + rsub + RPI * i;
-        const bool ok = r < ext_len;
-        const int rr = ok ? r : 0;
-        kreg[i] = *(const u32x4_t*)(kext + (int64_t)rr * kest);
-        const u32x4_t vv = *(const u32x4_t*)(vext + (int64_t)rr * vest);
-        vreg[i] = ok ? vv : zero4;
+        const int rr = min(base + rsub + RPI * i, ext_len - 1);
+        const char* ka = pre ? kpool + (int64_t)idn[i] * kpst : kext + (int64_t)rr * kest;
+        const char* va = pre ? vpool + (int64_t)idn[i] * vpst : vext + (int64_t)rr * vest;
+        kreg[i] = *(const u32x4_t*)ka;
+        vreg[i] = *(const u32x4_t*)va;
       }
     }
   };
-  auto lstore = [&](int buf) {
+  auto lstore = [&](int buf, int t) {  // t: the tile held in the staging registers
     char* kl = smem + buf * 2 * TILE_B;
     char* vl = kl + TILE_B;
+    const bool pre = t < npre_tiles;
+    const int base = pre ? t * kKT : (t - npre_tiles) * kKT;
+    const int limit = pre ? pre_len : ext_len;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int row = rsub + RPI * i;
       const int fk = (row / RPB) & KMASK, fv = (row / RPB) & VMASK;
-      *(u32x4_t*)(kl + row * ROWB + ((c16 ^ fk) << 4)) = kreg[i];
-      *(u32x4_t*)(vl + row * ROWB + ((((c16 >> 1) ^ fv) << 5) | ((c16 & 1) << 4))) = vreg[i];
+      u32x4_t kk = kreg[i], vv = vreg[i];
+      if constexpr (KV8) {
+        if (pre) {
+          kk = cvt8_fp8<T>(__builtin_bit_cast(u32x2_t, kraw[i]));
+          vv = cvt8_fp8<T>(__builtin_bit_cast(u32x2_t, vraw[i]));
+        }
+      }
+      if (base + row >= limit) vv = zero4;  // 0 * garbage must stay 0
+      *(u32x4_t*)(kl + row * ROWB + ((c16 ^ fk) << 4)) = kk;
+      *(u32x4_t*)(vl + row * ROWB + ((((c16 >> 1) ^ fv) << 5) | ((c16 & 1) << 4))) = vv;
     }
   };
 
@@ -215,13 +245,16 @@ __global__ __launch_bounds__(256, 2) void extend_attn_kernel(const ExtendParams 
   const float scale_log2 = p.sm_scale * kLog2e;
 
   if (ntiles > 0) {
+    load_idx(0);
     issue(0);
-    lstore(0);
+    load_idx(1);
+    lstore(0, 0);
   }
   __syncthreads();
   for (int t = 0; t < ntiles; ++t) {
     const int buf = t & 1;
-    if (t + 1 < ntiles) issue(t + 1);
+    issue(min(t + 1, ntiles - 1));  // unconditional (after the last tile: a re-read that is never stored)
+    load_idx(t + 2);
     const char* kl = smem + buf * 2 * TILE_B;
     const char* vl = kl + TILE_B;
     const bool in_prefix = t < npre_tiles;
@@ -340,7 +373,7 @@ __global__ __launch_bounds__(256, 2) void extend_attn_kernel(const ExtendParams 
         }
       }
     }
-    if (t + 1 < ntiles) lstore(buf ^ 1);
+    if (t + 1 < ntiles) lstore(buf ^ 1, t + 1);
     __syncthreads();
   }
 
