@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256, 2) void extend_attn_kernel(const ExtendParams 
   // ---- block -> (request, kv head chunk, q block); same (request, kv head) => same blockIdx % 8 (one XCD) ----
   const int bid = blockIdx.x;
   const int lo = bid & 7, rest = bid >> 3;
-  const int qb = rest % p.nqb;
+  const int qb = p.nqb - 1 - rest % p.nqb;  // longest key ranges first (causal): the launch ends with the short blocks
   const int pair = (rest / p.nqb) * 8 + lo;
   const int npairs = p.bs * p.hkv * p.hchunks;
   if (pair >= npairs) return;
@@ -349,28 +349,47 @@ __global__ __launch_bounds__(256, 2) void extend_attn_kernel(const ExtendParams 
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[qt][n] *= alpha;
       }
-      // ---- O^T += V^T P^T ----
-#pragma unroll
-      for (int n = 0; n < NT; ++n) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          s16x4_t t0, t1;
-          {
-            const int row = 32 * u + 4 * g + (a >> 2);
-            const int fv = (row / RPB) & VMASK;
-            t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (s16x4_t __attribute__((address_space(3)))*)(vl + row * ROWB + ((n ^ fv) << 5) + ((a & 3) << 3)));
-          }
-          {
-            const int row = 32 * u + 16 + 4 * g + (a >> 2);
-            const int fv = (row / RPB) & VMASK;
-            t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (s16x4_t __attribute__((address_space(3)))*)(vl + row * ROWB + ((n ^ fv) << 5) + ((a & 3) << 3)));
-          }
-          const vec8 vf = __builtin_bit_cast(vec8, __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7));
-#pragma unroll
-          for (int qt = 0; qt < 2; ++qt) acc[qt][n] = Tr::mfma16(vf, pf[qt][u], acc[qt][n]);
+      // ---- O^T += V^T P^T: the V^T fragments of two column tiles (8 transposed reads) are requested while the previous two are
+      // multiplied -- left to itself the compiler kept ONE fragment in flight, i.e. an LDS round trip per pair of MFMAs ----
+      auto ld_v = [&](int n, int u) -> vec8 {
+        s16x4_t t0, t1;
+        {
+          const int row = 32 * u + 4 * g + (a >> 2);
+          const int fv = (row / RPB) & VMASK;
+          t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (s16x4_t __attribute__((address_space(3)))*)(vl + row * ROWB + ((n ^ fv) << 5) + ((a & 3) << 3)));
         }
+        {
+          const int row = 32 * u + 16 + 4 * g + (a >> 2);
+          const int fv = (row / RPB) & VMASK;
+          t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (s16x4_t __attribute__((address_space(3)))*)(vl + row * ROWB + ((n ^ fv) << 5) + ((a & 3) << 3)));
+        }
+        return __builtin_bit_cast(vec8, __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7));
+      };
+      constexpr int NB = 2;  // column tiles per batch
+      vec8 vfb[2][NB][2];
+#pragma unroll
+      for (int nn = 0; nn < NB; ++nn)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) vfb[0][nn][u] = ld_v(nn, u);
+#pragma unroll
+      for (int nb = 0; nb < NT / NB; ++nb) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (nb + 1 < NT / NB) {
+#pragma unroll
+          for (int nn = 0; nn < NB; ++nn)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) vfb[(nb + 1) & 1][nn][u] = ld_v((nb + 1) * NB + nn, u);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int nn = 0; nn < NB; ++nn)
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+              acc[qt][nb * NB + nn] = Tr::mfma16(vfb[nb & 1][nn][u], pf[qt][u], acc[qt][nb * NB + nn]);
       }
     }
     if (t + 1 < ntiles) lstore(buf ^ 1, t + 1);
