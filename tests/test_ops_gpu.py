@@ -570,3 +570,24 @@ def test_decode_prepare_matches_index_ops(sk):
     assert torch.equal(r2t, r2t_ref) and torch.equal(seq2, seq_ref)
     for got, want in zip(bufs, (ids, req, seq_ref, loc, pos_ref)):
         assert torch.equal(got[:bs], want) and (got[bs:] == -7).all()
+
+
+def test_gemm256_phase_stagger_does_not_change_results(sk):
+    """The start stagger of the 256x256 kernel (sgl_mi355_fp8_gemm_force_tile(1000 + q)) only delays workgroups."""
+    from ltp_sglang_amd._cabi import lib
+
+    c = _cases.build_gemm_case(dict(m=2048, n=2304, k=512, bias=True, out="bf16"), seed=77)   
+    a, wt, sa, sb, bias = c["a"].to(DEV), c["w"].to(DEV), c["sa"].to(DEV), c["sb"].to(DEV), c["bias"].to(DEV)
+    a = a.repeat(8, 1)   # M = 16384: 64 x 9 = 576 tiles, more than two per CU, so the stagger is active
+    sa = sa.repeat(8)
+    outs = []
+    try:
+        lib.sgl_mi355_fp8_gemm_force_tile(2)
+        for q in (0, 1, 3):
+            lib.sgl_mi355_fp8_gemm_force_tile(1000 + q)
+            outs.append(sk.fp8_scaled_mm(a, wt.t(), sa, sb, torch.bfloat16, bias))
+    finally:
+        lib.sgl_mi355_fp8_gemm_force_tile(1001)
+        lib.sgl_mi355_fp8_gemm_force_tile(0)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert torch.equal(outs[0][:2048], outs[0][2048:4096])   # the repeated rows give repeated outputs
