@@ -6,11 +6,13 @@ from __graft_entry__ import load_package
 load_package()
 from ltp_sglang_amd import sgl_kernel
 
-def run(bs=32, hq=32, hkv=8, d=128, seq=2048, nsplit=2, max_splits=16, iters=20, layers=8):
+def run(bs=32, hq=32, hkv=8, d=128, seq=2048, nsplit=2, max_splits=16, iters=20, layers=8, contiguous=False):
     dev = torch.device("cuda:0")
     g = torch.Generator(device="cpu").manual_seed(0)
     pool = bs * seq + 1
     kv_indices = (torch.randperm(pool - 1, generator=g) + 1).int()[: bs * seq].to(dev)
+    if contiguous:  # the slots a sorted free list hands to a prefill: consecutive per request
+        kv_indices = (torch.arange(bs * seq, dtype=torch.int32) + 1).to(dev)
     kv_indptr = (torch.arange(bs + 1, dtype=torch.int32) * seq).to(dev)
     q = torch.randn(bs, hq, d, device=dev).bfloat16()
     # several layers' worth of distinct pools so the 256 MiB infinity cache cannot hold the stream
@@ -33,7 +35,7 @@ def run(bs=32, hq=32, hkv=8, d=128, seq=2048, nsplit=2, max_splits=16, iters=20,
     times.sort()
     ms = times[len(times) // 2]
     byts = bs * seq * hkv * d * 2 * 2
-    print(f"bs={bs} seq={seq} hq={hq} hkv={hkv} nsplit={nsplit}: {ms*1e3:.1f} us/layer  {byts/ms/1e6:.0f} GB/s algorithmic")
+    print(f"bs={bs} seq={seq} hq={hq} hkv={hkv} nsplit={nsplit}{' contiguous slots' if contiguous else ''}: {ms*1e3:.1f} us/layer  {byts/ms/1e6:.0f} GB/s algorithmic")
 
 if __name__ == "__main__":
     from ltp_sglang_amd._cabi import lib
@@ -42,5 +44,7 @@ if __name__ == "__main__":
         print("mode", mode)
         for ns in (1, 2, 4, 5, 8, 16):
             run(nsplit=ns)
+        if mode == 0:
+            run(nsplit=4, contiguous=True)
         run(bs=128, hq=8, hkv=1, seq=2048, nsplit=4)
         run(bs=128, hq=8, hkv=1, seq=2048, nsplit=8)
