@@ -292,6 +292,10 @@ int64_t sgl_mi355_radix_node_info(void* tree, int64_t node, int64_t* parent, int
 int sgl_mi355_awq_repack(const void* qweight, const void* scales, const void* qzeros, void* qpacked, void* sz, int K, int N,
                          int group_size, int scale_dtype, void* stream);
 /* number of f32 [M, N] slabs sgl_mi355_awq_gemm needs as workspace for this K (1: none) */
+/* Dense W [N, K] (row-major, scale dtype) from the repacked image: awq_dequantize + transpose in one pass for the M > 32
+ * (prefill) matmul of AWQLinearMethod.apply (awq.py:401-418); values are exactly awq_dequantize's. */
+int sgl_mi355_awq_unpack_nk(const void* qpacked, const void* sz, void* out, int N, int K, int group_size, int dtype,
+                            void* stream);
 int sgl_mi355_awq_gemm_num_kranges(int K);
 int sgl_mi355_awq_gemm(const void* x, int64_t x_stride_elems, const void* qpacked, const void* sz, void* y,
                        int64_t y_stride_elems, const void* bias, int M, int N, int K, int group_size, int dtype,

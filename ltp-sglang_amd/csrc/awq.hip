@@ -345,6 +345,34 @@ int awq_launch(const AwqGemmParams& p, int kranges, float* slabs, hipStream_t st
   return SGL_MI355_OK;
 }
 
+// Repacked weight -> dense W [N, K] (row-major, the layout the tiled GEMM multiplies by) in ONE pass: for prefill-sized M the
+// reference structure is awq_dequantize ([K, N]) + matmul (awq.py:401-418); reading the int4 image that already exists for the
+// decode GEMM and writing the transposed rows directly replaces dequantise + a separate 2-D transpose.  One wave per
+// (16-row tile, 128-k block): a wave-wide 16-byte load, four dequantised k-steps, four 16-byte stores per lane (64 contiguous
+// bytes per row and k-step).  Values are AwqDequant's, i.e. exactly awq_dequantize's.
+template <typename T, int SG>
+__global__ __launch_bounds__(256) void awq_unpack_nk_kernel(const uint32_t* __restrict__ qpacked, const uint32_t* __restrict__ sz,
+                                                            T* __restrict__ out, int N, int K, int G, int KB, int64_t nunits) {
+  typedef typename ElemTraits<T>::vec8 vec8;
+  const int lane = threadIdx.x & 63;
+  const int a = lane & 15, g = lane >> 4;
+  for (int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); unit < nunits; unit += (int64_t)gridDim.x * 4) {
+    const int t = (int)(unit / KB), b = (int)(unit - (int64_t)t * KB);
+    const u32x4_t wq = *(const u32x4_t*)(qpacked + (unit * 64 + lane) * 4);
+    uint32_t szw[SG];
+#pragma unroll
+    for (int q = 0; q < SG; ++q) szw[q] = sz[(int64_t)((128 * b + (128 / SG) * q) / G) * N + 16 * t + a];
+    T* orow = out + (int64_t)(16 * t + a) * K + 128 * b + 8 * g;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      AwqDequant<T> dq;
+      dq.setup(szw[SG == 1 ? 0 : (SG == 2 ? s4 / 2 : s4)]);
+      const vec8 v = dq.run(wq[s4]);
+      *(vec8*)(orow + 32 * s4) = v;
+    }
+  }
+}
+
 template <typename T>
 int awq_dispatch(const AwqGemmParams& p, int kranges, float* slabs, hipStream_t st) {
   const int sg = p.G % 128 == 0 ? 1 : 128 / p.G;
@@ -378,6 +406,34 @@ extern "C" int sgl_mi355_awq_dequantize(const void* qweight, const void* scales,
   else
     hipLaunchKernelGGL((awq_dequant_kernel<__bf16>), dim3(blocks), dim3(256), 0, st, (const uint32_t*)qweight,
                        (const __bf16*)scales, (const uint32_t*)qzeros, (__bf16*)out, K, num_packed_cols, group_size);
+  SGL_HIP_LAUNCH_CHECK();
+  return SGL_MI355_OK;
+}
+
+// Dense W [N, K] (scale dtype) from the repacked image: dequantise + transpose in one pass, for M > 32 (prefill).
+extern "C" int sgl_mi355_awq_unpack_nk(const void* qpacked, const void* sz, void* out, int N, int K, int group_size, int dtype,
+                                       void* stream) {
+  SGL_CHECK(N > 0 && K > 0 && group_size > 0, "awq_unpack_nk: bad shape");
+  SGL_CHECK(qpacked && sz && out, "awq_unpack_nk: null pointer");
+  SGL_CHECK(K % 128 == 0 && N % 16 == 0, "awq_unpack_nk: needs K %% 128 == 0 and N %% 16 == 0 (K=%d N=%d)", K, N);
+  SGL_CHECK(K % group_size == 0 && (group_size % 128 == 0 || group_size == 64 || group_size == 32),
+            "awq_unpack_nk: group_size=%d must be 32, 64 or a multiple of 128 dividing K", group_size);
+  SGL_CHECK(dtype == SGL_BF16 || dtype == SGL_F16, "awq_unpack_nk: dtype must be bf16 or f16");
+  SGL_CHECK(((uintptr_t)qpacked % 16) == 0 && ((uintptr_t)out % 16) == 0, "awq_unpack_nk: qpacked / out must be 16-byte aligned");
+  const int KB = K / 128;
+  const int64_t nunits = (int64_t)(N / 16) * KB;
+  const unsigned blocks = (unsigned)((nunits + 3) / 4 > 16384 ? 16384 : (nunits + 3) / 4);
+  const int sg = group_size % 128 == 0 ? 1 : 128 / group_size;
+  hipStream_t st = (hipStream_t)stream;
+#define SGL_UNPACK(Tv, SGv)                                                                                                \
+  hipLaunchKernelGGL((awq_unpack_nk_kernel<Tv, SGv>), dim3(blocks), dim3(256), 0, st, (const uint32_t*)qpacked, (const uint32_t*)sz, \
+                     (Tv*)out, N, K, group_size, KB, nunits)
+  if (dtype == SGL_F16) {
+    if (sg == 1) SGL_UNPACK(_Float16, 1); else if (sg == 2) SGL_UNPACK(_Float16, 2); else SGL_UNPACK(_Float16, 4);
+  } else {
+    if (sg == 1) SGL_UNPACK(__bf16, 1); else if (sg == 2) SGL_UNPACK(__bf16, 2); else SGL_UNPACK(__bf16, 4);
+  }
+#undef SGL_UNPACK
   SGL_HIP_LAUNCH_CHECK();
   return SGL_MI355_OK;
 }

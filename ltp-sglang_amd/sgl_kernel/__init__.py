@@ -29,6 +29,7 @@ from .gemm import (
     awq_dequantize,
     awq_gemm,
     awq_repack,
+    awq_unpack_nk,
     dense_linear,
     fp8_linear_slabs,
     fp8_scaled_mm,

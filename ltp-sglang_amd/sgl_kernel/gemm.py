@@ -72,6 +72,15 @@ def awq_repack(qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.Tensor
     return qpacked, sz
 
 
+def awq_unpack_nk(qpacked: torch.Tensor, sz: torch.Tensor, group_size: int, dtype) -> torch.Tensor:
+    """Dense W [N, K] (row-major) from the image made by :func:`awq_repack`: awq_dequantize(...).t() in one pass."""
+    _cuda(qpacked, sz)
+    n, k = sz.shape[1], qpacked.shape[1] * 128
+    out = torch.empty((n, k), dtype=dtype, device=qpacked.device)
+    check(lib.sgl_mi355_awq_unpack_nk(ptr(qpacked), ptr(sz), ptr(out), n, k, int(group_size), dtype_code(dtype), current_stream()))
+    return out
+
+
 def awq_gemm(x: torch.Tensor, qpacked: torch.Tensor, sz: torch.Tensor, group_size: int,
              bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """y [M, N] = x [M, K] @ dequant(W) (+ bias) for M <= 32 on a weight re-laid by :func:`awq_repack`; the weight values

@@ -12,7 +12,7 @@ import torch
 from torch.nn.parameter import Parameter
 
 from ...._cabi import check, current_stream, lib, ptr
-from ....sgl_kernel import awq_dequantize, awq_gemm, awq_repack, dense_linear
+from ....sgl_kernel import awq_dequantize, awq_gemm, awq_repack, awq_unpack_nk, dense_linear
 from .base_config import LinearMethodBase, QuantizationConfig
 
 
@@ -85,6 +85,10 @@ class AWQLinearMethod(LinearMethodBase):
         packed = getattr(layer, "_awq_packed", None)
         if packed is not None and x2d.shape[0] <= 32 and x2d.dtype == scales.dtype:
             return awq_gemm(x2d.contiguous(), packed[0], packed[1], self.quant_config.group_size, bias).reshape(out_shape)
+        if packed is not None and x2d.dtype == scales.dtype:
+            # prefill: the dense [N, K] weight straight from the repacked image (dequantise + transpose in one pass)
+            w_nk = awq_unpack_nk(packed[0], packed[1], self.quant_config.group_size, scales.dtype)
+            return dense_linear(x2d.contiguous(), w_nk, bias).reshape(out_shape)
         w_kn = awq_dequantize(qweight, scales, qzeros)              # [K, N], what the reference multiplies by
         w_nk = torch.empty((w_kn.shape[1], w_kn.shape[0]), dtype=w_kn.dtype, device=w_kn.device)
         check(lib.sgl_mi355_transpose_2d(ptr(w_nk), ptr(w_kn), w_kn.shape[0], w_kn.shape[1], current_stream()))

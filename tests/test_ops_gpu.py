@@ -591,3 +591,15 @@ def test_gemm256_phase_stagger_does_not_change_results(sk):
         lib.sgl_mi355_fp8_gemm_force_tile(0)
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     assert torch.equal(outs[0][:2048], outs[0][2048:4096])   # the repeated rows give repeated outputs
+
+
+@pytest.mark.parametrize("k,n,g,dtype", [(512, 256, 128, torch.float16), (3584, 4608, 128, torch.float16), (1024, 512, 64, torch.bfloat16),
+                                         (256, 1040, 32, torch.bfloat16)])
+def test_awq_unpack_nk_equals_dequantize_transposed(k, n, g, dtype, sk):
+    """Dense W [N, K] from the repacked image == awq_dequantize(...).t(), bit for bit (the prefill matmul's weight)."""
+    qw, qz, sc = _awq_case(k, n, g, dtype, seed=k + n)
+    qw, sc, qz = qw.to(DEV), sc.to(DEV), qz.to(DEV)
+    want = sk.awq_dequantize(qw, sc, qz).t().contiguous()
+    qp, sz = sk.awq_repack(qw, sc, qz)
+    got = sk.awq_unpack_nk(qp, sz, g, dtype)
+    assert got.shape == want.shape and torch.equal(got.view(torch.int16), want.view(torch.int16))
