@@ -278,20 +278,29 @@ __global__ __launch_bounds__(256, 2) void extend_attn_kernel(const ExtendParams 
     if (!skip) {
       // ---- S^T tiles: s[qt][tt][r] = score(query row a of tile qt, key 16 tt + 4 g + r) ----
       f32x4_t s[2][4];
-#pragma unroll
-      for (int tt = 0; tt < 4; ++tt) {
+      // K fragments two key groups ahead of their MFMAs (double-buffered registers): a fragment set requested right before its
+      // MFMAs made every 8 of them wait for an LDS round trip
+      vec8 kfb[2][KS];
+      auto ld_k = [&](int tt, vec8 (&kf)[KS]) {
         const int row = 16 * tt + a;
         const int fk = (row / RPB) & KMASK;
-        vec8 kf[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) kf[ks] = *(const vec8*)(kl + row * ROWB + (((4 * ks + g) ^ fk) << 4));
+      };
+      ld_k(0, kfb[0]);
+      ld_k(1, kfb[1]);
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
           f32x4_t c = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int ks = 0; ks < KS; ++ks) c = Tr::mfma16(kf[ks], qf[qt][ks], c);
+          for (int ks = 0; ks < KS; ++ks) c = Tr::mfma16(kfb[tt & 1][ks], qf[qt][ks], c);
           s[qt][tt] = c;
         }
+        __builtin_amdgcn_sched_barrier(0);
+        if (tt + 2 < 4) ld_k(tt + 2, kfb[tt & 1]);
       }
       // ---- soft-cap every score (CAP; otherwise the scale is folded into the exponent below); then ONE wave-uniform branch
       // masks the ragged last tile of a phase and the causal diagonal (tested per score, the flags cut this loop into ~70
