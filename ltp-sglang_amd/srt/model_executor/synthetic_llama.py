@@ -95,10 +95,19 @@ class LlamaAttention(nn.Module):
                                         quant_config=quant_config, params_dtype=dtype, prefix=f"{prefix}.o_proj")
         self.rotary_emb = get_rope(self.head_dim, self.head_dim, cfg.max_position_embeddings, cfg.rope_theta, True, dtype=dtype)
         self.attn = RadixAttention(self.num_heads, self.head_dim, self.head_dim ** -0.5, self.num_kv_heads, layer_id)
+        self.fused_rope_kv = True   # decode: rotary_emb + set_kv_buffer in one launch (bit-identical; 16-bit KV pools)
 
     def forward(self, positions, hidden_states, forward_batch):
         qkv, _ = self.qkv_proj(hidden_states)
         q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
+        pool = forward_batch.token_to_kv_pool
+        if self.fused_rope_kv and forward_batch.forward_mode.is_decode() and pool.dtype != torch.float8_e4m3fn:
+            lid = self.attn.layer_id
+            K.rope_set_kv(positions, q, k, v, self.head_dim, self.rotary_emb.cos_sin_cache, True, pool.get_key_buffer(lid),
+                          pool.get_value_buffer(lid), forward_batch.out_cache_loc)
+            attn_output = self.attn(q, k, v, forward_batch, save_kv_cache=False)
+            output, _ = self.o_proj(attn_output)
+            return output
         q, k = self.rotary_emb(positions, q, k)
         attn_output = self.attn(q, k, v, forward_batch)
         output, _ = self.o_proj(attn_output)
