@@ -137,10 +137,11 @@ __global__ __launch_bounds__(1024) void decode_meta_kernel(int32_t* kv_indptr, i
   }
   if (!num_kv_splits) return;
   if (static_splits == 2 && device_core_count > 0) {
-    // MI355X balance rule (measured, tools/bench_decode_attn.py): about TWO rounds of resident workgroups
-    // (2 x 256-thread workgroups per CU) stream fastest -- one round starts and drains in lock step, more rounds pay
-    // the per-workgroup prologue again.  Split length T = total key rows x (kv heads x head chunks) / (2 x resident),
-    // rounded up to whole 32-token tiles; each request gets ceil(len / T) splits.
+    // MI355X balance rule: ONE round of resident workgroups (2 x 256-thread workgroups per CU).  Split length T = total key
+    // rows x (kv heads x head chunks) / resident, rounded up to whole 32-token tiles; each request gets ceil(len / T) splits.
+    // (The kernel alone streams equally fast with one or two rounds; with the stage-2 merge inside the launch every extra
+    // split is partial-result traffic and merge work at the tail, and an A/B of whole decode steps on one box favours one
+    // round at every shape tried: 8B fp8 bs 32 / 48 / 64 +1.5 / +2.4 / +0.5 %, fp8 KV +2.9 %, Qwen2-7B AWQ +3.7 %, bs 128 equal.)
     int64_t tot = 0;
     for (int i = tid; i < num_seq; i += 1024) tot += ld_idx(seq_lens, i, sl64);
 #pragma unroll
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(1024) void decode_meta_kernel(int32_t* kv_indptr, i
     for (int w = 0; w < 16; ++w) tot += scan[w];
     const int kv_group = num_head / num_kv_head;
     const int64_t units = (int64_t)num_kv_head * ((kv_group + 15) / 16) * num_group;
-    const int64_t target_wgs = 2ll * 2 * device_core_count;
+    const int64_t target_wgs = 2ll * device_core_count;
     int64_t T = (tot * units + target_wgs - 1) / target_wgs;
     T = (T + 31) / 32 * 32;
     if (T < 64) T = 64;
