@@ -15,7 +15,8 @@ import torch  # noqa: F401  -- must be loaded BEFORE the library: torch brings i
 #                  "no ROCm-capable device is detected")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsgl_mi355.so")
+# SGL_MI355_LIB selects another build of the same library (tools/ab_libs.sh: same-box A/B without touching the product file)
+LIB_PATH = os.environ.get("SGL_MI355_LIB") or os.path.join(_HERE, "lib", "libsgl_mi355.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "sgl_mi355.h")
 
 BF16, F16, F32, FP8_E4M3 = 0, 1, 2, 3
