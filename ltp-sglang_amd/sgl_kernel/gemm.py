@@ -7,29 +7,37 @@ import torch
 from .._cabi import check, current_stream, dtype_code, lib, ptr
 
 _WORKSPACES = {}
+_RETIRED = []  # superseded workspaces: never freed (a captured HIP graph may still hold their address)
+WORKSPACE_FLOATS = 1 << 25  # 128 MiB: 4 k-ranges x 64 rows x 128 256 columns (70B-shaped lm_head at M = 64) fits
+
+
+def _workspace(device, need: int):
+    """The per-device f32 split-K scratch shared by the skinny, tiled and AWQ GEMMs.
+
+    Its address must stay valid for every HIP graph that captured a launch using it, so it is allocated ONCE at
+    ``WORKSPACE_FLOATS`` (covers every shape of the BASELINE configs); a larger request allocates a new buffer and the old
+    one is parked in ``_RETIRED`` for the life of the process instead of being returned to the caching allocator (where
+    another tensor would receive its memory while an old graph still writes split-K partials into it)."""
+    buf = _WORKSPACES.get(device)
+    if buf is None or buf.numel() < need:
+        if buf is not None:
+            _RETIRED.append(buf)
+        buf = torch.empty(max(int(need), WORKSPACE_FLOATS), dtype=torch.float32, device=device)
+        _WORKSPACES[device] = buf
+    return buf, buf.numel()
 
 
 def _splitk_workspace(m, n, k, dtype, device):
-    """f32 slab workspace for the split-K form of the weight-streaming GEMM (one cached buffer per device: the
-    launcher must not allocate inside a captured graph)."""
+    """f32 slab workspace for the split-K form of the weight-streaming GEMM."""
     kr = lib.sgl_mi355_skinny_gemm_num_kranges(m, n, k, dtype_code(dtype))
     if kr <= 1:
         return None, 0
-    need = kr * m * n
-    buf = _WORKSPACES.get(device)
-    if buf is None or buf.numel() < need:
-        buf = torch.empty(max(need, 1 << 22), dtype=torch.float32, device=device)
-        _WORKSPACES[device] = buf
-    return buf, buf.numel()
+    return _workspace(device, kr * m * n)
 
 
 def _tiled_workspace(device):
-    """Cached f32 scratch for the tiled GEMM's split-K (few-tile launches: decode at 64 < M <= 256)."""
-    buf = _WORKSPACES.get(device)
-    if buf is None or buf.numel() < (1 << 24):
-        buf = torch.empty(1 << 24, dtype=torch.float32, device=device)
-        _WORKSPACES[device] = buf
-    return buf, buf.numel()
+    """f32 scratch for the tiled GEMM's split-K (few-tile launches: decode at 64 < M <= 256)."""
+    return _workspace(device, 1 << 24)
 
 
 def _cuda(*ts):
@@ -95,12 +103,7 @@ def awq_gemm(x: torch.Tensor, qpacked: torch.Tensor, sz: torch.Tensor, group_siz
     kr = lib.sgl_mi355_awq_gemm_num_kranges(k)
     ws, ws_n = None, 0
     if kr > 1:
-        need = kr * m * n
-        ws = _WORKSPACES.get(x.device)
-        if ws is None or ws.numel() < need:
-            ws = torch.empty(max(need, 1 << 22), dtype=torch.float32, device=x.device)
-            _WORKSPACES[x.device] = ws
-        ws_n = ws.numel()
+        ws, ws_n = _workspace(x.device, kr * m * n)
     check(lib.sgl_mi355_awq_gemm(ptr(x), x.stride(0), ptr(qpacked), ptr(sz), ptr(out), out.stride(0), ptr(bias), m, n, k,
                                  int(group_size), dtype_code(x.dtype), ptr(ws), ws_n, current_stream()))
     return out

@@ -603,3 +603,41 @@ def test_awq_unpack_nk_equals_dequantize_transposed(k, n, g, dtype, sk):
     qp, sz = sk.awq_repack(qw, sc, qz)
     got = sk.awq_unpack_nk(qp, sz, g, dtype)
     assert got.shape == want.shape and torch.equal(got.view(torch.int16), want.view(torch.int16))
+
+
+def test_splitk_workspace_survives_growth_under_a_captured_graph(sk, pkg, monkeypatch):
+    """a HIP graph bakes in the split-K workspace's address.  A later, larger request must not hand
+    that memory back to the caching allocator: capture a split-K launch, force the workspace to grow, let other tensors
+    take whatever the allocator has, replay, and compare with the eager result."""
+    from ltp_sglang_amd.sgl_kernel import gemm
+
+    monkeypatch.setattr(gemm, "WORKSPACE_FLOATS", 1 << 16)
+    monkeypatch.setattr(gemm, "_WORKSPACES", {})
+    torch.manual_seed(0)
+    m, n, k = 32, 512, 8192      # K > 4096 bytes: k-ranges -> the f32 slab workspace is used
+    x = torch.randn(m, k, device=DEV).to(torch.float8_e4m3fn)
+    w = torch.randn(n, k, device=DEV).to(torch.float8_e4m3fn)
+    sa = torch.rand(m, device=DEV) + 0.5
+    sb = torch.rand(n, device=DEV) + 0.5
+    assert pkg._cabi.lib.sgl_mi355_skinny_gemm_num_kranges(m, n, k, pkg._cabi.FP8_E4M3) > 1
+    eager = sk.fp8_scaled_mm(x, w.t(), sa, sb, torch.bfloat16)
+    first = gemm._WORKSPACES[x.device]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            out_g = sk.fp8_scaled_mm(x, w.t(), sa, sb, torch.bfloat16)
+    torch.cuda.synchronize()
+    # a larger request (lm_head-like) replaces the workspace ...
+    big = sk.fp8_scaled_mm(x, torch.randn(8192, k, device=DEV).to(torch.float8_e4m3fn).t(), sa,
+                           torch.ones(8192, device=DEV), torch.bfloat16)
+    assert gemm._WORKSPACES[x.device] is not first and any(b is first for b in gemm._RETIRED)
+    del big
+    # ... and whatever the allocator can hand out is overwritten
+    junk = [torch.full((1 << 16,), float("nan"), device=DEV) for _ in range(64)]
+    out_g.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out_g, eager)
+    assert all(torch.isnan(j).all() for j in junk)   # the replay wrote nothing into memory owned by other tensors
