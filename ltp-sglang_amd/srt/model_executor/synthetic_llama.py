@@ -145,7 +145,9 @@ class LlamaForCausalLM(nn.Module):
         self.fused_attn_merge = True   # decode: stage-2 merge + quant by the last-arriving workgroup of each request
         self.fused_epilogues = True
         qc = None
-        if quantization is not None:
+        if quantization is not None and not isinstance(quantization, str):
+            qc = quantization   # a QuantizationConfig instance (e.g. a serialized-checkpoint config)
+        elif quantization is not None:
             cls = get_quantization_config(quantization)
             qc = cls(4, 128, True) if quantization == "awq" else cls()
         self.quant_config = qc
@@ -193,6 +195,31 @@ class LlamaForCausalLM(nn.Module):
                 else:
                     mod.bias.copy_(randn(mod.bias.shape))
             qm.process_weights_after_loading(mod)
+
+    @torch.no_grad()
+    def load_checkpoint(self, ckpt: dict):
+        """Loads an unsharded in-memory checkpoint (TP 1): ``embed``, ``lm_head``, ``norm`` and per layer ``ln1``, ``ln2`` and
+        ``qkv`` / ``o`` / ``gate_up`` / ``down`` dicts whose keys are the parameter names each linear method's
+        create_weights registered (weight, weight_scale, input_scale, qweight, qzeros, scales, bias), then runs
+        process_weights_after_loading -- the two calls a model loader makes (model_loader/loader.py).  Used by the G7 test."""
+        assert self.tp_size == 1, "load_checkpoint takes unsharded tensors"
+        dev = self.embed_tokens.device
+        self.embed_tokens.copy_(ckpt["embed"].to(dev))
+        self.lm_head.copy_(ckpt["lm_head"].to(dev))
+        self.norm.weight.copy_(ckpt["norm"].to(dev))
+        for layer, L in zip(self.layers, ckpt["layers"]):
+            layer.input_layernorm.weight.copy_(L["ln1"].to(dev))
+            layer.post_attention_layernorm.weight.copy_(L["ln2"].to(dev))
+            for mod, t in ((layer.self_attn.qkv_proj, L["qkv"]), (layer.self_attn.o_proj, L["o"]),
+                           (layer.mlp.gate_up_proj, L["gate_up"]), (layer.mlp.down_proj, L["down"])):
+                for name, value in t.items():
+                    param = getattr(mod, name)
+                    if param is None:
+                        raise RuntimeError(f"checkpoint tensor '{name}' has no parameter in {type(mod.quant_method).__name__}")
+                    param.data.copy_(value.to(dev).view(param.shape) if value.numel() == param.numel() else value.to(dev))
+                mod.quant_method.process_weights_after_loading(mod)
+                if hasattr(layer, "_fused_w"):
+                    del layer._fused_w
 
     def _fused_decode_ok(self, forward_batch) -> bool:
         return (self.fused_decode and forward_batch.forward_mode.is_decode()
@@ -383,7 +410,7 @@ class SyntheticModelRunner:
 
     def __init__(self, cfg: LlamaShape, quantization: Optional[str], max_running_requests: int, context_len: int,
                  max_total_tokens: int, device: str = "cuda:0", dtype=torch.bfloat16, seed: int = 0,
-                 kv_cache_dtype: Optional[torch.dtype] = None):
+                 kv_cache_dtype: Optional[torch.dtype] = None, init_weights: bool = True):
         self.device = device
         self.gpu_id = torch.device(device).index or 0
         self.dtype = dtype
@@ -407,7 +434,8 @@ class SyntheticModelRunner:
         self.token_to_kv_pool_allocator = TokenToKVPoolAllocator(max_total_tokens, kv_cache_dtype or dtype, device, self.token_to_kv_pool)
         with torch.device(device):
             self.model = LlamaForCausalLM(cfg, quantization, dtype)
-        self.model.init_random_weights(seed)
+        if init_weights:
+            self.model.init_random_weights(seed)   # else: the caller loads a checkpoint (model.load_checkpoint)
         self.attn_backend = HipAttnBackend(self)
         self._graphs = {}
 

@@ -250,6 +250,122 @@ def build_rope_case(case, seed=0):
 
 
 # ----------------------------------------------------------------------------------------------
+# G7: end-to-end model cases (2-layer Llama / Qwen2-shaped stacks).  build_model_case() returns the synthetic
+# "checkpoint" (half-precision or already-quantised tensors, exactly what a loader would hand to create_weights'
+# parameters), the prompts and a slot assignment; make_golden.py runs the reference's blocks over it.
+# ----------------------------------------------------------------------------------------------
+MODEL_CASES = [
+    dict(name="g7_w8a8_d128", quant="w8a8_fp8", hidden=1024, hq=8, hkv=2, d=128, inter=1024, layers=2, vocab=1024),
+    dict(name="g7_w8a8_d64", quant="w8a8_fp8", hidden=512, hq=8, hkv=2, d=64, inter=1024, layers=2, vocab=1024),
+    dict(name="g7_bf16_d128", quant=None, hidden=1024, hq=8, hkv=2, d=128, inter=1024, layers=2, vocab=1024),
+    # Qwen2-shaped: qkv bias, AWQ group 128, 7 q heads per kv head
+    dict(name="g7_awq_d128", quant="awq", hidden=896, hq=7, hkv=1, d=128, inter=1024, layers=2, vocab=1024, bias=True, group=128,
+         eps=1e-6, theta=1e6),
+    # Fp8LinearMethod: serialized per-tensor checkpoint, one weight scale per logical shard, static activation scales
+    dict(name="g7_fp8_static_d128", quant="fp8", hidden=1024, hq=8, hkv=2, d=128, inter=1024, layers=2, vocab=1024),
+]
+MODEL_LENS = [37, 5, 64]
+MODEL_DECODE_STEPS = 3
+MODEL_MAX_POS = 512
+
+
+def _fp8_per_channel(w):
+    wf = w.float()
+    s = wf.abs().amax(dim=1, keepdim=True).clamp(min=1e-10) / 448.0
+    return (wf / s).clamp(-448, 448).to(torch.float8_e4m3fn), s
+
+
+def build_model_case(case, seed=0):
+    rng = np.random.RandomState(seed + 700)
+    H, hq, hkv, d, I, V = case["hidden"], case["hq"], case["hkv"], case["d"], case["inter"], case["vocab"]
+    quant = case["quant"]
+    dt = torch.bfloat16
+
+    def randn(shape, std):
+        return torch.from_numpy((rng.standard_normal(shape) * std).astype(np.float32)).to(dt)
+
+    def norm_w():
+        return torch.from_numpy((1 + 0.1 * rng.standard_normal(H)).astype(np.float32)).to(dt)
+
+    def linear(n, k, shards):
+        """One linear's checkpoint tensors for this quant kind; shards = logical output widths (qkv: 3, gate_up: 2)."""
+        if quant == "awq":
+            g = case["group"]
+            return dict(
+                qweight=torch.from_numpy(rng.randint(0, 2**31 - 1, size=(k, n // 8), dtype=np.int64).astype(np.int32)),
+                qzeros=torch.from_numpy(rng.randint(0, 2**31 - 1, size=(k // g, n // 8), dtype=np.int64).astype(np.int32)),
+                scales=torch.from_numpy((rng.random_sample((k // g, n)) * 0.003).astype(np.float32)).to(dt))
+        w = randn((n, k), 0.02 * (1024.0 / k) ** 0.5 * 2)
+        if quant is None:
+            return dict(weight=w)
+        if quant == "w8a8_fp8":
+            q, s = _fp8_per_channel(w)
+            return dict(weight=q, weight_scale=s)
+        # "fp8": per-tensor scale per logical shard + static input scales (fp8.py:310-333)
+        qs, ss, start = [], [], 0
+        for width in shards:
+            blk = w[start:start + width].float()
+            sc = blk.abs().amax() / 448.0
+            qs.append((blk / sc).clamp(-448, 448).to(torch.float8_e4m3fn))
+            ss.append(sc)
+            start += width
+        in_scale = torch.tensor([0.02 + 0.005 * i for i in range(len(shards))], dtype=torch.float32)
+        return dict(weight=torch.cat(qs), weight_scale=torch.stack(ss).float(), input_scale=in_scale)
+
+    ckpt = dict(embed=randn((V, H), 1.0), lm_head=randn((V, H), 0.02), norm=norm_w(), layers=[])
+    for _ in range(case["layers"]):
+        L = dict(ln1=norm_w(), ln2=norm_w(),
+                 qkv=linear((hq + 2 * hkv) * d, H, [hq * d, hkv * d, hkv * d]),
+                 o=linear(H, hq * d, [H]), gate_up=linear(2 * I, H, [I, I]), down=linear(H, I, [H]))
+        if case.get("bias"):
+            L["qkv"]["bias"] = randn(((hq + 2 * hkv) * d,), 0.1)
+        ckpt["layers"].append(L)
+    ids = [torch.from_numpy(rng.randint(0, V, size=n).astype(np.int64)) for n in MODEL_LENS]
+    # slots: a random permutation, never slot 0; request rows non-trivial
+    total = sum(MODEL_LENS) + MODEL_DECODE_STEPS * len(MODEL_LENS)
+    pool_size = total + 29
+    perm = (1 + rng.permutation(pool_size)[:total]).astype(np.int64)
+    return dict(ckpt=ckpt, input_ids=ids, slots=torch.from_numpy(perm), pool_size=pool_size,
+                req_pool_indices=torch.tensor([2, 0, 3], dtype=torch.int64), max_reqs=5, max_ctx=max(MODEL_LENS) + 8,
+                eps=case.get("eps", 1e-5), theta=case.get("theta", 500000.0))
+
+
+def model_cfg(case, m):
+    from types import SimpleNamespace
+
+    return SimpleNamespace(hidden_size=case["hidden"], num_attention_heads=case["hq"], num_key_value_heads=case["hkv"],
+                           head_dim=case["d"], num_hidden_layers=case["layers"], intermediate_size=case["inter"],
+                           vocab_size=case["vocab"], rms_norm_eps=m["eps"], rope_theta=m["theta"],
+                           max_position_embeddings=MODEL_MAX_POS, attention_bias=bool(case.get("bias")))
+
+
+def run_model_script(model, m, tokens):
+    """One extend over MODEL_LENS then len(tokens) teacher-forced decode steps on an oracle-style model
+    (``forward(ids, positions, req_to_token, req_pool_indices, seq_lens, out_cache_loc, pre, ext)``) with the case's slot
+    assignment; returns the stacked logits [1 + steps, bs, V]."""
+    lens = list(MODEL_LENS)
+    bs = len(lens)
+    r2t = torch.zeros(m["max_reqs"], m["max_ctx"], dtype=torch.int32)
+    rpi, slots = m["req_pool_indices"], m["slots"]
+    cur = 0
+    for i, n in enumerate(lens):
+        r2t[rpi[i], :n] = slots[cur:cur + n].int()
+        cur += n
+    seq = torch.tensor(lens, dtype=torch.int64)
+    pos = torch.cat([torch.arange(n) for n in lens])
+    out = [model.forward(torch.cat(m["input_ids"]), pos, r2t, rpi, seq, slots[: sum(lens)].clone(),
+                         torch.zeros(bs, dtype=torch.int32), torch.tensor(lens, dtype=torch.int32))]
+    for step in range(tokens.shape[0]):
+        loc = slots[cur:cur + bs].clone()
+        cur += bs
+        for i in range(bs):
+            r2t[rpi[i], seq[i]] = int(loc[i])
+        seq = seq + 1
+        out.append(model.forward(tokens[step], seq - 1, r2t, rpi, seq, loc))
+    return torch.stack(out)
+
+
+# ----------------------------------------------------------------------------------------------
 # radix-cache / allocator scripts: the SAME seeded script is run against the reference classes (golden generator),
 # the oracle and the product classes; every observable (indices, lengths, freed slots, counters) is recorded.
 # ----------------------------------------------------------------------------------------------

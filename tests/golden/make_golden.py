@@ -1,6 +1,6 @@
 """Generates tests/golden/*.npz by running the *reference itself* in the build container.
 
-Run:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [attention|index|quant|radix|all]
+Run:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [attention|index|quant|elementwise|radix|model|all]
 
 The reference tree (/root/reference) is imported in-process with the recipe of
 tests/golden/_ref_import.py; it is never copied, and it does not exist on the GPU box:
@@ -18,6 +18,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))  # repo root: oracle/ (the exact-arithmetic twin of G7)
 
 import _ref_import  # noqa: E402
 
@@ -286,12 +287,180 @@ def gen_radix():
     print("radix.json", {k: len(v) for k, v in out.items()})
 
 
+def _ref_method(relpath, cls_name, fn_name, ns):
+    """A single method of a reference class, executed from its source text (for modules whose import needs absent
+    third-party packages); nothing is copied into the repo."""
+    import ast
+
+    path = os.path.join(_ref_import.REF_ROOT, relpath)
+    tree = ast.parse(open(path).read())
+    for node in tree.body:
+        if isinstance(node, ast.ClassDef) and node.name == cls_name:
+            for item in node.body:
+                if isinstance(item, ast.FunctionDef) and item.name == fn_name:
+                    exec(compile(ast.Module(body=[item], type_ignores=[]), path, "exec"), ns)
+                    return ns[fn_name]
+    raise KeyError(f"{cls_name}.{fn_name} not found in {relpath}")
+
+
+def gen_model():
+    """G7: a 2-layer Llama / Qwen2-shaped stack composed from the REFERENCE's own blocks --
+    RMSNorm.forward_native (layernorm.py), RotaryEmbedding.forward_native (rotary_embedding.py), SiluAndMul.forward_native
+    (activation.py), TorchNativeAttnBackend + RadixAttention + MHATokenToKVPool + ForwardBatch (the attention path exactly
+    as gen_attention runs it), and the linear methods in the form of the reference's own torch restatements
+    (sgl-kernel/tests: torch_per_token_quant_fp8, torch_scaled_fp8_quant, torch_scaled_mm, awq_dequantize_torch) wired as
+    W8A8Fp8LinearMethod.apply / Fp8LinearMethod (+ requantize_with_max_scale) / AWQLinearMethod.apply do.  Layer order:
+    models/llama.py:94-98,180-191,245-268,308-340.  Stores bf16 logits of one extend + MODEL_DECODE_STEPS greedy decode
+    steps, the tokens chosen, and the float64 'exact' logits of the same function (oracle/model.py, exact=True)."""
+    import typing
+    from types import SimpleNamespace
+
+    import torch.nn.functional as F
+    from sglang.srt.layers.attention.torch_native_backend import TorchNativeAttnBackend
+    from sglang.srt.layers.radix_attention import RadixAttention
+    from sglang.srt.layers.rotary_embedding import RotaryEmbedding
+    from sglang.srt.mem_cache.memory_pool import MHATokenToKVPool
+    from sglang.srt.model_executor.forward_batch_info import ForwardBatch, ForwardMode
+
+    from oracle.model import OracleLlama, process_checkpoint
+
+    t_tok = _load_ref_test_module("sgl-kernel/tests/test_per_token_quant_fp8.py", "ref_t_tok")
+    t_ten = _load_ref_test_module("sgl-kernel/tests/test_per_tensor_quant_fp8.py", "ref_t_ten")
+    t_mm = _load_ref_test_module("sgl-kernel/tests/test_fp8_gemm.py", "ref_t_mm")
+    t_awq = _load_ref_test_module("sgl-kernel/tests/test_awq_dequant.py", "ref_t_awq")
+    tns = {"torch": torch, "F": F, "Optional": typing.Optional, "Union": typing.Union, "Tuple": typing.Tuple}
+    rms_native = _ref_method("python/sglang/srt/layers/layernorm.py", "RMSNorm", "forward_native", dict(tns))
+    silu_native = _ref_method("python/sglang/srt/layers/activation.py", "SiluAndMul", "forward_native", dict(tns))
+
+    out = {}
+    for case in _cases.MODEL_CASES:
+        m = _cases.build_model_case(case)
+        ck, quant = m["ckpt"], case["quant"]
+        H, hq, hkv, d, I = case["hidden"], case["hq"], case["hkv"], case["d"], case["inter"]
+        L = case["layers"]
+        dt = torch.bfloat16
+
+        def rms(x, w, residual=None):
+            self = SimpleNamespace(weight=w, variance_epsilon=m["eps"], hidden_size=H, variance_size_override=None)
+            return rms_native(self, x) if residual is None else rms_native(self, x, residual)
+
+        rope_self = SimpleNamespace(head_size=d, rotary_dim=d, max_position_embeddings=_cases.MODEL_MAX_POS, base=m["theta"],
+                                    is_neox_style=True)
+        rope_self._compute_inv_freq = lambda base, s=rope_self: RotaryEmbedding._compute_inv_freq(s, base)
+        rope_self.cos_sin_cache = RotaryEmbedding._compute_cos_sin_cache(rope_self)
+
+        def linear(x, t, widths):
+            bias = t.get("bias")
+            if quant is None:                    # UnquantizedLinearMethod.apply
+                return F.linear(x, t["weight"], bias)
+            if quant == "w8a8_fp8":              # W8A8Fp8LinearMethod.apply -> apply_fp8_linear (per-token, per-channel)
+                scale = x.float().abs().amax(dim=1, keepdim=True) / 448.0      # per_token_quant_fp8.cu:49-57
+                safe = torch.where(scale == 0, torch.ones_like(scale), scale)
+                xq = t_tok.torch_per_token_quant_fp8(x, safe)
+                return t_mm.torch_scaled_mm(xq, t["weight"].t(), scale.flatten(), t["weight_scale"].flatten(), dt, bias)
+            if quant == "fp8":                   # Fp8LinearMethod: requantize_with_max_scale + static per-tensor activation
+                w, ws = t["weight"], t["weight_scale"]
+                smax = ws.max()
+                if ws.numel() > 1:
+                    parts, start = [], 0
+                    for i, width in enumerate(widths):
+                        dq = w[start:start + width].to(torch.float32) * ws[i]          # per_tensor_dequantize
+                        parts.append(t_ten.torch_scaled_fp8_quant(dq, smax.reshape(1)))  # scaled_fp8_quant(w_dq, max_scale)
+                        start += width
+                    w = torch.cat(parts)
+                sx = t["input_scale"].max().reshape(1)
+                xq = t_ten.torch_scaled_fp8_quant(x, sx)
+                return t_mm.torch_scaled_mm(xq, w.t(), sx.expand(x.shape[0]), smax.expand(w.shape[0]), dt, bias)
+            if quant == "awq":                   # AWQLinearMethod.apply (awq.py:401-418)
+                wd = t_awq.awq_dequantize_torch(t["qweight"], t["scales"], t["qzeros"], case["group"])
+                o = torch.matmul(x, wd.to(x.dtype))
+                if bias is not None:
+                    o.add_(bias)
+                return o
+            raise ValueError(quant)
+
+        backend = TorchNativeAttnBackend(SimpleNamespace(device="cpu"))
+        pool = MHATokenToKVPool(size=m["pool_size"], page_size=1, dtype=dt, head_num=hkv, head_dim=d, layer_num=L,
+                                device="cpu", enable_memory_saver=False)
+        attn_layers = [RadixAttention(num_heads=hq, head_dim=d, scaling=d ** -0.5, num_kv_heads=hkv, layer_id=i) for i in range(L)]
+        r2t = torch.zeros(m["max_reqs"], m["max_ctx"], dtype=torch.int32)
+        rpi = m["req_pool_indices"]
+
+        def forward(ids, positions, fb, last_index):
+            h = ck["embed"][ids]
+            residual = None
+            for li in range(L):
+                W = ck["layers"][li]
+                if residual is None:
+                    residual, h = h, rms(h, W["ln1"])
+                else:
+                    h, residual = rms(h, W["ln1"], residual)
+                qkv = linear(h, W["qkv"], [hq * d, hkv * d, hkv * d])
+                q, k, v = qkv.split([hq * d, hkv * d, hkv * d], dim=-1)
+                q, k = RotaryEmbedding.forward_native(rope_self, positions, q, k)
+                a = attn_layers[li](q, k, v, fb)
+                a = linear(a, W["o"], [H])
+                h, residual = rms(a, W["ln2"], residual)
+                gu = linear(h, W["gate_up"], [I, I])
+                h = linear(silu_native(None, gu), W["down"], [H])
+            h, _ = rms(h, ck["norm"], residual)
+            if last_index is not None:
+                h = h[last_index]
+            return F.linear(h, ck["lm_head"])
+
+        lens = list(_cases.MODEL_LENS)
+        bs = len(lens)
+        slots = m["slots"]
+        cur = 0
+        for i, n in enumerate(lens):
+            r2t[rpi[i], :n] = slots[cur:cur + n].int()
+            cur += n
+        ids = torch.cat(m["input_ids"])
+        seq = torch.tensor(lens, dtype=torch.int64)
+        loc = slots[: sum(lens)].clone()
+        fb = ForwardBatch(forward_mode=ForwardMode.EXTEND, batch_size=bs, input_ids=ids, req_pool_indices=rpi, seq_lens=seq,
+                          out_cache_loc=loc, seq_lens_sum=int(seq.sum()), extend_prefix_lens=torch.zeros(bs, dtype=torch.int32),
+                          extend_seq_lens=torch.tensor(lens, dtype=torch.int32), attn_backend=backend)
+        fb.req_to_token_pool = SimpleNamespace(req_to_token=r2t, size=r2t.shape[0])
+        fb.token_to_kv_pool = pool
+        backend.init_forward_metadata(fb)
+        pos = torch.cat([torch.arange(n) for n in lens])
+        logits = [forward(ids, pos, fb, torch.cumsum(seq, 0) - 1)]
+        tokens = []
+        for step in range(_cases.MODEL_DECODE_STEPS):
+            nxt = torch.argmax(logits[-1].float(), dim=-1)
+            tokens.append(nxt)
+            loc = slots[cur:cur + bs].clone()
+            cur += bs
+            for i in range(bs):
+                r2t[rpi[i], seq[i]] = int(loc[i])
+            seq = seq + 1
+            fb = ForwardBatch(forward_mode=ForwardMode.DECODE, batch_size=bs, input_ids=nxt, req_pool_indices=rpi, seq_lens=seq,
+                              out_cache_loc=loc, seq_lens_sum=int(seq.sum()), attn_backend=backend)
+            fb.req_to_token_pool = SimpleNamespace(req_to_token=r2t, size=r2t.shape[0])
+            fb.token_to_kv_pool = pool
+            backend.init_forward_metadata(fb)
+            logits.append(forward(nxt, seq - 1, fb, None))
+        ref = torch.stack(logits)                                     # [1 + steps, bs, V] bf16
+        out[case["name"] + ".logits"] = _cases.bits16(ref)
+        out[case["name"] + ".tokens"] = torch.stack(tokens).numpy()
+        # the same function in exact arithmetic, teacher-forced with the reference's tokens
+        cfg = _cases.model_cfg(case, m)
+        ex = OracleLlama(cfg, process_checkpoint(ck, quant, [hq * d, hkv * d, hkv * d]), torch.float64, pool_slots=m["pool_size"] + 1, exact=True)
+        exact = _cases.run_model_script(ex, m, torch.stack(tokens))
+        out[case["name"] + ".exact"] = exact.to(torch.float32).numpy()
+        err = (ref.double() - exact).abs()
+        print(case["name"], "max|logit|", float(exact.abs().max()), "ref-vs-exact max", float(err.max()), "mean", float(err.mean()))
+    np.savez_compressed(os.path.join(HERE, "model.npz"), **out)
+    print("model.npz", len(out), "arrays")
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     torch.manual_seed(0)
     if what in ("attention", "all"):
         gen_attention()
-    for extra in ("index", "quant", "elementwise", "radix"):
+    for extra in ("index", "quant", "elementwise", "radix", "model"):
         fn = globals().get("gen_" + extra)
         if fn is not None and what in (extra, "all"):
             fn()
