@@ -116,15 +116,24 @@ def extend_attention_fwd(
 def decode_attention(query, k_cache, v_cache, output, key, value, loc, attn_logits, req_to_token, req_pool_indices,
                      seq_lens, sm_scale, logit_cap) -> None:
     """Native-op form (decode_attention_cpu schema, torch_extension_cpu.cpp:264-268): writes (key, value) into the pool
-    at ``loc`` first (the fused decode_set_kv_buffer of decode.cpp:771), then attends through req_to_token directly.
-    attn_logits f32 [bs, Hq, num_kv_splits, Dv + 1] as in the reference (intel_amx_backend.py:36-45); the last column
-    of each split row holds the LSE."""
+    at ``loc`` first (the fused decode_set_kv_buffer of decode.cpp:771), then attends through req_to_token directly
+    (int32 or int64 table, decode.cpp:1441-1451).  ``attn_logits`` f32 [bs, Hq, num_kv_splits, Dv + 1] is the CALLER's
+    split scratch as in the reference (intel_amx_backend.py:36-45, decode.cpp:1375-1575): on return each split row holds
+    acc / l in its first Dv columns and the split's log-sum-exp in the last one.  An e4m3 pool (no scale arguments in this
+    schema) is written with the plain cast and read with unit scales."""
     from .kvcache import set_kv_buffer
 
     _require_cuda(query, k_cache, v_cache, output, key, value, loc, attn_logits, req_to_token, req_pool_indices, seq_lens)
     bs, hq, d = query.shape
     hkv, dv = v_cache.shape[1], v_cache.shape[2]
-    assert req_to_token.dtype == torch.int32 and req_pool_indices.dtype == torch.int64 and seq_lens.dtype == torch.int64
+    if req_pool_indices.dtype != torch.int64 or seq_lens.dtype != torch.int64:
+        raise RuntimeError("decode_attention: expect req_pool_indices and seq_lens to be int64")   # decode.cpp:1445-1451
+    if req_to_token.dtype not in (torch.int32, torch.int64):
+        raise RuntimeError("decode_attention: expect req_to_token to be either int32 or int64")    # decode.cpp:1441-1444
+    if attn_logits.dtype != torch.float32 or attn_logits.dim() != 4 or tuple(attn_logits.shape[:2]) != (bs, hq) \
+            or attn_logits.shape[3] != dv + 1:
+        raise RuntimeError(f"decode_attention: attn_logits must be float32 [bs, Hq, num_kv_splits, Dv + 1], got {tuple(attn_logits.shape)}")
+    r2t = req_to_token if req_to_token.dtype == torch.int32 else req_to_token.to(torch.int32)   # slot ids fit int32 (memory_pool.py:66-68)
     set_kv_buffer(k_cache, v_cache, loc.to(torch.int64), key, value)
     splits = attn_logits.shape[2]
     logits = torch.empty((bs, hq, splits, dv), dtype=torch.float32, device=query.device)
@@ -135,11 +144,18 @@ def decode_attention(query, k_cache, v_cache, output, key, value, loc, attn_logi
     check(
         lib.sgl_mi355_decode_attention(
             ptr(query), query.stride(0), ptr(k_cache), ptr(v_cache), kst, ksh, vst, vsh, ptr(output), output.stride(0),
-            None, None, ptr(req_to_token), req_to_token.stride(0), ptr(req_pool_indices), ptr(seq_lens), ptr(logits),
+            None, None, ptr(r2t), r2t.stride(0), ptr(req_pool_indices), ptr(seq_lens), ptr(logits),
             ptr(lse), ptr(nsplit), splits, bs, hq, hkv, d, dv, float(sm_scale), float(logit_cap), dtype_code(query.dtype),
             dtype_code(k_cache.dtype), 1.0, 1.0, current_stream(),
         )
     )
+    # the kernel's scratch is [.., Dv] + a separate LSE plane (16-byte vector stores); hand it back in the caller's layout.
+    # Splits that received no token keep whatever the caller had there (the reference leaves them unwritten too).
+    tiles = (seq_lens.view(bs, 1).to(torch.int32) + splits - 1) // splits
+    per = (tiles + 31) // 32 * 32                                   # split_len of the kernel (decode_attention.py:90-94)
+    live = (torch.arange(splits, device=query.device, dtype=torch.int32).view(1, splits) * per < seq_lens.view(bs, 1)).view(bs, 1, splits, 1)
+    attn_logits[..., :dv] = torch.where(live, logits, attn_logits[..., :dv])
+    attn_logits[..., dv:] = torch.where(live, lse.unsqueeze(-1), attn_logits[..., dv:])
 
 
 def extend_attention(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, req_to_token, req_pool_indices, seq_lens,

@@ -69,7 +69,9 @@ class Fp8LinearMethod(LinearMethodBase):
             layer.weight_scale = Parameter(weight_scale, requires_grad=False)
             layer.input_scale = None
             return
-        # fused modules (qkv, gate_up) carry one scale per shard: requantise to the max scale (fp8.py:360-400)
+        # fused modules (qkv, gate_up) carry one scale per shard: dequantise each shard with its own scale and quantise it
+        # again with the max scale (requantize_with_max_scale, quantization/utils.py:95-120: per_tensor_dequantize +
+        # scaled_fp8_quant(weight_dq, max_w_scale) -- the same static per-tensor quant kernel as for activations)
         ws = layer.weight_scale.data
         w = layer.weight.data
         max_scale = ws.max()
@@ -77,8 +79,8 @@ class Fp8LinearMethod(LinearMethodBase):
             start = 0
             wq = torch.empty_like(w)
             for i, width in enumerate(layer.logical_widths):
-                shard = w[start : start + width].to(torch.float32) * ws[i]
-                wq[start : start + width] = (shard / max_scale).clamp(-fp8_max, fp8_max).to(fp8_dtype)
+                shard = (w[start : start + width].to(torch.float16) * ws[i]).contiguous()   # per_tensor_dequantize: f16 (utils.py:59-64)
+                wq[start : start + width], _ = scaled_fp8_quant(shard, max_scale.reshape(1))
                 start += width
             w = wq
         layer.weight = Parameter(w.t(), requires_grad=False)

@@ -42,7 +42,7 @@ def process_checkpoint(ckpt, quant, qkv_widths=None):
             if ws.numel() > 1:   # requantize_with_max_scale: dequantise each shard with its scale, quantise with the max
                 parts, start = [], 0
                 for i, width in enumerate(widths):
-                    dq = w[start:start + width].to(torch.float32) * ws[i]
+                    dq = w[start:start + width].to(torch.float16) * ws[i]   # per_tensor_dequantize goes through f16 (utils.py:59-64)
                     parts.append(oq.per_tensor_quant_fp8(dq, smax.reshape(1))[0])
                     start += width
                 w = torch.cat(parts)

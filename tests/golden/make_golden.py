@@ -364,7 +364,7 @@ def gen_model():
                 if ws.numel() > 1:
                     parts, start = [], 0
                     for i, width in enumerate(widths):
-                        dq = w[start:start + width].to(torch.float32) * ws[i]          # per_tensor_dequantize
+                        dq = w[start:start + width].to(torch.float16) * ws[i]          # per_tensor_dequantize (utils.py:59-64)
                         parts.append(t_ten.torch_scaled_fp8_quant(dq, smax.reshape(1)))  # scaled_fp8_quant(w_dq, max_scale)
                         start += width
                     w = torch.cat(parts)

@@ -200,3 +200,72 @@ def test_in_launch_merge_quant_bit_identical_to_two_kernels(dtype, d, kv8, pkg):
         assert torch.equal(o, o_ref), it
         assert torch.equal(oq.view(torch.uint8), q_ref.view(torch.uint8)) and torch.equal(osc, s_ref), it
         assert int(counters.abs().sum()) == 0
+
+
+# ---------------------------------------------------------------- a16: the native-op schema (decode_attention_cpu)
+@pytest.mark.parametrize("case", DECODE_CASES, ids=lambda c: c["name"])
+@pytest.mark.parametrize("r2t_dtype", [torch.int32, torch.int64])
+@pytest.mark.parametrize("logit_cap", [0.0, 30.0])
+def test_native_op_decode_attention_fused_kv_write(case, r2t_dtype, logit_cap, pkg, golden):
+    """sgl_kernel.decode_attention = the decode_attention_cpu schema (torch_extension_cpu.cpp:264-268, decode.cpp:1375-1575):
+    fused KV write at ``loc``, req_to_token addressing (the kernel's kv_indptr == NULL branch) with non-contiguous request
+    rows, int32 / int64 table, logit cap, and the caller's attn_logits [bs, Hq, S, Dv + 1] scratch (acc / l + LSE column)
+    -- against the golden of the reference's torch-native backend (cap 0) and the float64 oracle; the split partials are
+    checked by re-merging them on the host."""
+    from ltp_sglang_amd import sgl_kernel
+
+    dev = torch.device("cuda:0")
+    c = _cases.build_attn_case(case)
+    bs, hq, d = c["bs"], c["hq"], c["d"]
+    dt = c["dtype"]
+    new = c["out_cache_loc"]
+    k_cache, v_cache = c["k_buffer"].clone(), c["v_buffer"].clone()
+    key, value = k_cache[new].clone(), v_cache[new].clone()
+    k_cache[new] = 0   # the op must write the new token's K/V itself before attending
+    v_cache[new] = 0
+    k_cache, v_cache = k_cache.to(dev), v_cache.to(dev)
+    splits = 4
+    attn_logits = torch.full((bs, hq, splits, c["v_buffer"].shape[-1] + 1), float("nan"), dtype=torch.float32, device=dev)
+    out = torch.full((bs, hq, c["v_buffer"].shape[-1]), float("nan"), dtype=dt, device=dev)
+    sgl_kernel.decode_attention(c["q"].to(dev), k_cache, v_cache, out, key.to(dev), value.to(dev), new.to(dev), attn_logits,
+                                c["req_to_token"].to(r2t_dtype).to(dev), c["req_pool_indices"].to(dev), c["seq_lens"].to(dev),
+                                c["scaling"], logit_cap)
+    torch.cuda.synchronize()
+    assert torch.equal(k_cache.cpu(), c["k_buffer"]) and torch.equal(v_cache.cpu(), c["v_buffer"])   # fused KV write, bit-exact
+    ref = oa.decode_attention_f64(c["q"], c["k_buffer"], c["v_buffer"], c["req_to_token"], c["req_pool_indices"], c["seq_lens"],
+                                  c["scaling"], logit_cap)
+    err = (out.cpu().double() - ref).abs().max().item()
+    assert err <= TOL_F64[dt], err
+    if logit_cap == 0.0:
+        gold = _cases.from_bits16(golden("attention")[case["name"]], dt).reshape(out.shape)
+        assert (out.cpu().double() - gold.double()).abs().max().item() <= TOL_GOLD[dt]
+    # the caller's scratch: merging the live split rows by their LSE column reproduces the output
+    al = attn_logits.cpu().double()
+    dv = al.shape[-1] - 1
+    for b in range(bs):
+        n = int(c["seq_lens"][b])
+        per = ((n + splits - 1) // splits + 31) // 32 * 32
+        live = [s for s in range(splits) if s * per < n]
+        assert torch.isnan(al[b, :, [s for s in range(splits) if s not in live]]).all()   # untouched rows stay the caller's
+        lse = al[b, :, live, dv]                                       # [Hq, nlive]
+        w = torch.softmax(lse, dim=-1).unsqueeze(-1)
+        merged = (al[b, :, live, :dv] * w).sum(dim=1)
+        assert (merged - ref[b]).abs().max().item() <= 1e-3 + (0 if dt == torch.float16 else 5e-3)
+
+
+def test_native_op_decode_attention_argument_checks(pkg):
+    from ltp_sglang_amd import sgl_kernel
+
+    dev = torch.device("cuda:0")
+    c = _cases.build_attn_case(DECODE_CASES[0])
+    args = dict(query=c["q"].to(dev), k_cache=c["k_buffer"].to(dev), v_cache=c["v_buffer"].to(dev),
+                output=torch.empty_like(c["q"], device=dev), key=c["k_buffer"][c["out_cache_loc"]].to(dev),
+                value=c["v_buffer"][c["out_cache_loc"]].to(dev), loc=c["out_cache_loc"].to(dev),
+                attn_logits=torch.empty(c["bs"], c["hq"], 2, c["d"] + 1, device=dev), req_to_token=c["req_to_token"].to(dev),
+                req_pool_indices=c["req_pool_indices"].to(dev), seq_lens=c["seq_lens"].to(dev), sm_scale=c["scaling"], logit_cap=0.0)
+    with pytest.raises(RuntimeError, match="int64"):
+        sgl_kernel.decode_attention(**{**args, "seq_lens": args["seq_lens"].int()})
+    with pytest.raises(RuntimeError, match="int32 or int64"):
+        sgl_kernel.decode_attention(**{**args, "req_to_token": args["req_to_token"].to(torch.int16)})
+    with pytest.raises(RuntimeError, match="Dv \\+ 1"):
+        sgl_kernel.decode_attention(**{**args, "attn_logits": torch.empty(c["bs"], c["hq"], 2, c["d"], device=dev)})

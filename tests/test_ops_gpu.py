@@ -641,3 +641,60 @@ def test_splitk_workspace_survives_growth_under_a_captured_graph(sk, pkg, monkey
     torch.cuda.synchronize()
     assert torch.equal(out_g, eager)
     assert all(torch.isnan(j).all() for j in junk)   # the replay wrote nothing into memory owned by other tensors
+
+
+# ---------------------------------------------------------------- a17: Fp8LinearMethod (per-tensor fp8, fp8.py:336-501)
+@pytest.mark.parametrize("scheme", ["dynamic_unserialized", "dynamic_serialized", "static_serialized"])
+@pytest.mark.parametrize("m", [5, 48, 200])
+def test_fp8_linear_method_per_tensor(scheme, m, sk, pkg):
+    """Fp8LinearMethod end to end (create_weights -> process_weights_after_loading -> apply) against the oracle's
+    restatement of the same steps (oracle/model.py::process_checkpoint + oracle/quant.py): per-tensor weight quantisation
+    of a half-precision checkpoint, the per-shard -> max-scale requantisation of a serialized fused module
+    (quantization/utils.py:95-120), dynamic and static per-tensor activation scales."""
+    from ltp_sglang_amd.srt.layers.linear import MergedColumnParallelLinear
+    from ltp_sglang_amd.srt.layers.quantization.fp8 import Fp8Config
+    from oracle.model import process_checkpoint
+
+    torch.manual_seed(1)
+    k, widths = 512, [256, 128]
+    n = sum(widths)
+    serialized = scheme != "dynamic_unserialized"
+    static = scheme == "static_serialized"
+    cfg = Fp8Config(serialized, "static" if static else "dynamic")
+    with torch.device(DEV):
+        layer = MergedColumnParallelLinear(k, widths, bias=True, quant_config=cfg, params_dtype=torch.bfloat16, tp_rank=0, tp_size=1)
+    w = (torch.randn(n, k) * 0.05).to(torch.bfloat16)
+    bias = torch.randn(n).to(torch.bfloat16)
+    x = torch.randn(m, k).to(torch.bfloat16)
+    layer.bias.data.copy_(bias)
+    if serialized:
+        qs, ss, start = [], [], 0
+        for width in widths:
+            blk = w[start:start + width].float()
+            sc = blk.abs().amax() / 448.0 * (1.0 if start == 0 else 1.7)   # distinct shard scales -> requantisation really happens
+            qs.append((blk / sc).clamp(-448, 448).to(torch.float8_e4m3fn))
+            ss.append(sc)
+            start += width
+        t = dict(weight=torch.cat(qs), weight_scale=torch.stack(ss).float())
+        if static:
+            t["input_scale"] = torch.tensor([0.011, 0.013])
+        layer.weight.data.copy_(t["weight"].to(DEV))
+        layer.weight_scale.data.copy_(t["weight_scale"].to(DEV))
+        if static:
+            layer.input_scale.data.copy_(t["input_scale"].to(DEV))
+        _, wq, ws, in_s, _ = process_checkpoint(dict(embed=None, lm_head=None, norm=None, layers=[dict(
+            ln1=None, ln2=None, qkv=t, o=dict(weight=t["weight"][:1], weight_scale=t["weight_scale"][:1]),
+            gate_up=t, down=dict(weight=t["weight"][:1], weight_scale=t["weight_scale"][:1]))]), "fp8", widths)["layers"][0]["qkv"]
+    else:
+        layer.weight.data.copy_(w.to(DEV))
+        wq, ws = oq.per_tensor_quant_fp8(w)
+        in_s = None
+    layer.quant_method.process_weights_after_loading(layer)
+    assert layer.weight_scale.numel() == 1 and torch.equal(layer.weight_scale.cpu().reshape(1), ws.reshape(1))
+    assert torch.equal(layer.weight.t().contiguous().cpu().view(torch.uint8), wq.view(torch.uint8))   # weight bytes bit-exact
+    y, _ = layer(x.to(DEV))
+    xq, sx = oq.per_tensor_quant_fp8(x, in_s)
+    ref = oq.scaled_mm(xq, wq.t(), sx.expand(m), ws.expand(n), torch.bfloat16, bias)
+    err = (y.cpu().float() - ref.float()).abs()
+    tol = 1.6e-2 * ref.float().abs() + 2e-2
+    assert (err <= tol).all(), float(err.max())
