@@ -229,7 +229,7 @@ def sgl_per_tensor_quant_fp8(input: torch.Tensor, output_q: torch.Tensor, output
                                              dtype_code(input.dtype), current_stream()))
 
 
-def sgl_per_token_group_quant_fp8(input, output_q, output_s, group_size, eps, fp8_min, fp8_max, scale_ue8m0=False) -> None:
+def sgl_per_token_group_quant_fp8(input, output_q, output_s, group_size, eps, fp8_min, fp8_max, scale_ue8m0) -> None:
     """gemm.py:100-112 (row-major float scales only)."""
     _cuda(input, output_q, output_s)
     if scale_ue8m0:

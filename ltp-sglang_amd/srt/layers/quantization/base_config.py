@@ -33,9 +33,8 @@ class QuantizationConfig(ABC):
     def __init__(self):
         self.packed_modules_mapping: Dict[str, List[str]] = dict()
 
-    @classmethod
     @abstractmethod
-    def get_name(cls) -> str:
+    def get_name(self) -> str:
         raise NotImplementedError()
 
     @abstractmethod
@@ -51,9 +50,32 @@ class QuantizationConfig(ABC):
     def get_quant_method(self, layer: torch.nn.Module, prefix: str) -> Optional[QuantizeMethodBase]:
         raise NotImplementedError()
 
+    @classmethod
+    def get_min_capability(cls) -> int:
+        """CUDA compute capability gate of the reference (base_config.py:126-135); meaningless on gfx950: always satisfied."""
+        return 0
+
+    @staticmethod
+    def get_config_filenames() -> List[str]:
+        return []
+
+    @classmethod
+    def override_quantization_method(cls, hf_quant_cfg, user_quant) -> Optional[str]:
+        return None
+
     @staticmethod
     def get_from_keys(config: Dict[str, Any], keys: List[str]) -> Any:
         for key in keys:
             if key in config:
                 return config[key]
         raise ValueError(f"Cannot find any of {keys} in the model's quantization config.")
+
+    @staticmethod
+    def get_from_keys_or(config: Dict[str, Any], keys: List[str], default: Any) -> Any:
+        try:
+            return QuantizationConfig.get_from_keys(config, keys)
+        except ValueError:
+            return default
+
+    def get_scaled_act_names(self) -> List[str]:
+        return []

@@ -15,7 +15,7 @@ import torch
 
 
 class ReqToTokenPool:
-    def __init__(self, size: int, max_context_len: int, device: str, enable_memory_saver: bool = False):
+    def __init__(self, size: int, max_context_len: int, device: str, enable_memory_saver: bool):
         self.size = size
         self.max_context_len = max_context_len
         self.device = device
@@ -60,7 +60,7 @@ class KVCache:
 
 class MHATokenToKVPool(KVCache):
     def __init__(self, size: int, page_size: int, dtype: torch.dtype, head_num: int, head_dim: int, layer_num: int,
-                 device: str, enable_memory_saver: bool = False, start_layer: Optional[int] = None,
+                 device: str, enable_memory_saver: bool, start_layer: Optional[int] = None,
                  end_layer: Optional[int] = None):
         super().__init__(size, page_size, dtype, layer_num, device, start_layer, end_layer)
         self.head_num = head_num

@@ -428,9 +428,9 @@ class SyntheticModelRunner:
         self.server_args = SimpleNamespace(triton_attention_num_kv_splits=16, speculative_num_draft_tokens=None,
                                            speculative_num_steps=None, page_size=1)
         self.page_size = 1
-        self.req_to_token_pool = ReqToTokenPool(max_running_requests, context_len, device)
+        self.req_to_token_pool = ReqToTokenPool(max_running_requests, context_len, device, False)
         self.token_to_kv_pool = MHATokenToKVPool(max_total_tokens, 1, kv_cache_dtype or dtype, kv_heads, cfg.head_dim,
-                                                 cfg.num_hidden_layers, device)
+                                                 cfg.num_hidden_layers, device, False)
         self.token_to_kv_pool_allocator = TokenToKVPoolAllocator(max_total_tokens, kv_cache_dtype or dtype, device, self.token_to_kv_pool)
         with torch.device(device):
             self.model = LlamaForCausalLM(cfg, quantization, dtype)

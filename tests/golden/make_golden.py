@@ -455,12 +455,102 @@ def gen_model():
     print("model.npz", len(out), "arrays")
 
 
+def gen_interface():
+    """Interface snapshot: names, parameter order and defaults of the plugin surfaces this build mirrors,
+    read from the reference's source with ``ast`` (signatures only -- data, no code), plus the two native attention op
+    schemas (string literals of torch_extension_cpu.cpp).  tests/test_interface_snapshot.py compares this build with it."""
+    import ast
+    import json
+    import re
+
+    ref = _ref_import.REF_ROOT
+
+    def sig(fn):
+        a = fn.args
+        pos = a.posonlyargs + a.args
+        defaults = [None] * (len(pos) - len(a.defaults)) + [ast.unparse(d) for d in a.defaults]
+        params = [[p.arg, d] for p, d in zip(pos, defaults)]
+        if a.vararg:
+            params.append(["*" + a.vararg.arg, None])
+        for p, d in zip(a.kwonlyargs, a.kw_defaults):
+            params.append([p.arg, None if d is None else ast.unparse(d)])
+        if a.kwarg:
+            params.append(["**" + a.kwarg.arg, None])
+        return params
+
+    def module(rel):
+        return ast.parse(open(os.path.join(ref, rel)).read())
+
+    def class_methods(rel, cls, only=None):
+        for node in module(rel).body:
+            if isinstance(node, ast.ClassDef) and node.name == cls:
+                return {f.name: sig(f) for f in node.body if isinstance(f, ast.FunctionDef) and (only is None or f.name in only)}
+        raise KeyError(cls)
+
+    def functions(rel, names):
+        return {f.name: sig(f) for f in module(rel).body if isinstance(f, ast.FunctionDef) and f.name in names}
+
+    def dataclass_fields(rel, cls):
+        for node in module(rel).body:
+            if isinstance(node, ast.ClassDef) and node.name == cls:
+                return [[st.target.id, ast.unparse(st.annotation), None if st.value is None else ast.unparse(st.value)]
+                        for st in node.body if isinstance(st, ast.AnnAssign) and isinstance(st.target, ast.Name)]
+        raise KeyError(cls)
+
+    def enum_members(rel, cls):
+        for node in module(rel).body:
+            if isinstance(node, ast.ClassDef) and node.name == cls:
+                return [st.targets[0].id for st in node.body if isinstance(st, ast.Assign) and isinstance(st.targets[0], ast.Name)]
+        raise KeyError(cls)
+
+    cpu_ext = open(os.path.join(ref, "sgl-kernel/csrc/cpu/torch_extension_cpu.cpp")).read()
+    schemas = {}
+    for op in ("decode_attention_cpu", "extend_attention_cpu"):
+        mm = re.search(r'"(' + op + r'\([^;]*?->\s*\(\))"', cpu_ext.replace('"\n', '"').replace('\n', ' '), flags=re.S)
+        text = re.sub(r'"\s*"', "", mm.group(1))
+        schemas[op] = " ".join(text.split())
+    snap = {
+        "AttentionBackend": class_methods("python/sglang/srt/layers/attention/base_attn_backend.py", "AttentionBackend"),
+        "TritonAttnBackend": class_methods("python/sglang/srt/layers/attention/triton_backend.py", "TritonAttnBackend",
+                                           {"__init__", "init_forward_metadata", "init_cuda_graph_state",
+                                            "init_forward_metadata_capture_cuda_graph", "init_forward_metadata_replay_cuda_graph",
+                                            "get_cuda_graph_seq_len_fill_value", "forward_extend", "forward_decode"}),
+        "ForwardBatch.fields": dataclass_fields("python/sglang/srt/model_executor/forward_batch_info.py", "ForwardBatch"),
+        "ForwardMode.members": enum_members("python/sglang/srt/model_executor/forward_batch_info.py", "ForwardMode"),
+        "ForwardMode.methods": sorted(class_methods("python/sglang/srt/model_executor/forward_batch_info.py", "ForwardMode")),
+        "QuantizeMethodBase": class_methods("python/sglang/srt/layers/quantization/base_config.py", "QuantizeMethodBase"),
+        "LinearMethodBase": class_methods("python/sglang/srt/layers/quantization/base_config.py", "LinearMethodBase"),
+        "QuantizationConfig": class_methods("python/sglang/srt/layers/quantization/base_config.py", "QuantizationConfig"),
+        "RadixAttention": class_methods("python/sglang/srt/layers/radix_attention.py", "RadixAttention", {"__init__", "forward"}),
+        "ReqToTokenPool": class_methods("python/sglang/srt/mem_cache/memory_pool.py", "ReqToTokenPool"),
+        "MHATokenToKVPool": class_methods("python/sglang/srt/mem_cache/memory_pool.py", "MHATokenToKVPool",
+                                          {"__init__", "get_key_buffer", "get_value_buffer", "get_kv_buffer", "set_kv_buffer"}),
+        "TokenToKVPoolAllocator": class_methods("python/sglang/srt/mem_cache/allocator.py", "TokenToKVPoolAllocator"),
+        "RadixCache": class_methods("python/sglang/srt/mem_cache/radix_cache.py", "RadixCache",
+                                    {"__init__", "reset", "match_prefix", "insert", "cache_finished_req", "cache_unfinished_req",
+                                     "evict", "inc_lock_ref", "dec_lock_ref", "evictable_size", "protected_size"}),
+        "sgl_kernel.gemm": functions("sgl-kernel/python/sgl_kernel/gemm.py",
+                                     {"awq_dequantize", "fp8_scaled_mm", "sgl_per_token_group_quant_fp8", "sgl_per_tensor_quant_fp8",
+                                      "sgl_per_token_quant_fp8"}),
+        "sgl_kernel.attention": functions("sgl-kernel/python/sgl_kernel/attention.py", {"merge_state", "merge_state_v2"}),
+        "sgl_kernel.elementwise": functions("sgl-kernel/python/sgl_kernel/elementwise.py",
+                                            {"rmsnorm", "fused_add_rmsnorm", "silu_and_mul", "apply_rope_with_cos_sin_cache_inplace"}),
+        "triton_ops": {**functions("python/sglang/srt/layers/attention/triton_ops/decode_attention.py", {"decode_attention_fwd"}),
+                       **functions("python/sglang/srt/layers/attention/triton_ops/extend_attention.py", {"extend_attention_fwd"})},
+        "apply_fp8_linear": functions("python/sglang/srt/layers/quantization/fp8_utils.py", {"apply_fp8_linear"})["apply_fp8_linear"],
+        "cpu_op_schemas": schemas,
+    }
+    with open(os.path.join(HERE, "interface.json"), "w") as f:
+        json.dump(snap, f, indent=1, sort_keys=True)
+    print("interface.json", {k: (len(v) if hasattr(v, "__len__") else v) for k, v in snap.items()})
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     torch.manual_seed(0)
     if what in ("attention", "all"):
         gen_attention()
-    for extra in ("index", "quant", "elementwise", "radix", "model"):
+    for extra in ("index", "quant", "elementwise", "radix", "model", "interface"):
         fn = globals().get("gen_" + extra)
         if fn is not None and what in (extra, "all"):
             fn()

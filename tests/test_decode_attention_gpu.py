@@ -269,3 +269,54 @@ def test_native_op_decode_attention_argument_checks(pkg):
         sgl_kernel.decode_attention(**{**args, "req_to_token": args["req_to_token"].to(torch.int16)})
     with pytest.raises(RuntimeError, match="Dv \\+ 1"):
         sgl_kernel.decode_attention(**{**args, "attn_logits": torch.empty(c["bs"], c["hq"], 2, c["d"], device=dev)})
+
+
+def test_decode_config5_shard_shape_bs128_ragged(pkg):
+    """BASELINE config 5 as one TP-8 rank sees it: Hq 8 / Hkv 1 / D 128, batch 128, ragged seq ~ U(512, 4096),
+    the backend's own metadata path (decode_metadata balance rule + create_kv_indices), both decode modes; 4 sampled
+    requests (shortest, longest, two random) against the float64 oracle; all rows finite; the two modes agree."""
+    from ltp_sglang_amd import _cabi, sgl_kernel
+
+    dev = torch.device("cuda:0")
+    bs, hq, hkv, d = 128, 8, 1, 128
+    g = torch.Generator().manual_seed(5)
+    seq = torch.randint(512, 4097, (bs,), generator=g)
+    total = int(seq.sum())
+    pool = total + 1
+    perm = (torch.randperm(pool - 1, generator=g) + 1).int()
+    max_ctx = int(seq.max())
+    r2t = torch.zeros(bs + 2, max_ctx, dtype=torch.int32)
+    rpi = torch.randperm(bs + 2, generator=g)[:bs]
+    cur = 0
+    for i in range(bs):
+        r2t[rpi[i], : seq[i]] = perm[cur:cur + int(seq[i])]
+        cur += int(seq[i])
+    q = torch.randn(bs, hq, d, generator=g).bfloat16()
+    k = torch.randn(pool, hkv, d, generator=g).bfloat16()
+    v = torch.randn(pool, hkv, d, generator=g).bfloat16()
+    qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
+    kv_indptr = torch.zeros(bs + 1, dtype=torch.int32, device=dev)
+    nsplit = torch.zeros(bs, dtype=torch.int32, device=dev)
+    sgl_kernel.decode_metadata(kv_indptr, nsplit, seq.to(dev), 1, hq, hkv, 16, 256, 2)
+    kv_indices = torch.empty(total, dtype=torch.int32, device=dev)
+    sgl_kernel.create_kv_indices(r2t.to(dev), rpi.to(dev), seq.to(dev), kv_indptr, None, kv_indices)
+    assert int(kv_indptr[-1]) == total and int(nsplit.min()) >= 1 and int(nsplit.max()) <= 16
+    outs = []
+    for mode in (0, 1):
+        _cabi.check(_cabi.lib.sgl_mi355_decode_attention_set_mode(mode))
+        try:
+            o = torch.full((bs, hq, d), float("nan"), dtype=torch.bfloat16, device=dev)
+            logits = torch.empty(bs, hq, 16, d, dtype=torch.float32, device=dev)
+            lse = torch.empty(bs, hq, 16, dtype=torch.float32, device=dev)
+            sgl_kernel.decode_attention_fwd(qd, kd, vd, o, kv_indptr, kv_indices, logits, lse, nsplit, 16, d ** -0.5)
+            torch.cuda.synchronize()
+        finally:
+            _cabi.lib.sgl_mi355_decode_attention_set_mode(0)
+        outs.append(o.float().cpu())
+        assert torch.isfinite(outs[-1]).all()
+    assert (outs[0] - outs[1]).abs().max().item() <= 1.6e-2
+    sample = sorted({int(seq.argmin()), int(seq.argmax()), 17, 101})
+    for b in sample:
+        ref = oa.decode_attention_f64(q[b:b + 1], k, v, r2t, rpi[b:b + 1], seq[b:b + 1], d ** -0.5)
+        for o in outs:
+            assert (o[b].double() - ref[0]).abs().max().item() <= 2e-2

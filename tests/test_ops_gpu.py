@@ -698,3 +698,29 @@ def test_fp8_linear_method_per_tensor(scheme, m, sk, pkg):
     err = (y.cpu().float() - ref.float()).abs()
     tol = 1.6e-2 * ref.float().abs() + 2e-2
     assert (err <= tol).all(), float(err.max())
+
+
+# ---------------------------------------------------------------- the prefill GEMM at its real size vs the oracle
+@pytest.mark.parametrize("n", [6144, 28672])
+def test_fp8_gemm_prefill_size_sampled_rows_vs_oracle(n, sk):
+    """fp8_gemm256_kernel (49 % of the profile's GPU time) at M = 16 384, K = 4096, N = qkv / gate_up of Llama-3-8B: 64
+    sampled rows x ALL columns against oracle.quant.scaled_mm (= the reference's torch_scaled_mm, test_fp8_gemm.py:6-14),
+    inputs with the magnitudes of the model (N(0,1) activations per-token quantised, N(0, 0.02) weights per-channel)."""
+    m, k = 16384, 4096
+    g = torch.Generator(device=DEV).manual_seed(n)
+    x = torch.randn(m, k, generator=g, device=DEV, dtype=torch.float32).to(torch.bfloat16)
+    w = (torch.randn(n, k, generator=g, device=DEV, dtype=torch.float32) * 0.02).to(torch.bfloat16)
+    xq = torch.empty(m, k, dtype=torch.float8_e4m3fn, device=DEV)
+    xs = torch.empty(m, 1, dtype=torch.float32, device=DEV)
+    sk.sgl_per_token_quant_fp8(x, xq, xs)
+    ws = w.float().abs().amax(dim=1, keepdim=True).clamp(min=1e-10) / 448.0
+    wq = (w.float() / ws).clamp(-448, 448).to(torch.float8_e4m3fn)
+    bias = torch.randn(n, generator=g, device=DEV, dtype=torch.float32).to(torch.bfloat16)
+    out = sk.fp8_scaled_mm(xq, wq.t(), xs.view(-1), ws.view(-1), torch.bfloat16, bias)
+    rows = torch.cat([torch.tensor([0, 1, 255, 256, m - 1]), torch.randint(0, m, (59,), generator=torch.Generator().manual_seed(3))])
+    ref = oq.scaled_mm(xq[rows.to(DEV)].cpu(), wq.cpu().t(), xs.view(-1)[rows.to(DEV)].cpu(), ws.view(-1).cpu(), torch.bfloat16, bias.cpu())
+    got = out[rows.to(DEV)].cpu().float()
+    torch.testing.assert_close(got, ref.float(), rtol=1.6e-2, atol=2e-2)
+    # the whole output is finite and every 256-row tile is populated (a dropped tile would read as zeros)
+    assert torch.isfinite(out.float()).all()
+    assert (out.float().abs().amax(dim=1) > 0).all()

@@ -89,7 +89,7 @@ def test_request_level_flow_matches_reference(seed, pkg):
     from ltp_sglang_amd.srt.mem_cache.radix_cache import RadixCache
 
     def env():
-        pool = ReqToTokenPool(32, 256, "cpu")
+        pool = ReqToTokenPool(32, 256, "cpu", False)
         alloc = TokenToKVPoolAllocator(600, torch.bfloat16, "cpu", None)
         return RadixCache(pool, alloc, page_size=1), pool, alloc
 
