@@ -46,6 +46,9 @@ from .kvcache import (
     set_kv_buffer,
     write_req_to_token,
 )
+from .torch_ops import register as register_torch_ops
+
+register_torch_ops()   # torch.ops.sgl_kernel.<op>: what the reference's Python wrappers call (gemm.py:34-42)
 
 
 def sglang_per_token_quant_fp8(x):

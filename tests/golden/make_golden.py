@@ -509,7 +509,15 @@ def gen_interface():
         mm = re.search(r'"(' + op + r'\([^;]*?->\s*\(\))"', cpu_ext.replace('"\n', '"').replace('\n', ' '), flags=re.S)
         text = re.sub(r'"\s*"', "", mm.group(1))
         schemas[op] = " ".join(text.split())
+    ext = open(os.path.join(ref, "sgl-kernel/csrc/common_extension.cc")).read()
+    ext = re.sub(r'"\s*\n\s*"', "", ext)   # join adjacent string literals
+    torch_ops = {}
+    for op in ("fp8_scaled_mm", "sgl_per_token_group_quant_fp8", "sgl_per_tensor_quant_fp8", "sgl_per_token_quant_fp8",
+               "awq_dequantize", "merge_state", "merge_state_v2", "rmsnorm", "fused_add_rmsnorm", "silu_and_mul"):
+        mm = re.search(r'm\.def\(\s*"(' + op + r'\([^"]*)"', ext)
+        torch_ops[op] = " ".join(mm.group(1).split())
     snap = {
+        "torch_op_schemas": torch_ops,
         "AttentionBackend": class_methods("python/sglang/srt/layers/attention/base_attn_backend.py", "AttentionBackend"),
         "TritonAttnBackend": class_methods("python/sglang/srt/layers/attention/triton_backend.py", "TritonAttnBackend",
                                            {"__init__", "init_forward_metadata", "init_cuda_graph_state",

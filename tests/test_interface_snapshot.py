@@ -135,3 +135,23 @@ def test_forward_batch_and_mode(pkg):
     assert [m.name for m in ForwardMode] == SNAP["ForwardMode.members"]
     for meth in SNAP["ForwardMode.methods"]:
         assert hasattr(ForwardMode, meth), f"ForwardMode.{meth} is missing"
+
+
+@gpu_free
+def test_torch_ops_registered_with_the_reference_schemas(pkg):
+    """torch.ops.sgl_kernel.<op>.default -- what the reference's Python wrappers call (gemm.py:34-42) -- exists with the
+    reference's m.def schema (common_extension.cc / torch_extension_cpu.cpp) and has no CPU kernel (fails loudly)."""
+    import torch
+
+    from ltp_sglang_amd import sgl_kernel  # noqa: F401  (registers)
+
+    def canon(schema):
+        return ([(a.name, str(a.type), bool(a.alias_info and a.alias_info.is_write), a.has_default_value()) for a in schema.arguments],
+                [str(r.type) for r in schema.returns])
+
+    for name, ref_schema in {**SNAP["torch_op_schemas"], **SNAP["cpu_op_schemas"]}.items():
+        op = getattr(torch.ops.sgl_kernel, name).default
+        assert canon(op._schema) == canon(torch._C.parse_schema(ref_schema)), (name, str(op._schema), ref_schema)
+    with pytest.raises(NotImplementedError):
+        torch.ops.sgl_kernel.sgl_per_token_quant_fp8.default(torch.zeros(2, 8, dtype=torch.bfloat16),
+                                                             torch.zeros(2, 8).to(torch.float8_e4m3fn), torch.zeros(2))
