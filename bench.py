@@ -46,6 +46,9 @@ def parse_args():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prefill-chunk", type=int, default=8, help="requests per prefill call")
+    ap.add_argument("--emulate-tp", type=int, default=0,
+                    help="ONE process builds rank 0's shard of a tp-N model and replaces each collective by a same-size device copy: "
+                         "per-rank compute ms/step without communication (TP-readiness measurement on a 1-GPU box; not the metric)")
     return ap.parse_args()
 
 
@@ -81,21 +84,70 @@ def cpu_baseline_sample(cfg, batch, seq_len, layers):
             xq, sx = oq.per_token_quant_fp8(x)
             oq.scaled_mm(xq, wq.t(), sx.flatten(), sw, torch.bfloat16)
 
-    layer_once()  # warm-up
-    times, budget = [], time.perf_counter() + 20.0
-    while len(times) < 3 and (not times or time.perf_counter() < budget):
-        t0 = time.perf_counter()
-        layer_once()
-        times.append(time.perf_counter() - t0)
-    t_layer = sorted(times)[len(times) // 2]
+    def median_of(fn, n=5):
+        fn()  # warm-up
+        times = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            fn()
+            times.append(time.perf_counter() - t0)
+        return sorted(times)[len(times) // 2], len(times)
+
+    t_layer, n_dec = median_of(layer_once)
     step = t_layer * layers
-    return {"value": batch / step, "unit": "tokens/s", "cores": cores, "kind": "port",
+    # extend leg: one layer's torch-native extend attention + the four linears at a reduced batch
+    eb = min(2, batch)   # reduced batch: the full 32 x 2048 extend would take minutes per iteration on the host
+    e_seq = torch.full((eb,), seq_len, dtype=torch.int64)
+    e_q = torch.randn(eb * seq_len, hq, d, generator=g).bfloat16()
+    e_xs = [torch.randn(eb * seq_len, k, generator=g).bfloat16() for _, k in shapes]
+    zeros = torch.zeros(eb, dtype=torch.int32)
+
+    def extend_once():
+        oa.extend_attention_sdpa(e_q, k_buf, v_buf, req_to_token, rpi[:eb], e_seq, zeros, e_seq.int(), d ** -0.5)
+        for (wq, sw), x in zip(ws, e_xs):
+            xq, sx = oq.per_token_quant_fp8(x)
+            oq.scaled_mm(xq, wq.t(), sx.flatten(), sw, torch.bfloat16)
+
+    t_ext, n_ext = median_of(extend_once)
+    lin = sum(n * k for n, k in shapes)
+    ext_flops = 2.0 * lin * eb * seq_len + eb * (4.0 * seq_len * seq_len * hq * d) / 2
+    cpu_model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "")
+    except OSError:
+        pass
+    return {"value": batch / step, "unit": "tokens/s", "cores": cores, "kind": "port", "cpu_model": cpu_model,
             "sample": f"1 of {layers} decoder layers (torch-native decode attention + 4 w8a8 linears) at batch {batch} x seq {seq_len}, "
-                      f"median of {len(times)} = {t_layer:.3f} s, extrapolated x{layers}; lm_head/norms excluded"}
+                      f"median of {n_dec} = {t_layer:.3f} s, extrapolated x{layers}; lm_head/norms excluded",
+            "extend": {"value": ext_flops / t_ext / 1e12, "unit": "TFLOP/s",
+                       "sample": f"1 layer (torch-native extend attention + 4 w8a8 linears) at batch {eb} x seq {seq_len} without prefix, "
+                                 f"median of {n_ext} = {t_ext:.3f} s"}}
+
+
+def _traffic_profile():
+    """Newest committed PMC summary (profiles/round*_pmc_traffic.json) and the git SHA it was taken at."""
+    import glob
+    import re
+
+    files = glob.glob(os.path.join(ROOT, "profiles", "round*_pmc_traffic.json"))
+    if not files:
+        return None, None
+    path = max(files, key=lambda f: int(re.search(r"round(\d+)", os.path.basename(f)).group(1)))
+    with open(path) as f:
+        return os.path.relpath(path, ROOT), json.load(f)
 
 
 def main():
     args = parse_args()
+    phases, t_phase = {}, time.perf_counter()
+
+    def phase(name):
+        nonlocal t_phase
+        now = time.perf_counter()
+        phases[name] = round(phases.get(name, 0.0) + now - t_phase, 3)
+        t_phase = now
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -120,6 +172,10 @@ def main():
     from ltp_sglang_amd.srt.model_executor.synthetic_llama import LlamaShape, SyntheticModelRunner
 
     comm.init_tensor_parallel()
+    if args.emulate_tp > 1:
+        if world > 1:
+            raise SystemExit("--emulate-tp is a single-process measurement")
+        comm.init_emulated_tensor_parallel(args.emulate_tp)
     if args.decode_attn_mode >= 0:
         from ltp_sglang_amd import _cabi
 
@@ -145,6 +201,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    phase("setup")
     # ---- prefill: fills the KV pool (random token ids as bench_one_batch.py:215) and measures prefill TFLOP/s ----
     import numpy as np
 
@@ -157,6 +214,7 @@ def main():
     gperm = torch.Generator(device=dev).manual_seed(1)
     alloc.free_pages = alloc.free_pages[torch.randperm(alloc.free_pages.numel(), generator=gperm, device=dev)]
     barrier()
+    phase("prefill_warmup")
     t0 = time.perf_counter()
     states, last_logits = [], []
     for c0 in range(0, bs, args.prefill_chunk):
@@ -165,6 +223,7 @@ def main():
         last_logits.append(logits)
     barrier()
     prefill_s = time.perf_counter() - t0
+    phase("prefill")
     from types import SimpleNamespace
 
     state = SimpleNamespace(req_pool_indices=torch.cat([s.req_pool_indices for s in states]),
@@ -181,10 +240,17 @@ def main():
     if use_graph:
         try:
             runner.capture_decode_graph(bs)
-        except Exception as e:  # e.g. a collective that cannot be captured: measure eagerly instead
-            if rank == 0:
+        except Exception as e:
+            if world > 1 and args.dist_backend == "nccl":
+                # the measured N > 1 configuration is the graph-captured step: an eager fallback would silently report a
+                # different (launch-bound) number, so fail instead
+                print(f"[bench] rank {rank}: HIP-graph capture of the decode step failed under RCCL "
+                      f"({type(e).__name__}: {e})", file=sys.stderr)
+                raise SystemExit(3)
+            if rank == 0:   # gloo rehearsal (host-staged collectives cannot be captured): eager by design
                 print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             use_graph = False
+    phase("capture")
     step_fn = runner.decode_graph if use_graph else runner.decode
     for _ in range(args.warmup):
         next_ids = K_argmax(step_fn(state, next_ids))
@@ -194,6 +260,7 @@ def main():
         next_ids = K_argmax(step_fn(state, next_ids))
     barrier()
     elapsed = time.perf_counter() - t0
+    phase("decode")
     if world > 1:
         import torch.distributed as dist
 
@@ -225,19 +292,20 @@ def main():
     kv_bytes = float(sum(state.seq_lens_cpu)) * hkv_r * d * 2 * kv_es  # K and V rows of every cached token
     achieved = kv_bytes / (attn_ms * 1e-3) / 1e9
 
+    phase("roofline_probe")
     if rank != 0:
         return
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the process, so the per-launch figure
-    # comes from the committed summary of a `rocprofv3 --pmc` pass over this same command (tools/pmc_traffic.py)
-    traffic, traffic_src = None, None
-    pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_pmc_traffic.json")
-    if os.path.exists(pmc_path) and (args.model, args.quant, bs, seq, world, args.kv_cache_dtype) == ("llama3-8b", "w8a8_fp8", 32, 2048, 1, "auto"):
-        with open(pmc_path) as f:
-            pmc = json.load(f)
-        k1 = pmc.get("kernels", {}).get("decode_attn_stage1", {})
+    # comes from the newest committed summary of a `rocprofv3 --pmc` pass over this same command (tools/profile_round.sh,
+    # tools/pmc_traffic.py), together with the git SHA that profile was taken at
+    traffic, traffic_src, traffic_sha = None, None, None
+    if (args.model, args.quant, bs, seq, world, args.kv_cache_dtype, args.emulate_tp) == ("llama3-8b", "w8a8_fp8", 32, 2048, 1, "auto", 0):
+        pmc_rel, pmc = _traffic_profile()
+        k1 = (pmc or {}).get("kernels", {}).get("decode_attn_stage1", {})
         if "fetch_bytes_per_launch" in k1:
             traffic = k1["fetch_bytes_per_launch"] + k1.get("write_bytes_per_launch", 0.0)
-            traffic_src = "profiles/round1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; FETCH_SIZE x2 on gfx950)"
+            traffic_src = f"{pmc_rel} (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; FETCH_SIZE x2 on gfx950)"
+            traffic_sha = pmc.get("git_sha")
     tok_s = bs * args.steps / elapsed
     weights_bytes = lin_params * (1 if quant in ("w8a8_fp8", "fp8") else (0.5 if quant == "awq" else 2)) + V * hid * 2
     step_bytes = weights_bytes + bs * (seq + args.warmup + args.steps / 2) * L * 2 * hkv * d * kv_es
@@ -251,7 +319,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"{args.model} {args.quant} decode, batch {bs} x context {seq} (+{args.warmup}+{args.steps} steps), "
                                f"KV pool filled by a real {bs}x{seq} prefill", "global_batch": bs, "seq_len": seq,
-                   "parallelism": f"tp{tp}", "hip_graph": bool(use_graph), "layers": L, "kv_cache_dtype": args.kv_cache_dtype,
+                   "parallelism": f"tp{tp}" + (" (EMULATED: rank 0's shard in one process, collectives = same-size device copies)" if args.emulate_tp > 1 else ""),
+                   "hip_graph": bool(use_graph), "layers": L, "kv_cache_dtype": args.kv_cache_dtype,
                    "act_dtype": args.dtype},
         "prefill": {"tflops": prefill_flops / prefill_s / 1e12, "seconds": prefill_s, "tokens": bs * seq,
                     "tokens_per_s": bs * seq / prefill_s, "flops": prefill_flops},
@@ -259,10 +328,12 @@ def main():
                           "frac_of_hbm_roofline": step_bytes / (elapsed / args.steps) / (8e12 * world)},
         "roofline": {"kernel": "decode_attn_stage1", "bound": "hbm", "achieved": achieved, "peak": 8000.0,
                      "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
-                     "traffic_source": traffic_src, "launch_us": attn_ms * 1e3, "algorithmic_bytes_per_launch": kv_bytes},
+                     "traffic_source": traffic_src, "traffic_profile_git_sha": traffic_sha, "launch_us": attn_ms * 1e3, "algorithmic_bytes_per_launch": kv_bytes},
     }
-    if not args.no_cpu_baseline and args.model != "tiny" and world == 1:  # rank 0 at N = 1 only
+    if not args.no_cpu_baseline and args.model != "tiny" and world == 1 and args.emulate_tp <= 1:  # rank 0 at N = 1 only
         out["cpu_baseline"] = cpu_baseline_sample(cfg, bs, seq, L)
+    phase("cpu_baseline")
+    out["phases_s"] = phases
     print(json.dumps(out))
 
 

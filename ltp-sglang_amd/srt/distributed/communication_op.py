@@ -15,11 +15,14 @@ _TP_GROUP: Optional[dist.ProcessGroup] = None
 _TP_SIZE = 1
 _TP_RANK = 0
 _HOST_STAGED = False  # gloo group + device tensors (single-GPU rehearsal of the TP path): collectives go through host copies
+_EMULATED = False     # one process builds rank 0's shard of a tp-N model; every collective is a same-size device copy
+_CUSTOM_AR = None     # optional one-shot P2P all-reduce over IPC-mapped peer buffers (custom_all_reduce.py)
 
 
 def init_tensor_parallel(group: Optional[dist.ProcessGroup] = None) -> None:
     """Adopts an initialised torch.distributed group (default: WORLD) as the tensor-parallel group."""
-    global _TP_GROUP, _TP_SIZE, _TP_RANK, _HOST_STAGED
+    global _TP_GROUP, _TP_SIZE, _TP_RANK, _HOST_STAGED, _EMULATED
+    _EMULATED = False
     if not dist.is_initialized():
         _TP_GROUP, _TP_SIZE, _TP_RANK, _HOST_STAGED = None, 1, 0, False
         return
@@ -27,6 +30,22 @@ def init_tensor_parallel(group: Optional[dist.ProcessGroup] = None) -> None:
     _HOST_STAGED = dist.get_backend(_TP_GROUP) == "gloo"
     _TP_SIZE = dist.get_world_size(_TP_GROUP)
     _TP_RANK = dist.get_rank(_TP_GROUP)
+
+
+def init_emulated_tensor_parallel(world_size: int) -> None:
+    """Measurement mode (bench.py --emulate-tp N): this process is rank 0 of a tensor-parallel group of ``world_size`` whose
+    other ranks do not exist.  Layers build rank 0's shard (Hq/N heads, N/N columns, K/N rows, vocab/N); each all-reduce /
+    all-gather is replaced by a device copy of the same byte count, so the step time is ONE rank's compute + launch cost
+    with zero communication latency.  Results are NOT the model's (partial sums are never summed): timing only."""
+    global _TP_GROUP, _TP_SIZE, _TP_RANK, _HOST_STAGED, _EMULATED
+    _TP_GROUP, _TP_SIZE, _TP_RANK, _HOST_STAGED, _EMULATED = None, int(world_size), 0, False, world_size > 1
+
+
+def set_custom_all_reduce(obj) -> None:
+    """Installs (or removes, with None) a custom all-reduce object with ``should_use(t)`` / ``all_reduce(t)``
+    (the reference's GroupCoordinator.ca_comm, parallel_state.py:480-500)."""
+    global _CUSTOM_AR
+    _CUSTOM_AR = obj
 
 
 def get_tensor_model_parallel_world_size() -> int:
@@ -41,6 +60,10 @@ def tensor_model_parallel_all_reduce(input_: torch.Tensor) -> torch.Tensor:
     """In-place sum over the TP group (bypassed when tp == 1, parallel_state.py:466-468)."""
     if _TP_SIZE == 1:
         return input_
+    if _EMULATED:
+        return input_.clone()
+    if _CUSTOM_AR is not None and _CUSTOM_AR.should_use(input_):
+        return _CUSTOM_AR.all_reduce(input_)
     if _HOST_STAGED and input_.is_cuda:
         host = input_.cpu()
         dist.all_reduce(host, op=dist.ReduceOp.SUM, group=_TP_GROUP)
@@ -56,6 +79,12 @@ def tensor_model_parallel_all_gather(input_: torch.Tensor, dim: int = -1) -> tor
         return input_
     if dim < 0:
         dim += input_.dim()
+    if _EMULATED:
+        shape = list(input_.shape)
+        shape[dim] *= _TP_SIZE
+        out = torch.empty(shape, dtype=input_.dtype, device=input_.device)
+        out.narrow(dim, 0, input_.shape[dim]).copy_(input_)   # the bytes one rank contributes; the peers' slices stay unwritten
+        return out
     if _HOST_STAGED and input_.is_cuda:
         host = input_.contiguous().cpu()
         parts = [torch.empty_like(host) for _ in range(_TP_SIZE)]

@@ -614,7 +614,7 @@ def test_splitk_workspace_survives_growth_under_a_captured_graph(sk, pkg, monkey
     monkeypatch.setattr(gemm, "WORKSPACE_FLOATS", 1 << 16)
     monkeypatch.setattr(gemm, "_WORKSPACES", {})
     torch.manual_seed(0)
-    m, n, k = 32, 512, 8192      # K > 4096 bytes: k-ranges -> the f32 slab workspace is used
+    m, n, k = 32, 512, 14336     # K > 8 KiB: four k-ranges -> the f32 slab workspace is used
     x = torch.randn(m, k, device=DEV).to(torch.float8_e4m3fn)
     w = torch.randn(n, k, device=DEV).to(torch.float8_e4m3fn)
     sa = torch.rand(m, device=DEV) + 0.5

@@ -56,6 +56,7 @@ def main():
     unit = 1024.0
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) around bench.py --no-graph",
            "corrections": "counter unit = 1024 B; FETCH_SIZE doubled on gfx950 (128-B requests tallied as 64 B)",
+           "git_sha": os.environ.get("GIT_SHA"),   # the GPU box has no .git: pass GIT_SHA=$(git rev-parse --short HEAD) in the gpurun command
            "kernels": {}}
     fetch = load(fetch_dir, "FETCH_SIZE")
     write = load(write_dir, "WRITE_SIZE") if write_dir else {}

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round profile on the GPU box: kernel stats of the default bench command, then the two PMC passes (separately).
-#   tools/profile_round.sh <tag>     -> gpurun_out/<tag>_kernel_stats.csv, gpurun_out/<tag>_pmc_traffic.json
+#   GIT_SHA=<sha> tools/profile_round.sh <tag>     -> gpurun_out/<tag>_kernel_stats.csv, gpurun_out/<tag>_pmc_traffic.json (records the SHA)
 set -e -o pipefail
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 TAG=${1:-round}
