@@ -86,7 +86,10 @@ int sgl_mi355_decode_attention_set_mode(int mode);
  * kv_indices), and extend_attention_cpu's addressing (sgl-kernel/csrc/cpu/extend.cpp:579-723, schema
  * torch_extension_cpu.cpp:270-275) with (req_to_token, req_pool_indices, seq_lens, extend_seq_lens,
  * extend_start_loc) when qo_indptr == NULL.  q/o [T, Hq, D], k/v_extend [T, Hkv, D] (heads contiguous).
- * custom masks and sliding windows (speculative decoding / Gemma) are not part of this build. */
+ * custom_mask (u8 / bool, request b's [ext_len, prefix_len + ext_len] block at mask_indptr[b]; NULL = none),
+ * skip_prefix_custom_mask and sliding_window_size (<= 0 = none) follow extend_attention.py:131-203 (prefix phase: mask
+ * unless skipped, window q_idx <= kv_idx + W over the kv_indices the caller windowed, triton_backend.py:927-955) and
+ * :205-284 (extend phase: the custom mask REPLACES the causal rule). */
 int sgl_mi355_extend_attention(const void* q_extend, const void* k_extend, const void* v_extend, void* o_extend,
                                int64_t q_stride_t, int64_t k_stride_t_ext, int64_t v_stride_t_ext, int64_t o_stride_t,
                                const void* k_buffer, const void* v_buffer, int64_t k_stride_t, int64_t k_stride_h,
@@ -96,7 +99,8 @@ int sgl_mi355_extend_attention(const void* q_extend, const void* k_extend, const
                                const int32_t* extend_seq_lens, const int32_t* extend_start_loc, int batch,
                                int total_q_tokens, int max_len_extend, int num_q_heads, int num_kv_heads, int head_dim,
                                int v_head_dim, float sm_scale, float logit_cap, int is_causal, int dtype, int kv_dtype,
-                               float k_scale, float v_scale, void* stream);
+                               float k_scale, float v_scale, const uint8_t* custom_mask, const int64_t* mask_indptr,
+                               int skip_prefix_custom_mask, int sliding_window_size, void* stream);
 
 /* ---- KV pool / index kernels (bit-exact) -------------------------------------------------- */
 /* create_flashinfer_kv_indices_triton, python/sglang/srt/layers/attention/utils.py:10-45 */

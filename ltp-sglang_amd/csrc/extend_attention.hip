@@ -44,6 +44,15 @@ struct ExtendParams {
   int is_causal;
   int kv_fp8;              // the pool (prefix) rows are e4m3fn bytes; k_extend / v_extend stay in the q dtype
   float k_scale, v_scale;  // K_true = K_fp8 * k_scale, V_true = V_fp8 * v_scale for the prefix part
+  // custom mask / sliding window (extend_attention.py:131-203 stage 1, :205-284 stage 2), MASKED instantiations only:
+  //   custom_mask u8, request b's block starts at mask_indptr[b] and is [ext_len, pre_len + ext_len] row-major; in the prefix
+  //   phase it applies unless skip_prefix_mask; in the extend phase it REPLACES the causal rule (:253-268);
+  //   sliding_window W > 0 masks prefix key j (index inside kv_indices) for query row i (index inside the extend part)
+  //   unless i <= j + W (:191-196) -- the backend hands in the last W + 1 prefix slots (triton_backend.py:927-955).
+  const uint8_t* custom_mask;
+  const int64_t* mask_indptr;
+  int skip_prefix_mask;
+  int sliding_window;
 };
 
 constexpr int kKT = 64;  // kv tokens per tile
@@ -71,7 +80,10 @@ __device__ __forceinline__ u32x4_t cvt8_fp8(const u32x2_t& in) {
   return out;
 }
 
-template <typename T, int D, bool KV8 = false, bool CAP = false>  // CAP: logit soft-capping (its own instantiation)
+// CAP: logit soft-capping (its own instantiation).  MASKED: custom mask and / or sliding window (speculative decoding, window
+// models): every tile takes the masking pass, the per-score mask bytes are plain global loads -- a correctness path whose
+// extra work stays out of the unmasked instantiations; the logit cap is a run-time branch there.
+template <typename T, int D, bool KV8 = false, bool CAP = false, bool MASKED = false>
 __global__ __launch_bounds__(256, 2) void extend_attn_kernel(const ExtendParams p) {
   using Tr = ElemTraits<T>;
   using vec8 = typename Tr::vec8;
@@ -120,6 +132,12 @@ __global__ __launch_bounds__(256, 2) void extend_attn_kernel(const ExtendParams 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int a = lane & 15, g = lane >> 4;
+  const uint8_t* mrow = nullptr;        // MASKED: this request's mask block
+  const int seq_total = pre_len + ext_len;
+  if constexpr (MASKED) {
+    if (p.custom_mask) mrow = p.custom_mask + p.mask_indptr[b];
+  }
+  const bool capped = CAP || (MASKED && p.logit_cap > 0.0f);
 
   // ---- this wave's two 16-row query tiles: tile t covers head slot (16 t) / bq, positions (16 t) % bq ... ----
   int hq_idx[2], qpos[2];
@@ -272,9 +290,10 @@ __global__ __launch_bounds__(256, 2) void extend_attn_kernel(const ExtendParams 
     // a wave whose rows all lie in the causal past of this tile skips it (wave-uniform)
     const int wave_qmax = qpos0 + (((2 * w + 1) * 16) & (bq - 1)) + 15;
     const int wave_qmax0 = qpos0 + (((2 * w) * 16) & (bq - 1)) + 15;
-    const bool skip = !in_prefix && p.is_causal && kbase > max(wave_qmax, wave_qmax0);
+    // (a custom mask replaces the causal rule in the extend phase: no causal skip then)
+    const bool skip = !in_prefix && p.is_causal && !(MASKED && mrow) && kbase > max(wave_qmax, wave_qmax0);
     const int wave_qmin = qpos0 + (bq >= 32 ? ((32 * w) & (bq - 1)) : 0);
-    const bool need_mask = (kbase + kKT > klimit) || (!in_prefix && p.is_causal && kbase + kKT - 1 > wave_qmin);
+    const bool need_mask = MASKED || (kbase + kKT > klimit) || (!in_prefix && p.is_causal && kbase + kKT - 1 > wave_qmin);
     if (!skip) {
       // ---- S^T tiles: s[qt][tt][r] = score(query row a of tile qt, key 16 tt + 4 g + r) ----
       f32x4_t s[2][4];
@@ -305,7 +324,7 @@ __global__ __launch_bounds__(256, 2) void extend_attn_kernel(const ExtendParams 
       // ---- soft-cap every score (CAP; otherwise the scale is folded into the exponent below); then ONE wave-uniform branch
       // masks the ragged last tile of a phase and the causal diagonal (tested per score, the flags cut this loop into ~70
       // basic blocks and nothing was scheduled across them) ----
-      if constexpr (CAP) {
+      if (capped) {   // compile-time true / false in the unmasked instantiations
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
@@ -313,7 +332,30 @@ __global__ __launch_bounds__(256, 2) void extend_attn_kernel(const ExtendParams 
 #pragma unroll
             for (int r = 0; r < 4; ++r) s[qt][tt][r] = softcap2(s[qt][tt][r] * tsm, p.logit_cap);
       }
-      if (need_mask) {
+      if constexpr (MASKED) {
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+          const int qp = qpos[qt];
+          const bool qrow_ok = qp < ext_len;   // padding rows are never stored: keep their mask reads in bounds
+          const uint8_t* mq = mrow ? mrow + (int64_t)min(qp, ext_len - 1) * seq_total + (in_prefix ? 0 : pre_len) : nullptr;
+#pragma unroll
+          for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int key = kbase + 16 * tt + 4 * g + r;
+              bool ok = key < klimit;
+              if (in_prefix) {
+                if (p.sliding_window > 0) ok = ok && (qp <= key + p.sliding_window);
+                if (mq && !p.skip_prefix_mask && ok && qrow_ok) ok = mq[key] != 0;
+              } else if (mq) {
+                if (ok && qrow_ok) ok = mq[key] != 0;
+              } else if (p.is_causal) {
+                ok = ok && (key <= qp);
+              }
+              s[qt][tt][r] = ok ? s[qt][tt][r] : -INFINITY;
+            }
+        }
+      } else if (need_mask) {
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
@@ -328,7 +370,7 @@ __global__ __launch_bounds__(256, 2) void extend_attn_kernel(const ExtendParams 
       }
       // ---- online softmax per query tile, branch-free (m_i in log2 units; the score scale is folded into the exponent's fma;
       // a row that has seen no key yet keeps m = -inf, l = 0, acc = 0 through the clamped maximum) ----
-      const float cs = CAP ? 1.0f : tlog2;  // x = s * cs (sm_scale * log2 e > 0; soft-capped scores are already in log2 units)
+      const float cs = capped ? 1.0f : tlog2;  // x = s * cs (sm_scale * log2 e > 0; soft-capped scores are already in log2 units)
       vec8 pf[2][2];
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt) {
@@ -456,6 +498,9 @@ __global__ __launch_bounds__(64) void extend_attn_generic(const ExtendParams p, 
   const int kh = h / p.group;
   const int nvis = p.is_causal ? qi + 1 : ext_len;
   const int total = pre_len + nvis;
+  // custom mask (subsets of the causal triangle: a row's own key range is [0, qi]; the reference bounds the extend keys per
+  // 64-row block instead, which only differs for mask bits above the diagonal) and sliding window, as in the MFMA kernel
+  const uint8_t* mq = p.custom_mask ? p.custom_mask + p.mask_indptr[b] + (int64_t)qi * (pre_len + ext_len) : nullptr;
   const T* qrow = (const T*)p.q + (int64_t)tq * p.q_stride_t + (int64_t)h * d_qk;
   float accv[4] = {0.f, 0.f, 0.f, 0.f};
   float m_i = -INFINITY, l_i = 0.f;
@@ -463,6 +508,9 @@ __global__ __launch_bounds__(64) void extend_attn_generic(const ExtendParams p, 
     const int key = t0 + lane;
     const bool valid = key < total;
     const bool in_pre = key < pre_len;
+    bool seen = valid;
+    if (valid && in_pre && p.sliding_window > 0) seen = qi <= key + p.sliding_window;
+    if (seen && mq && !(in_pre && p.skip_prefix_mask)) seen = mq[key] != 0;
     const int id = valid ? (in_pre ? idx_row[key] : key - pre_len) : 0;
     float sdot = 0.f;
     if (valid) {
@@ -472,8 +520,8 @@ __global__ __launch_bounds__(64) void extend_attn_generic(const ExtendParams p, 
     }
     float xv = sdot * p.sm_scale;
     xv = (p.logit_cap > 0.f) ? softcap2(xv, p.logit_cap) : xv * kLog2e;
-    xv = valid ? xv : -INFINITY;
-    const float m_new = fmaxf(m_i, wave_reduce_max(xv));
+    xv = seen ? xv : -INFINITY;
+    const float m_new = fmaxf(fmaxf(m_i, wave_reduce_max(xv)), -1e30f);   // (a tile may be masked out entirely)
     const float alpha = __builtin_amdgcn_exp2f(m_i - m_new);
     const float pv = __builtin_amdgcn_exp2f(xv - m_new);
     l_i = l_i * alpha + wave_reduce_sum(pv);
@@ -507,15 +555,16 @@ __global__ __launch_bounds__(64) void extend_attn_generic(const ExtendParams p, 
   }
 }
 
-template <typename T, int D, bool KV8, bool CAP = false>
+template <typename T, int D, bool KV8, bool CAP = false, bool MASKED = false>
 int launch_mfma(ExtendParams& p, int max_len_extend, hipStream_t st) {
-  if constexpr (!CAP) {
+  if constexpr (!CAP && !MASKED) {
+    if (p.custom_mask != nullptr || p.sliding_window > 0) return launch_mfma<T, D, KV8, false, true>(p, max_len_extend, st);
     if (p.logit_cap > 0.0f) return launch_mfma<T, D, KV8, true>(p, max_len_extend, st);
   }
   constexpr int smem = 2 * 2 * kKT * D * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)extend_attn_kernel<T, D, KV8, CAP>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)extend_attn_kernel<T, D, KV8, CAP, MASKED>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
   // head slots per workgroup: smallest power of two >= min(group, 8); positions per workgroup = 128 / slots
@@ -533,7 +582,7 @@ int launch_mfma(ExtendParams& p, int max_len_extend, hipStream_t st) {
     snprintf(g_sgl_mi355_err, sizeof(g_sgl_mi355_err), "extend_attention: grid too large");
     return SGL_MI355_EINVAL;
   }
-  hipLaunchKernelGGL((extend_attn_kernel<T, D, KV8, CAP>), dim3((unsigned)nblocks), dim3(256), smem, st, p);
+  hipLaunchKernelGGL((extend_attn_kernel<T, D, KV8, CAP, MASKED>), dim3((unsigned)nblocks), dim3(256), smem, st, p);
   SGL_HIP_LAUNCH_CHECK();
   return SGL_MI355_OK;
 }
@@ -557,8 +606,11 @@ extern "C" int sgl_mi355_extend_attention(
     const int64_t* req_pool_indices, const int64_t* seq_lens, const int32_t* extend_seq_lens,
     const int32_t* extend_start_loc, int batch, int total_q_tokens, int max_len_extend, int num_q_heads,
     int num_kv_heads, int head_dim, int v_head_dim, float sm_scale, float logit_cap, int is_causal, int dtype,
-    int kv_dtype, float k_scale, float v_scale, void* stream) {
+    int kv_dtype, float k_scale, float v_scale, const uint8_t* custom_mask, const int64_t* mask_indptr,
+    int skip_prefix_custom_mask, int sliding_window_size, void* stream) {
   SGL_CHECK(batch >= 0 && total_q_tokens >= 0, "extend_attention: negative sizes");
+  SGL_CHECK(custom_mask == nullptr || (mask_indptr != nullptr && qo_indptr != nullptr),
+            "extend_attention: custom_mask needs mask_indptr (and the qo_indptr / kv_indptr addressing mode)");
   if (batch == 0 || total_q_tokens == 0 || max_len_extend <= 0) return SGL_MI355_OK;
   SGL_CHECK(q_extend && k_extend && v_extend && o_extend, "extend_attention: null tensor pointer");
   SGL_CHECK((qo_indptr && kv_indptr) || (req_to_token && req_pool_indices && seq_lens && extend_seq_lens && extend_start_loc),
@@ -594,6 +646,8 @@ extern "C" int sgl_mi355_extend_attention(
   p.sm_scale = sm_scale; p.logit_cap = logit_cap; p.is_causal = is_causal;
   p.kv_fp8 = kv8 ? 1 : 0; p.k_scale = kv8 ? k_scale : 1.0f; p.v_scale = kv8 ? v_scale : 1.0f;
   p.nqb = 0; p.bq_log2 = 0; p.hchunks = 1;
+  p.custom_mask = custom_mask; p.mask_indptr = mask_indptr; p.skip_prefix_mask = skip_prefix_custom_mask ? 1 : 0;
+  p.sliding_window = sliding_window_size > 0 ? sliding_window_size : 0;
   hipStream_t st = (hipStream_t)stream;
   return dtype == SGL_BF16 ? launch_all<__bf16>(p, head_dim, v_head_dim, total_q_tokens, max_len_extend, st)
                            : launch_all<_Float16>(p, head_dim, v_head_dim, total_q_tokens, max_len_extend, st);

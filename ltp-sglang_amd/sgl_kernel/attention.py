@@ -88,11 +88,16 @@ def extend_attention_fwd(
 ) -> None:
     """Same contract as extend_attention.py:306-438: q/o_extend [T, Hq, D], k/v_extend [T, Hkv, D] contiguous new
     tokens, k/v_buffer the pool, kv_indices the cached prefix slots of each request."""
-    _require_cuda(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr, kv_indptr, kv_indices)
-    if custom_mask is not None:
-        raise RuntimeError("custom_mask (speculative decoding) is not supported by the MI355X extend kernel")
-    if sliding_window_size is not None and sliding_window_size > 0:
-        raise RuntimeError("sliding-window attention is not supported by the MI355X extend kernel")
+    _require_cuda(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr, kv_indptr, kv_indices, custom_mask,
+                  mask_indptr)
+    mask_u8 = None
+    if custom_mask is not None:   # bool / uint8, flat; request b's [ext_len, prefix_len + ext_len] block at mask_indptr[b]
+        if mask_indptr is None or mask_indptr.dtype != torch.int64:
+            raise RuntimeError("extend_attention_fwd: custom_mask needs an int64 mask_indptr")   # triton_backend.py:97-99
+        if custom_mask.dtype not in (torch.bool, torch.uint8):
+            raise RuntimeError(f"extend_attention_fwd: custom_mask must be bool or uint8, got {custom_mask.dtype}")
+        mask_u8 = custom_mask.contiguous().view(torch.uint8)
+    window = int(sliding_window_size) if sliding_window_size is not None and sliding_window_size > 0 else -1
     t, hq, d = q_extend.shape
     hkv, dv = v_extend.shape[1], v_extend.shape[2]
     assert q_extend.stride(2) == 1 and q_extend.stride(1) == d and o_extend.stride(1) == dv
@@ -108,7 +113,7 @@ def extend_attention_fwd(
             ptr(kv_indptr), ptr(kv_indices), None, 0, None, None, None, None, qo_indptr.numel() - 1, t,
             int(max_len_extend), hq, hkv, d, dv, float(sm_scale), float(logit_cap), int(bool(is_causal)),
             dtype_code(q_extend.dtype), dtype_code(q_extend.dtype if k_buffer is None else k_buffer.dtype), float(k_scale),
-            float(v_scale), current_stream(),
+            float(v_scale), ptr(mask_u8), ptr(mask_indptr), int(bool(skip_prefix_custom_mask)), window, current_stream(),
         )
     )
 
@@ -175,7 +180,8 @@ def extend_attention(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer,
             v_extend.stride(0), o_extend.stride(0), ptr(k_buffer), ptr(v_buffer), kst, ksh, vst, vsh, None, None, None,
             ptr(req_to_token), req_to_token.stride(0), ptr(req_pool_indices), ptr(seq_lens), ptr(extend_seq_lens),
             ptr(extend_start_loc), seq_lens.numel(), t, int(max_len_extend), hq, hkv, d, dv, float(sm_scale),
-            float(logit_cap), 1, dtype_code(q_extend.dtype), dtype_code(k_buffer.dtype), 1.0, 1.0, current_stream(),
+            float(logit_cap), 1, dtype_code(q_extend.dtype), dtype_code(k_buffer.dtype), 1.0, 1.0, None, None, 0, -1,
+            current_stream(),
         )
     )
 

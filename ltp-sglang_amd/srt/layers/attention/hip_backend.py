@@ -29,6 +29,10 @@ class ForwardMetadata:
     qo_indptr: Optional[torch.Tensor]
     custom_mask: Optional[torch.Tensor] = None
     mask_indptr: Optional[torch.Tensor] = None
+    # sliding-window layers attend over the last min(len, W + 1) slots only (triton_backend.py:23-37,927-955)
+    window_kv_indptr: Optional[torch.Tensor] = None
+    window_kv_indices: Optional[torch.Tensor] = None
+    window_num_kv_splits: Optional[torch.Tensor] = None
 
 
 def _rows(t):
@@ -53,13 +57,16 @@ class HipAttnBackend(AttentionBackend):
         self.skip_prefill = skip_prefill
         if not skip_prefill:
             self.qo_indptr = torch.zeros((max_bs + 1,), dtype=torch.int32, device=self.device)
-        if getattr(model_runner, "sliding_window_size", None):
-            raise RuntimeError("HipAttnBackend: sliding-window models are outside this build's hot path")
+        self.sliding_window_size = getattr(model_runner, "sliding_window_size", None)
+        self.window_kv_indptr = torch.zeros_like(self.kv_indptr) if self._has_window() else None   # triton_backend.py:81-89
         cfg = model_runner.model_config
         tp = getattr(model_runner, "attention_tp_size", 1)
         self.num_head = cfg.num_attention_heads // tp
         self.num_kv_head = cfg.get_num_kv_heads(tp)
         args = getattr(model_runner, "server_args", None)
+        self.num_draft_tokens = getattr(args, "speculative_num_draft_tokens", None)
+        if not skip_prefill:
+            self.mask_indptr = torch.zeros((max_bs + 1,), dtype=torch.int64, device=self.device)   # triton_backend.py:97-99
         self.max_kv_splits = getattr(args, "triton_attention_num_kv_splits", None) or default_max_kv_splits()
         # 0 = reference heuristic, 1 = static, 2 = MI355X balance rule (default; split counts are not parity-critical)
         self.static_kv_splits = 1 if getattr(args, "static_kv_splits", False) else int(getattr(args, "kv_split_rule", 2))
@@ -74,7 +81,23 @@ class HipAttnBackend(AttentionBackend):
         self._merge_counters = torch.zeros(self.max_bs_hint, dtype=torch.int32, device=self.device)
 
     # ------------------------------------------------------------------ metadata
-    def _decode_metadata(self, bs, req_pool_indices, seq_lens, seq_lens_sum, kv_indices=None, scratch=None):
+    def _has_window(self) -> bool:
+        return self.sliding_window_size is not None and self.sliding_window_size > 0
+
+    def _window_metadata(self, bs, req_pool_indices, lens, want_splits, kv_indices=None, num_kv_splits=None):
+        """update_sliding_window_buffer (triton_backend.py:927-983): the last min(len, W + 1) slots of every request."""
+        window_lens = torch.clamp(lens, max=self.sliding_window_size + 1)
+        indptr = self.window_kv_indptr[: bs + 1]
+        if want_splits and num_kv_splits is None:
+            num_kv_splits = torch.empty((bs,), dtype=torch.int32, device=self.device)
+        K.decode_metadata(indptr, num_kv_splits if want_splits else None, window_lens, 1, self.num_head, self.num_kv_head,
+                          self.max_kv_splits, self.device_core_count, self.static_kv_splits)
+        if kv_indices is None:
+            kv_indices = torch.empty(bs * (self.sliding_window_size + 1), dtype=torch.int32, device=self.device)
+        K.create_kv_indices(self.req_to_token, req_pool_indices, window_lens, indptr, lens - window_lens, kv_indices)
+        return indptr, kv_indices, (num_kv_splits if want_splits else None)
+
+    def _decode_metadata(self, bs, req_pool_indices, seq_lens, seq_lens_sum, kv_indices=None, scratch=None, window_bufs=None):
         kv_indptr = self.kv_indptr[: bs + 1]
         if scratch is None:
             num_kv_splits = torch.empty((bs,), dtype=torch.int32, device=self.device)
@@ -88,12 +111,37 @@ class HipAttnBackend(AttentionBackend):
         if kv_indices is None:
             kv_indices = torch.empty(seq_lens_sum, dtype=torch.int32, device=self.device)
         K.create_kv_indices(self.req_to_token, req_pool_indices, seq_lens, kv_indptr, None, kv_indices)
-        return ForwardMetadata(attn_logits, attn_lse, None, num_kv_splits, kv_indptr, kv_indices, None)
+        md = ForwardMetadata(attn_logits, attn_lse, None, num_kv_splits, kv_indptr, kv_indices, None)
+        if self._has_window():
+            wi, ws = window_bufs if window_bufs is not None else (None, None)
+            md.window_kv_indptr, md.window_kv_indices, md.window_num_kv_splits = self._window_metadata(
+                bs, req_pool_indices, seq_lens, True, wi, ws)
+        return md
+
+    def _target_verify_metadata(self, forward_batch):
+        """Speculative-decoding verification (triton_backend.py:224-258): every request extends by num_draft_tokens over its
+        whole cached sequence under the tree mask spec_info.custom_mask; only the attention inputs are built here (the
+        draft / verify control flow around it is outside this build)."""
+        bs = len(forward_batch.req_pool_indices)
+        n = int(self.num_draft_tokens)
+        spec = forward_batch.spec_info
+        qo_indptr = torch.arange(0, (1 + bs) * n, step=n, dtype=torch.int32, device=self.device)
+        kv_indptr = self.kv_indptr[: bs + 1]
+        K.decode_metadata(kv_indptr, None, forward_batch.seq_lens, 1, self.num_head, self.num_kv_head, self.max_kv_splits,
+                          self.device_core_count)
+        kv_indices = torch.empty(int(forward_batch.seq_lens_sum), dtype=torch.int32, device=self.device)
+        K.create_kv_indices(self.req_to_token, forward_batch.req_pool_indices, forward_batch.seq_lens, kv_indptr, None, kv_indices)
+        mask_indptr = self.mask_indptr[: bs + 1]
+        mask_indptr[1:] = torch.cumsum(n * (forward_batch.seq_lens[:bs] + n), dim=0)
+        return ForwardMetadata(None, None, n, None, kv_indptr, kv_indices, qo_indptr, spec.custom_mask, mask_indptr)
 
     def init_forward_metadata(self, forward_batch):
         bs = forward_batch.batch_size
+        if forward_batch.forward_mode.is_target_verify():
+            self.forward_metadata = self._target_verify_metadata(forward_batch)
+            return
         if forward_batch.spec_info is not None:
-            raise RuntimeError("HipAttnBackend: speculative decoding is outside this build's hot path")
+            raise RuntimeError("HipAttnBackend: draft-model speculative modes are outside this build's hot path")
         if forward_batch.forward_mode.is_decode_or_idle():
             self.forward_metadata = self._decode_metadata(bs, forward_batch.req_pool_indices, forward_batch.seq_lens,
                                                           forward_batch.seq_lens_sum)
@@ -113,6 +161,10 @@ class HipAttnBackend(AttentionBackend):
         ext_cpu = forward_batch.extend_seq_lens_cpu
         max_extend_len = int(max(ext_cpu)) if ext_cpu is not None else int(forward_batch.extend_seq_lens.max().item())
         self.forward_metadata = ForwardMetadata(None, None, max_extend_len, None, kv_indptr, kv_indices, qo_indptr)
+        if self._has_window():
+            md = self.forward_metadata
+            md.window_kv_indptr, md.window_kv_indices, _ = self._window_metadata(
+                bs, forward_batch.req_pool_indices, forward_batch.extend_prefix_lens, False)
 
     # ------------------------------------------------------------------ HIP-graph hooks
     def init_cuda_graph_state(self, max_bs: int, max_num_tokens: int, kv_indices_buf: Optional[torch.Tensor] = None):
@@ -123,6 +175,9 @@ class HipAttnBackend(AttentionBackend):
             attn_lse=torch.zeros((max_num_tokens, self.num_head, self.max_kv_splits), dtype=torch.float32, device=self.device),
             num_kv_splits=torch.full((max_num_tokens,), self.max_kv_splits, dtype=torch.int32, device=self.device),
         )
+        if self._has_window():   # triton_backend.py:371-392
+            self._graph["window_kv_indices"] = torch.zeros((max_num_tokens * (self.sliding_window_size + 1),), dtype=torch.int32, device=self.device)
+            self._graph["window_num_kv_splits"] = torch.full((max_num_tokens,), self.max_kv_splits, dtype=torch.int32, device=self.device)
 
     def init_forward_metadata_capture_cuda_graph(self, bs, num_tokens, req_pool_indices, seq_lens, encoder_lens,
                                                  forward_mode, spec_info):
@@ -130,7 +185,8 @@ class HipAttnBackend(AttentionBackend):
             raise ValueError(f"Invalid forward mode: {forward_mode=} for HIP graph capture.")
         g = self._graph
         scratch = (g["num_kv_splits"][:bs], g["attn_logits"][:bs], g["attn_lse"][:bs])
-        self.forward_metadata = self._decode_metadata(bs, req_pool_indices, seq_lens, 0, g["kv_indices"], scratch)
+        wb = (g["window_kv_indices"], g["window_num_kv_splits"][:bs]) if self._has_window() else None
+        self.forward_metadata = self._decode_metadata(bs, req_pool_indices, seq_lens, 0, g["kv_indices"], scratch, wb)
 
     def init_forward_metadata_replay_cuda_graph(self, bs, req_pool_indices, seq_lens, seq_lens_sum, encoder_lens,
                                                 forward_mode, spec_info, seq_lens_cpu):
@@ -138,20 +194,27 @@ class HipAttnBackend(AttentionBackend):
             raise ValueError(f"Invalid forward mode: {forward_mode=} for HIP graph replay.")
         g = self._graph
         scratch = (g["num_kv_splits"][:bs], g["attn_logits"][:bs], g["attn_lse"][:bs])
+        wb = (g["window_kv_indices"], g["window_num_kv_splits"][:bs]) if self._has_window() else None
         self.forward_metadata = self._decode_metadata(bs, req_pool_indices[:bs], seq_lens[:bs], seq_lens_sum,
-                                                      g["kv_indices"], scratch)
+                                                      g["kv_indices"], scratch, wb)
 
     def get_cuda_graph_seq_len_fill_value(self):
         return 1
 
     # ------------------------------------------------------------------ forwards
-    @staticmethod
-    def _check_layer(layer):
+    def _layer_kv(self, layer):
+        """(kv_indptr, kv_indices, num_kv_splits, window) a layer attends over: the window buffers for a sliding-window layer
+        (triton_backend.py:655-666,713-719), the full ones otherwise.  A window layer's decode uses the split counts computed
+        for the window lengths (the reference passes the full-length counts; split counts do not change the result)."""
+        md = self.forward_metadata
         if layer.sliding_window_size is not None and layer.sliding_window_size > -1:
-            raise RuntimeError("HipAttnBackend: sliding-window layers are outside this build's hot path")
+            if md.window_kv_indptr is None:
+                raise RuntimeError("HipAttnBackend: a sliding-window layer needs model_runner.sliding_window_size to be set")
+            return md.window_kv_indptr, md.window_kv_indices, md.window_num_kv_splits, int(layer.sliding_window_size)
+        return md.kv_indptr, md.kv_indices, md.num_kv_splits, -1
 
     def forward_extend(self, q, k, v, layer, forward_batch, save_kv_cache=True):
-        self._check_layer(layer)
+        kv_indptr, kv_indices, _, window = self._layer_kv(layer)
         o = q.new_empty((q.shape[0], layer.tp_q_head_num * layer.v_head_dim))
         if save_kv_cache:
             forward_batch.token_to_kv_pool.set_kv_buffer(layer, forward_batch.out_cache_loc, k, v, layer.k_scale, layer.v_scale)
@@ -162,13 +225,13 @@ class HipAttnBackend(AttentionBackend):
             o.view(-1, layer.tp_q_head_num, layer.v_head_dim),
             forward_batch.token_to_kv_pool.get_key_buffer(layer.layer_id),
             forward_batch.token_to_kv_pool.get_value_buffer(layer.layer_id),
-            md.qo_indptr, md.kv_indptr, md.kv_indices, None, causal, None, md.max_extend_len, layer.scaling, layer.logit_cap,
-            k_scale=layer.k_scale_float or 1.0, v_scale=layer.v_scale_float or 1.0,
+            md.qo_indptr, kv_indptr, kv_indices, md.custom_mask, causal, md.mask_indptr, md.max_extend_len, layer.scaling,
+            layer.logit_cap, sliding_window_size=window, k_scale=layer.k_scale_float or 1.0, v_scale=layer.v_scale_float or 1.0,
         )
         return o
 
     def forward_decode(self, q, k, v, layer, forward_batch, save_kv_cache=True):
-        self._check_layer(layer)
+        kv_indptr, kv_indices, num_kv_splits, _ = self._layer_kv(layer)
         q = q.reshape(-1, layer.tp_q_head_num * layer.qk_head_dim)
         o = q.new_empty((q.shape[0], layer.tp_q_head_num * layer.v_head_dim))
         if save_kv_cache:  # decode reads the new token from the pool, so this must precede the attention launch
@@ -179,7 +242,7 @@ class HipAttnBackend(AttentionBackend):
             forward_batch.token_to_kv_pool.get_key_buffer(layer.layer_id),
             forward_batch.token_to_kv_pool.get_value_buffer(layer.layer_id),
             o.view(-1, layer.tp_q_head_num, layer.v_head_dim),
-            md.kv_indptr, md.kv_indices, md.attn_logits, md.attn_lse, md.num_kv_splits, self.max_kv_splits,
+            kv_indptr, kv_indices, md.attn_logits, md.attn_lse, num_kv_splits, self.max_kv_splits,
             layer.scaling, layer.logit_cap, layer.k_scale_float or 1.0, layer.v_scale_float or 1.0,
         )
         return o
@@ -187,13 +250,13 @@ class HipAttnBackend(AttentionBackend):
     def forward_decode_partial(self, q, layer, forward_batch):
         """Stage 1 only (the caller has already written K/V and will merge the split partials itself, e.g. fused with
         the next op's quantisation): returns the ForwardMetadata holding attn_logits / attn_lse / num_kv_splits."""
-        self._check_layer(layer)
+        kv_indptr, kv_indices, num_kv_splits, _ = self._layer_kv(layer)
         md = self.forward_metadata
         K.decode_attention_fwd(
             q.reshape(-1, layer.tp_q_head_num, layer.qk_head_dim),
             forward_batch.token_to_kv_pool.get_key_buffer(layer.layer_id),
             forward_batch.token_to_kv_pool.get_value_buffer(layer.layer_id),
-            None, md.kv_indptr, md.kv_indices, md.attn_logits, md.attn_lse, md.num_kv_splits, self.max_kv_splits,
+            None, kv_indptr, kv_indices, md.attn_logits, md.attn_lse, num_kv_splits, self.max_kv_splits,
             layer.scaling, layer.logit_cap, layer.k_scale_float or 1.0, layer.v_scale_float or 1.0,
         )
         return md
@@ -201,7 +264,7 @@ class HipAttnBackend(AttentionBackend):
     def forward_decode_merged_quant(self, q, layer, forward_batch, want_o=False):
         """Stage 1 + in-launch stage 2 + per-token fp8 quantisation of the merged rows (the attention -> o_proj hand-off of the
         w8a8 decode step in one kernel).  Returns (o or None, o_q, o_scale)."""
-        self._check_layer(layer)
+        kv_indptr, kv_indices, num_kv_splits, _ = self._layer_kv(layer)
         md = self.forward_metadata
         if self._merge_counters is None or self._merge_counters.device != q.device:
             self._merge_counters = torch.zeros(max(self.max_bs_hint, q.shape[0]), dtype=torch.int32, device=q.device)
@@ -211,7 +274,7 @@ class HipAttnBackend(AttentionBackend):
             q.reshape(-1, layer.tp_q_head_num, layer.qk_head_dim),
             forward_batch.token_to_kv_pool.get_key_buffer(layer.layer_id),
             forward_batch.token_to_kv_pool.get_value_buffer(layer.layer_id),
-            md.kv_indptr, md.kv_indices, md.attn_logits, md.attn_lse, md.num_kv_splits, self.max_kv_splits, layer.scaling,
+            kv_indptr, kv_indices, md.attn_logits, md.attn_lse, num_kv_splits, self.max_kv_splits, layer.scaling,
             self._merge_counters, layer.logit_cap, layer.k_scale_float or 1.0, layer.v_scale_float or 1.0, want_o=want_o)
 
     def support_triton(self):

@@ -118,6 +118,44 @@ def extend_attention_f64(
     return out
 
 
+def extend_attention_masked_f64(q, k_extend, v_extend, k_buffer, v_buffer, qo_indptr, kv_indptr, kv_indices, custom_mask, mask_indptr,
+                                scaling, is_causal=True, skip_prefix_custom_mask=True, sliding_window_size=-1, logit_cap=0.0):
+    """The Triton extend kernel's visibility rules (extend_attention.py:131-203 prefix phase, :205-284 extend phase) in float64:
+    prefix key j (position inside kv_indices) is seen by query row i (position inside the extend part) iff
+    [custom_mask[i, j] unless skipped] and [i <= j + W when a window is set]; extend key j iff custom_mask[i, pre + j] when a
+    mask is given, else j <= i when causal.  Pinned by tests/golden/extend_mask.npz (the reference kernel on the interpreter)."""
+    t, hq, _ = q.shape
+    hkv = k_extend.shape[1]
+    grp = hq // hkv
+    out = torch.zeros(t, hq, v_extend.shape[2], dtype=torch.float64)
+    for b in range(len(qo_indptr) - 1):
+        q0, q1 = int(qo_indptr[b]), int(qo_indptr[b + 1])
+        ext = q1 - q0
+        if ext == 0:
+            continue
+        idx = kv_indices[int(kv_indptr[b]): int(kv_indptr[b + 1])].long()
+        pre = idx.numel()
+        keys = torch.cat([k_buffer[idx], k_extend[q0:q1]]).double().repeat_interleave(grp, dim=1)   # [pre + ext, Hq, D]
+        vals = torch.cat([v_buffer[idx], v_extend[q0:q1]]).double().repeat_interleave(grp, dim=1)
+        s = torch.einsum("qhd,nhd->hqn", q[q0:q1].double(), keys) * scaling
+        s = _softcap(s, logit_cap)
+        qi = torch.arange(ext).view(ext, 1)
+        vis = torch.ones(ext, pre + ext, dtype=torch.bool)
+        if custom_mask is not None:
+            m = custom_mask[int(mask_indptr[b]): int(mask_indptr[b]) + ext * (pre + ext)].view(ext, pre + ext).bool()
+            if not skip_prefix_custom_mask:
+                vis[:, :pre] &= m[:, :pre]
+            vis[:, pre:] &= m[:, pre:]
+        elif is_causal:
+            vis[:, pre:] &= torch.arange(ext).view(1, ext) <= qi
+        if sliding_window_size is not None and sliding_window_size > 0:
+            vis[:, :pre] &= qi <= torch.arange(pre).view(1, pre) + sliding_window_size
+        s = s.masked_fill(~vis.unsqueeze(0), -math.inf)
+        p = torch.softmax(s, dim=-1)
+        out[q0:q1] = torch.einsum("hqn,nhd->qhd", torch.nan_to_num(p), vals)
+    return out
+
+
 def merge_state(v_a, s_a, v_b, s_b):
     """merge_state_torch, sgl-kernel/tests/test_merge_state_v2.py:101-135 (the reference's own torch restatement)."""
     p, s = s_a.float().clone(), s_b.float().clone()

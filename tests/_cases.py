@@ -250,6 +250,71 @@ def build_rope_case(case, seed=0):
 
 
 # ----------------------------------------------------------------------------------------------
+# custom-mask / sliding-window extend cases (reference: the Triton _fwd_kernel itself under TRITON_INTERPRET=1, f16 -- the
+# interpreter has no bf16).  The mask of request b is a [ext, pre + ext] block: prefix columns random, extend columns a random
+# SUBSET of the causal triangle with the diagonal set (what a speculative-decoding tree mask is).
+# ----------------------------------------------------------------------------------------------
+MASK_CASES = [
+    dict(name="msk_tree_skip_prefix", hq=8, hkv=2, d=128, pre=[70, 0, 33], ext=[40, 65, 7], mask=True, skip_prefix=True, window=-1),
+    dict(name="msk_tree_full", hq=8, hkv=2, d=128, pre=[70, 0, 33], ext=[40, 65, 7], mask=True, skip_prefix=False, window=-1),
+    dict(name="msk_window", hq=8, hkv=2, d=128, pre=[150, 20, 64], ext=[90, 30, 1], mask=False, skip_prefix=True, window=48),
+    # (every row must see a key of its FIRST prefix tile: the reference's online softmax turns a fully masked first tile into
+    # NaN -- exp(-inf - -inf) -- so extend lengths stay <= window here; this build's kernel is NaN-free there)
+    dict(name="msk_window_and_mask_d64", hq=4, hkv=4, d=64, pre=[100, 5], ext=[30, 25], mask=True, skip_prefix=False, window=31),
+]
+
+
+def mask_rows(c, max_rows=40):
+    """Output rows kept in the extend_mask fixture: first and last new token of every request + seeded random rows."""
+    total = int(c["qo_indptr"][-1])
+    ends = c["qo_indptr"][1:].long()
+    keep = set((ends - 1).tolist()) | set(c["qo_indptr"][:-1].long().tolist())
+    rng = np.random.RandomState(4321)
+    for r in rng.permutation(total):
+        if len(keep) >= max_rows:
+            break
+        keep.add(int(r))
+    return torch.tensor(sorted(keep), dtype=torch.int64)
+
+
+def build_mask_case(case, seed=0):
+    """The attention problem (f16) + custom_mask (bool, flat) / mask_indptr (int64) + the kv_indptr / kv_indices the backend
+    would hand to the kernel: with a window, the LAST min(pre, W + 1) prefix slots (triton_backend.py:927-955)."""
+    base = dict(name=case["name"], kind="extend", dtype="f16", hq=case["hq"], hkv=case["hkv"], d=case["d"], pre=case["pre"], ext=case["ext"])
+    c = build_attn_case(base, seed=seed + 11)
+    rng = np.random.RandomState(seed + 900)
+    bs = c["bs"]
+    pre, ext = list(case["pre"]), list(case["ext"])
+    w = case["window"]
+    kpre = [min(p, w + 1) for p in pre] if w > 0 else pre       # prefix keys the kernel is given
+    kv_indptr = torch.zeros(bs + 1, dtype=torch.int32)
+    kv_indptr[1:] = torch.cumsum(torch.tensor(kpre), 0)
+    kv_indices = torch.cat([c["req_to_token"][c["req_pool_indices"][i], pre[i] - kpre[i]: pre[i]] for i in range(bs)]).int()
+    qo_indptr = torch.zeros(bs + 1, dtype=torch.int32)
+    qo_indptr[1:] = torch.cumsum(torch.tensor(ext), 0)
+    custom_mask = mask_indptr = None
+    if case["mask"]:
+        blocks, lens = [], []
+        for i in range(bs):
+            m = rng.random_sample((ext[i], kpre[i] + ext[i])) < 0.6
+            tri = np.tril(np.ones((ext[i], ext[i]), dtype=bool))
+            m[:, kpre[i]:] &= tri
+            m[np.arange(ext[i]), kpre[i] + np.arange(ext[i])] = True
+            if kpre[i]:
+                m[:, 0] = True   # the first prefix tile is never fully masked (reference NaN, see MASK_CASES)
+            blocks.append(m.reshape(-1))
+            lens.append(m.size)
+        custom_mask = torch.from_numpy(np.concatenate(blocks))
+        mask_indptr = torch.zeros(bs + 1, dtype=torch.int64)
+        mask_indptr[1:] = torch.cumsum(torch.tensor(lens), 0)
+    new = c["out_cache_loc"]
+    c.update(kv_indptr=kv_indptr, kv_indices=kv_indices, qo_indptr=qo_indptr, custom_mask=custom_mask, mask_indptr=mask_indptr,
+             k_extend=c["k_buffer"][new].contiguous(), v_extend=c["v_buffer"][new].contiguous(), kpre=kpre,
+             skip_prefix=case["skip_prefix"], window=w, max_len_extend=max(ext))
+    return c
+
+
+# ----------------------------------------------------------------------------------------------
 # G7: end-to-end model cases (2-layer Llama / Qwen2-shaped stacks).  build_model_case() returns the synthetic
 # "checkpoint" (half-precision or already-quantised tensors, exactly what a loader would hand to create_weights'
 # parameters), the prompts and a slot assignment; make_golden.py runs the reference's blocks over it.

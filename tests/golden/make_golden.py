@@ -455,6 +455,36 @@ def gen_model():
     print("model.npz", len(out), "arrays")
 
 
+def gen_extend_mask():
+    """Custom-mask / sliding-window extend attention from the reference's own Triton kernel (extend_attention.py:41-438) on the
+    CPU interpreter.  The module cannot be imported here (it pulls prefill_attention.py, which queries the GPU at import), so
+    the three definitions it needs -- tanh, _fwd_kernel, extend_attention_fwd -- are executed from its source text with the
+    module's platform switches set to the generic branch (64 x 64 tiles)."""
+    import ast
+
+    import triton
+    import triton.language as tl
+
+    path = os.path.join(_ref_import.REF_ROOT, "python/sglang/srt/layers/attention/triton_ops/extend_attention.py")
+    tree = ast.parse(open(path).read())
+    ns = {"torch": torch, "triton": triton, "tl": tl, "_is_hip": False, "_is_cuda": False, "CUDA_CAPABILITY": (0, 0)}
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in ("tanh", "_fwd_kernel", "extend_attention_fwd"):
+            exec(compile(ast.Module(body=[node], type_ignores=[]), path, "exec"), ns)
+    fwd = ns["extend_attention_fwd"]
+    out = {}
+    for case in _cases.MASK_CASES:
+        c = _cases.build_mask_case(case)
+        q = c["q"]
+        o = torch.zeros_like(q)
+        fwd(q, c["k_extend"], c["v_extend"], o, c["k_buffer"], c["v_buffer"], c["qo_indptr"], c["kv_indptr"], c["kv_indices"],
+            c["custom_mask"], True, c["mask_indptr"], c["max_len_extend"], c["scaling"], 0.0, c["skip_prefix"], c["window"])
+        assert torch.isfinite(o.float()).all()
+        out[case["name"]] = _cases.bits16(o[_cases.mask_rows(c)])
+        print(case["name"], tuple(o.shape), float(o.float().abs().max()))
+    np.savez_compressed(os.path.join(HERE, "extend_mask.npz"), **out)
+
+
 def gen_interface():
     """Interface snapshot: names, parameter order and defaults of the plugin surfaces this build mirrors,
     read from the reference's source with ``ast`` (signatures only -- data, no code), plus the two native attention op
@@ -558,7 +588,7 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     if what in ("attention", "all"):
         gen_attention()
-    for extra in ("index", "quant", "elementwise", "radix", "model", "interface"):
+    for extra in ("index", "quant", "elementwise", "radix", "model", "interface", "extend_mask"):
         fn = globals().get("gen_" + extra)
         if fn is not None and what in (extra, "all"):
             fn()

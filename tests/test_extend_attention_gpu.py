@@ -101,3 +101,196 @@ def test_extend_long_sequence_properties(pkg):
     loc0 = c["out_cache_loc"][0]
     v0 = c["v_buffer"][loc0].repeat_interleave(4, dim=0)  # [Hq, D]
     assert torch.equal(o[0], v0)
+
+
+# ---------------------------------------------------------------- a14: custom mask + sliding window (extend_attention.py:131-284)
+def _run_masked(c, dtype=None, logit_cap=0.0, mask_dtype=torch.bool):
+    from ltp_sglang_amd import sgl_kernel
+
+    dt = dtype or c["dtype"]
+    q = c["q"].to(dt).to(DEV)
+    o = torch.full(q.shape, float("nan"), dtype=dt, device=DEV)
+    new = c["out_cache_loc"]
+    kb, vb = c["k_buffer"].to(dt), c["v_buffer"].to(dt)
+    kb[new] = float("nan")   # new tokens come from k_extend / v_extend
+    vb[new] = float("nan")
+    cm = None if c["custom_mask"] is None else c["custom_mask"].to(mask_dtype).to(DEV)
+    mi = None if c["mask_indptr"] is None else c["mask_indptr"].to(DEV)
+    sgl_kernel.extend_attention_fwd(q, c["k_extend"].to(dt).to(DEV), c["v_extend"].to(dt).to(DEV), o, kb.to(DEV), vb.to(DEV),
+                                    c["qo_indptr"].to(DEV), c["kv_indptr"].to(DEV), c["kv_indices"].to(DEV), cm, True, mi,
+                                    c["max_len_extend"], c["scaling"], logit_cap, c["skip_prefix"], c["window"])
+    torch.cuda.synchronize()
+    return o.cpu()
+
+
+def _masked_f64(c, dtype=None, logit_cap=0.0):
+    dt = dtype or c["dtype"]
+    return oa.extend_attention_masked_f64(c["q"].to(dt), c["k_extend"].to(dt), c["v_extend"].to(dt), c["k_buffer"].to(dt),
+                                          c["v_buffer"].to(dt), c["qo_indptr"], c["kv_indptr"], c["kv_indices"], c["custom_mask"],
+                                          c["mask_indptr"], c["scaling"], True, c["skip_prefix"], c["window"], logit_cap)
+
+
+@pytest.mark.parametrize("case", _cases.MASK_CASES, ids=lambda c: c["name"])
+def test_masked_extend_matches_reference_triton_kernel(case, pkg, golden):
+    """HIP kernel (MASKED instantiation) against the outputs of the reference's own Triton kernel (interpreter, f16) and the
+    float64 restatement of its visibility rules; then the same problem in bf16 against the oracle."""
+    c = _cases.build_mask_case(case)
+    o = _run_masked(c)
+    assert torch.isfinite(o.float()).all()
+    rows = _cases.mask_rows(c)
+    gold = _cases.from_bits16(golden("extend_mask")[case["name"]], torch.float16)
+    assert (o[rows].double() - gold.double()).abs().max().item() <= TOL_GOLD[torch.float16]
+    assert (o.double() - _masked_f64(c)).abs().max().item() <= TOL_F64[torch.float16]
+    ob = _run_masked(c, torch.bfloat16, mask_dtype=torch.uint8)
+    assert (ob.double() - _masked_f64(c, torch.bfloat16)).abs().max().item() <= TOL_F64[torch.bfloat16]
+    oc = _run_masked(c, torch.bfloat16, logit_cap=20.0)
+    assert (oc.double() - _masked_f64(c, torch.bfloat16, 20.0)).abs().max().item() <= TOL_F64[torch.bfloat16]
+
+
+def test_all_ones_custom_mask_equals_plain_causal(pkg):
+    """The reference's own custom-mask test (test_triton_attention_kernels.py:36-181): a mask of [ones | lower triangle] must
+    reproduce the unmasked causal result -- here bit for bit (same arithmetic, other instantiation)."""
+    from ltp_sglang_amd import sgl_kernel
+
+    case = dict(name="ones", hq=12, hkv=4, d=128, pre=[130, 1, 77, 300], ext=[140, 200, 3, 64], mask=True, skip_prefix=False, window=-1)
+    c = _cases.build_mask_case(case)
+    blocks = []
+    for i in range(c["bs"]):
+        e, p = case["ext"][i], case["pre"][i]
+        blocks.append(torch.cat([torch.ones(e, p, dtype=torch.bool), torch.tril(torch.ones(e, e)) == 1], dim=1).flatten())
+    c["custom_mask"] = torch.cat(blocks)
+    masked = _run_masked(c, torch.bfloat16)
+    c["custom_mask"] = c["mask_indptr"] = None
+    plain = _run_masked(c, torch.bfloat16)
+    assert torch.equal(masked, plain)
+    c["skip_prefix"] = True
+    c["custom_mask"], c["mask_indptr"] = torch.cat(blocks), _cases.build_mask_case(case)["mask_indptr"]
+    assert torch.equal(_run_masked(c, torch.bfloat16), plain)
+
+
+def test_masked_extend_generic_head_dim(pkg):
+    """D = 80 (the reference test sweeps 128 / 96 / 80 / 13): the any-head-dim kernel with mask + window."""
+    case = dict(name="g80", hq=4, hkv=2, d=80, pre=[50, 9], ext=[20, 33], mask=True, skip_prefix=False, window=40)
+    c = _cases.build_mask_case(case)
+    o = _run_masked(c, torch.bfloat16)
+    assert (o.double() - _masked_f64(c, torch.bfloat16)).abs().max().item() <= TOL_F64[torch.bfloat16]
+
+
+def test_fully_masked_prefix_tile_is_finite(pkg):
+    """Where the reference's online softmax yields NaN (a row whose first prefix tile is entirely masked, e.g. extend rows
+    beyond 2 W under a sliding window), this build returns the softmax over the keys the row does see."""
+    case = dict(name="nan", hq=8, hkv=2, d=128, pre=[200], ext=[150], mask=False, skip_prefix=True, window=16)
+    c = _cases.build_mask_case(case)
+    o = _run_masked(c, torch.bfloat16)
+    assert torch.isfinite(o.float()).all()
+    assert (o.double() - _masked_f64(c, torch.bfloat16)).abs().max().item() <= TOL_F64[torch.bfloat16]
+
+
+# ---------------------------------------------------------------- a11: backend metadata for window layers and target-verify
+def _stub_backend(pkg, c, window=None, num_draft=None, max_ctx=None):
+    from types import SimpleNamespace
+
+    from ltp_sglang_amd.srt.layers.attention.hip_backend import HipAttnBackend
+    from ltp_sglang_amd.srt.mem_cache.memory_pool import MHATokenToKVPool
+
+    hq, hkv, d = c["hq"], c["hkv"], c["d"]
+    pool = MHATokenToKVPool(c["pool_size"], 1, c["dtype"], hkv, d, 1, DEV, False)
+    pool.k_buffer[0].copy_(c["k_buffer"].to(DEV))
+    pool.v_buffer[0].copy_(c["v_buffer"].to(DEV))
+    r2t = c["req_to_token"].to(DEV)
+    runner = SimpleNamespace(
+        device=DEV, gpu_id=0, req_to_token_pool=SimpleNamespace(size=r2t.shape[0], req_to_token=r2t), token_to_kv_pool=pool,
+        model_config=SimpleNamespace(num_attention_heads=hq, get_num_kv_heads=lambda tp: hkv, context_len=max_ctx or r2t.shape[1],
+                                     is_encoder_decoder=False),
+        sliding_window_size=window,
+        server_args=SimpleNamespace(triton_attention_num_kv_splits=8, speculative_num_draft_tokens=num_draft, speculative_num_steps=None))
+    return HipAttnBackend(runner), pool
+
+
+@pytest.mark.parametrize("graph_hooks", [False, True])
+def test_backend_sliding_window_decode_and_extend(graph_hooks, pkg):
+    """A sliding-window layer through HipAttnBackend: decode attends over the last W + 1 slots (update_sliding_window_buffer,
+    triton_backend.py:927-983; also through the four HIP-graph hooks), extend over the windowed prefix with the kernel's
+    window rule -- against the float64 oracle fed the same windowed indices."""
+    from ltp_sglang_amd.srt.layers.radix_attention import RadixAttention
+    from ltp_sglang_amd.srt.model_executor.forward_batch_info import ForwardBatch, ForwardMode
+
+    W = 48
+    case = dict(name="dec_win", kind="decode", dtype="bf16", hq=8, hkv=2, d=128, seq=[5, 49, 50, 200, 131])
+    c = _cases.build_attn_case(case)
+    backend, pool = _stub_backend(pkg, c, window=W)
+    layer = RadixAttention(c["hq"], c["d"], c["scaling"], c["hkv"], 0, sliding_window_size=W)
+    bs = c["bs"]
+    rpi, seq = c["req_pool_indices"].to(DEV), c["seq_lens"].to(DEV)
+    fb = ForwardBatch(forward_mode=ForwardMode.DECODE, batch_size=bs, input_ids=torch.zeros(bs, dtype=torch.int64, device=DEV),
+                      req_pool_indices=rpi, seq_lens=seq, out_cache_loc=c["out_cache_loc"].to(DEV), seq_lens_sum=int(c["seq_lens"].sum()),
+                      token_to_kv_pool=pool, attn_backend=backend)
+    if graph_hooks:
+        backend.init_cuda_graph_state(bs, bs)
+        backend.init_forward_metadata_capture_cuda_graph(bs, bs, rpi, torch.ones_like(seq), None, ForwardMode.DECODE, None)
+        backend.init_forward_metadata_replay_cuda_graph(bs, rpi, seq, int(c["seq_lens"].sum()), None, ForwardMode.DECODE, None, None)
+    else:
+        backend.init_forward_metadata(fb)
+    q = c["q"].reshape(bs, -1).to(DEV)
+    new = c["out_cache_loc"]
+    o = backend.forward(q, c["k_buffer"][new].to(DEV), c["v_buffer"][new].to(DEV), layer, fb, save_kv_cache=True)
+    wl = torch.clamp(c["seq_lens"], max=W + 1)
+    win_r2t = torch.zeros_like(c["req_to_token"])
+    for i in range(bs):
+        n, k = int(c["seq_lens"][i]), int(wl[i])
+        win_r2t[c["req_pool_indices"][i], :k] = c["req_to_token"][c["req_pool_indices"][i], n - k:n]
+    ref = oa.decode_attention_f64(c["q"], c["k_buffer"], c["v_buffer"], win_r2t, c["req_pool_indices"], wl, c["scaling"])
+    assert (o.view(bs, c["hq"], c["d"]).cpu().double() - ref).abs().max().item() <= TOL_F64[torch.bfloat16]
+    # a full-attention layer on the same backend still sees every token
+    full = RadixAttention(c["hq"], c["d"], c["scaling"], c["hkv"], 0)
+    o2 = backend.forward(q, None, None, full, fb, save_kv_cache=False)
+    ref2 = oa.decode_attention_f64(c["q"], c["k_buffer"], c["v_buffer"], c["req_to_token"], c["req_pool_indices"], c["seq_lens"], c["scaling"])
+    assert (o2.view(bs, c["hq"], c["d"]).cpu().double() - ref2).abs().max().item() <= TOL_F64[torch.bfloat16]
+    if graph_hooks:
+        return
+    # extend: windowed prefix + the kernel's window rule
+    mcase = dict(name="ext_win", hq=8, hkv=2, d=128, pre=[150, 20, 64], ext=[40, 30, 1], mask=False, skip_prefix=True, window=W)
+    m = _cases.build_mask_case(mcase)
+    backend, pool = _stub_backend(pkg, m, window=W)
+    bs = m["bs"]
+    fb = ForwardBatch.init_new(ForwardMode.EXTEND, m["req_pool_indices"].to(DEV), m["seq_lens"].to(DEV), m["out_cache_loc"].to(DEV),
+                               torch.zeros(int(m["qo_indptr"][-1]), dtype=torch.int64, device=DEV),
+                               None, pool, backend, extend_prefix_lens=m["extend_prefix_lens"].to(DEV),
+                               extend_seq_lens=m["extend_seq_lens"].to(DEV), seq_lens_cpu=m["seq_lens"])
+    backend.init_forward_metadata(fb)
+    md = backend.forward_metadata
+    assert torch.equal(md.window_kv_indptr.cpu(), m["kv_indptr"]) and torch.equal(md.window_kv_indices[: m["kv_indices"].numel()].cpu(), m["kv_indices"])
+    t = int(m["qo_indptr"][-1])
+    o = backend.forward(m["q"].reshape(t, -1).to(DEV), m["k_extend"].to(DEV), m["v_extend"].to(DEV), layer, fb, save_kv_cache=False)
+    ref = _masked_f64(m)
+    assert (o.view(t, m["hq"], m["d"]).cpu().double() - ref).abs().max().item() <= TOL_F64[torch.float16]
+
+
+def test_backend_target_verify_custom_mask(pkg):
+    """ForwardMode.TARGET_VERIFY through HipAttnBackend (triton_backend.py:224-258): qo_indptr in steps of num_draft_tokens,
+    kv over the whole cached sequence, mask_indptr = cumsum(n * (seq_len + n)), spec_info.custom_mask handed to the kernel
+    (prefix part skipped: the reference calls extend_attention_fwd with its default skip_prefix_custom_mask = True)."""
+    from types import SimpleNamespace
+
+    from ltp_sglang_amd.srt.layers.radix_attention import RadixAttention
+    from ltp_sglang_amd.srt.model_executor.forward_batch_info import ForwardBatch, ForwardMode
+
+    n = 8
+    mcase = dict(name="verify", hq=8, hkv=2, d=128, pre=[70, 33, 129], ext=[n, n, n], mask=True, skip_prefix=True, window=-1)
+    m = _cases.build_mask_case(mcase)
+    backend, pool = _stub_backend(pkg, m, num_draft=n)
+    bs = m["bs"]
+    pre = m["extend_prefix_lens"].long()
+    # in verify mode forward_batch.seq_lens are the CACHED lengths; the draft tokens' K/V are passed as k / v
+    fb = ForwardBatch(forward_mode=ForwardMode.TARGET_VERIFY, batch_size=bs, input_ids=torch.zeros(bs * n, dtype=torch.int64, device=DEV),
+                      req_pool_indices=m["req_pool_indices"].to(DEV), seq_lens=pre.to(DEV), out_cache_loc=m["out_cache_loc"].to(DEV),
+                      seq_lens_sum=int(pre.sum()), token_to_kv_pool=pool, attn_backend=backend,
+                      spec_info=SimpleNamespace(custom_mask=m["custom_mask"].to(DEV)))
+    backend.init_forward_metadata(fb)
+    md = backend.forward_metadata
+    assert md.qo_indptr.tolist() == [0, n, 2 * n, 3 * n] and md.max_extend_len == n
+    assert torch.equal(md.mask_indptr.cpu(), m["mask_indptr"]) and torch.equal(md.kv_indices.cpu(), m["kv_indices"])
+    layer = RadixAttention(m["hq"], m["d"], m["scaling"], m["hkv"], 0)
+    o = backend.forward(m["q"].reshape(bs * n, -1).to(DEV), m["k_extend"].to(DEV), m["v_extend"].to(DEV), layer, fb, save_kv_cache=False)
+    ref = _masked_f64(m)
+    assert (o.view(bs * n, m["hq"], m["d"]).cpu().double() - ref).abs().max().item() <= TOL_F64[torch.float16]

@@ -47,3 +47,17 @@ def test_f64_twin_agrees_with_sdpa(case):
     b = _run_f64(case, c)
     tol = 3e-2 if c["dtype"] == torch.bfloat16 else 4e-3
     assert (a - b).abs().max().item() < tol
+
+
+@pytest.mark.parametrize("case", _cases.MASK_CASES, ids=lambda c: c["name"])
+def test_masked_extend_oracle_matches_reference_triton_kernel(case, golden):
+    """custom mask / sliding window: the oracle's restatement of the Triton kernel's visibility rules against the outputs of
+    the reference kernel itself (run on the CPU interpreter in f16 by make_golden.py::gen_extend_mask)."""
+    c = _cases.build_mask_case(case)
+    ref = oa.extend_attention_masked_f64(c["q"], c["k_extend"], c["v_extend"], c["k_buffer"], c["v_buffer"], c["qo_indptr"],
+                                         c["kv_indptr"], c["kv_indices"], c["custom_mask"], c["mask_indptr"], c["scaling"], True,
+                                         c["skip_prefix"], c["window"])
+    gold = _cases.from_bits16(golden("extend_mask")[case["name"]], torch.float16).double()
+    rows = _cases.mask_rows(c)
+    assert gold.shape[0] == rows.numel()
+    assert (ref[rows] - gold).abs().max().item() <= 3e-3   # f16 kernel vs exact arithmetic
