@@ -76,6 +76,23 @@ int sgl_mi355_decode_attention_merge_quant(const void* q, int64_t q_stride_t, co
 int sgl_mi355_merge_state(const void* v_a, const float* s_a, const void* v_b, const float* s_b, void* v_merged, float* s_merged,
                           int64_t num_tokens, int num_heads, int head_size, int dtype, void* stream);
 
+/* Cascade shared-prefix decode ("shared-prefix once, unique-suffix per request"): every request of the batch
+ * shares its first prefix_len KV slots -- one RadixCache node (python/sglang/srt/mem_cache/radix_cache.py:370-412).  The
+ * prefix rows are attended once for the query heads of ALL requests (they become extra MFMA columns), each request's private
+ * suffix (kv_indptr / kv_indices over the slots AFTER the prefix) separately, and the two partial states are combined by
+ * their log-sum-exp inside the second launch -- the math of merge_state / merge_state_v2
+ * (sgl-kernel/csrc/attention/merge_attn_states.cu, python/sgl_kernel/attention.py:12-52).  Outputs as
+ * sgl_mi355_decode_attention_merge_quant.  attn_logits / attn_lse: max_kv_splits slots per (request, head), of which the
+ * first prefix_splits belong to the prefix.  merge_counters: int32 [batch], zero on entry, left zero. */
+int sgl_mi355_decode_attention_cascade(const void* q, int64_t q_stride_t, const void* k_buffer, const void* v_buffer,
+                                       int64_t k_stride_t, int64_t k_stride_h, int64_t v_stride_t, int64_t v_stride_h,
+                                       const int32_t* prefix_indices, int prefix_len, int prefix_splits,
+                                       const int32_t* kv_indptr, const int32_t* kv_indices, float* attn_logits,
+                                       float* attn_lse, const int32_t* num_kv_splits, int max_kv_splits, int batch,
+                                       int num_q_heads, int num_kv_heads, int head_dim, int v_head_dim, float sm_scale,
+                                       float logit_cap, int dtype, int kv_dtype, float k_scale, float v_scale,
+                                       int32_t* merge_counters, void* out_o, void* out_q, float* out_s, void* stream);
+
 /* Measurement hook: 1 (default) = every wave owns one (request, kv head, split) unit; 0 = the first design, a
  * 4-wave workgroup sharing one split with an LDS merge. */
 int sgl_mi355_decode_attention_set_mode(int mode);

@@ -57,6 +57,17 @@ struct DecodeParams {
   void* mq_o;          // optional T [bs, Hq * Dv]
   void* mq_q;          // optional e4m3 [bs, Hq * Dv] with mq_s f32 [bs]
   float* mq_s;
+  // Cascade shared-prefix decode (the LSE merge is merge_attn_states.cu's): all `bs` requests share the first
+  // prefix_len slots of their sequences.
+  //   prefix pass  (shared_reqs = bs > 0): ONE virtual request whose GQA group of kv head kh is the bs * group query heads
+  //                {(request r, head kh * group + j)}: every K/V row of the prefix is read once per (kv head, 16-column chunk,
+  //                split) for ALL requests -- the extra requests are extra MFMA columns.  Keys = kv_indices[0, prefix_len),
+  //                prefix_splits splits, partials go to split slots [0, prefix_splits) of each request.
+  //   suffix pass  (split_base = prefix_splits): the ordinary kernel over every request's private slots; its partials go to
+  //                slots [split_base, split_base + num_kv_splits[b]) and the in-launch merge combines prefix + suffix slots.
+  int shared_reqs;
+  int prefix_len, prefix_splits;
+  int split_base;
 };
 
 constexpr int kTile = 32;  // tokens per wave tile == reference _MIN_BLOCK_KV (decode_attention.py:35)
@@ -93,7 +104,7 @@ __device__ __forceinline__ float softcap_log2(float s_scaled, float cap) {
 // last ticket acquires (agent scope: ONE cache invalidate per request), merges all splits of the request, rounds, optionally
 // quantises per token (the op sequence stage 2 -> sgl_per_token_quant_fp8) and puts the counter back to zero.  Correct for
 // any placement of the request's workgroups over CUs / XCDs; workgroup-scope fences or an L1-only invalidate would not be.
-template <typename T>
+template <typename T, bool CASC = false>
 __device__ __forceinline__ void arrive_and_merge(const DecodeParams& p, int b, int seq_len, int nsplit, int hchunks, char* smem) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -112,9 +123,11 @@ __device__ __forceinline__ void arrive_and_merge(const DecodeParams& p, int b, i
   __syncthreads();
   float* red = (float*)smem + 4;
   if (p.hq * p.dv <= 256 * 8 * 4)
-    merge_quant_row<T, 4>(b, p.attn_logits, p.attn_lse, seq_len, nsplit, p.max_kv_splits, p.hq, p.dv, (T*)p.mq_o, (uint8_t*)p.mq_q, p.mq_s, red);
+    merge_quant_row<T, 4>(b, p.attn_logits, p.attn_lse, seq_len, nsplit, p.max_kv_splits, p.hq, p.dv, (T*)p.mq_o, (uint8_t*)p.mq_q, p.mq_s, red,
+                          CASC ? p.prefix_len : 0, CASC ? p.split_base : 0);
   else
-    merge_quant_row<T, 8>(b, p.attn_logits, p.attn_lse, seq_len, nsplit, p.max_kv_splits, p.hq, p.dv, (T*)p.mq_o, (uint8_t*)p.mq_q, p.mq_s, red);
+    merge_quant_row<T, 8>(b, p.attn_logits, p.attn_lse, seq_len, nsplit, p.max_kv_splits, p.hq, p.dv, (T*)p.mq_o, (uint8_t*)p.mq_q, p.mq_s, red,
+                          CASC ? p.prefix_len : 0, CASC ? p.split_base : 0);
   if (threadIdx.x == 0) __hip_atomic_store(p.merge_cnt + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -140,7 +153,9 @@ __device__ __forceinline__ void cvt16_fp8(const u32x4_t& in, u32x4_t& lo, u32x4_
 //         units of one request with the kv head fastest, so they read ADJACENT 256-byte pieces of the same token rows
 //         at about the same time (whole 2-KiB token rows per workgroup instead of scattered 256-byte pieces) and no
 //         barrier or cross-wave merge exists at all.
-template <typename T, int D, int NW, int MODE, int KVB = 2>  // KVB: bytes per pool element (1 = e4m3 KV cache, converted on the way into LDS)
+// KVB: bytes per pool element (1 = e4m3 KV cache, converted on the way into LDS).  CASC: the cascade (shared-prefix) forms of
+// MODE 0 -- their extra index arithmetic stays out of the ordinary instantiation (it cost 28 spilled SGPRs there).
+template <typename T, int D, int NW, int MODE, int KVB = 2, bool CASC = false>
 __global__ __launch_bounds__(NW * 64, 2) void decode_attn_stage1(const DecodeParams p) {
   using Tr = ElemTraits<T>;
   using vec8 = typename Tr::vec8;
@@ -164,7 +179,10 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attn_stage1(const DecodePar
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int hchunks = (p.group + 15) >> 4;
+  const bool shared = CASC && p.shared_reqs > 0;                  // cascade prefix pass (wave-uniform)
+  const int split_base = CASC ? p.split_base : 0;
+  const int vgroup = shared ? p.shared_reqs * p.group : p.group;  // query columns that share one kv head's K/V rows
+  const int hchunks = (vgroup + 15) >> 4;
   int khc, split;
   if constexpr (MODE == 0) {
     khc = blockIdx.x;
@@ -177,21 +195,30 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attn_stage1(const DecodePar
   const int kh = khc / hchunks;
   const int hc = khc - kh * hchunks;
   const int b = blockIdx.y;
-  const int h0 = kh * p.group + hc * 16;
-  const int nh = min(16, p.group - hc * 16);
+  const int nh = min(16, vgroup - hc * 16);
+  // column v = hc * 16 + a of this kv head -> (request row, q head); identity for an ordinary launch
+  auto col_req = [&](int v) -> int { return shared ? v / p.group : b; };
+  auto col_head = [&](int v) -> int { return kh * p.group + (shared ? v % p.group : v); };
 
   const int32_t* idx_row;
   int seq_len;
-  request_range(p, b, idx_row, seq_len);
-  int nsplit = p.num_kv_splits[b];
-  nsplit = max(1, min(nsplit, p.max_kv_splits));
+  int nsplit;
+  if (shared) {
+    idx_row = p.kv_indices;
+    seq_len = p.prefix_len;
+    nsplit = p.prefix_splits;
+  } else {
+    request_range(p, b, idx_row, seq_len);
+    nsplit = p.num_kv_splits[b];
+  }
+  nsplit = max(1, min(nsplit, p.max_kv_splits - split_base));
   if (split >= nsplit) return;  // MODE 1: a whole-wave exit; the kernel has no barrier in that mode
   const int per = split_len(seq_len, nsplit);
   const int start = split * per;
   const int end = min(start + per, seq_len);
   if (start >= end) {
     if constexpr (MODE == 0) {  // an empty split still counts as arrived for the in-launch merge (uniform per workgroup)
-      if (p.merge_cnt) arrive_and_merge<T>(p, b, seq_len, nsplit, hchunks, smem);
+      if (p.merge_cnt) arrive_and_merge<T, CASC>(p, b, seq_len, nsplit, hchunks, smem);
     }
     return;
   }
@@ -207,7 +234,8 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attn_stage1(const DecodePar
   // Q fragments: B operand of S^T = K Q^T, lane (a,g) holds Q[h0+a][32*ks + 8*g .. +8]
   vec8 qf[KS];
   {
-    const T* qrow = (const T*)p.q + (int64_t)b * p.q_stride_t + (int64_t)(h0 + a) * D;
+    const int va = hc * 16 + min(a, nh - 1);
+    const T* qrow = (const T*)p.q + (int64_t)col_req(va) * p.q_stride_t + (int64_t)col_head(va) * D;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       if (a < nh) {
@@ -369,7 +397,7 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attn_stage1(const DecodePar
   if constexpr (MODE == 1) {
     // the wave IS the split: write acc / l and m + log(l) straight from the accumulator layout
     if (a < nh) {
-      const int64_t slot = ((int64_t)b * p.hq + (h0 + a)) * p.max_kv_splits + split;
+      const int64_t slot = ((int64_t)b * p.hq + (kh * p.group + hc * 16 + a)) * p.max_kv_splits + split;
       const float inv = p.v_scale / l_i;
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
@@ -407,7 +435,8 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attn_stage1(const DecodePar
       L += red_l[ww * 16 + h] * sc;
       val += red_acc[(ww * 16 + h) * D + d] * sc;
     }
-    const int64_t slot = ((int64_t)b * p.hq + (h0 + h)) * p.max_kv_splits + split;
+    const int vh = hc * 16 + h;
+    const int64_t slot = ((int64_t)col_req(vh) * p.hq + col_head(vh)) * p.max_kv_splits + split_base + split;
     const float ov = val / L * p.v_scale, lv = M * kLn2 + __logf(L);
     if (p.merge_cnt) {  // in-launch merge: the partial is PUBLISHED -- write-through (sc1) stores, no release fence needed
       __hip_atomic_store(p.attn_logits + slot * D + d, ov, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -417,7 +446,7 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attn_stage1(const DecodePar
       if (d == 0) p.attn_lse[slot] = lv;
     }
   }
-  if (p.merge_cnt) arrive_and_merge<T>(p, b, seq_len, nsplit, hchunks, smem);
+  if (p.merge_cnt) arrive_and_merge<T, CASC>(p, b, seq_len, nsplit, hchunks, smem);
 }
 
 // Any-head-dim fallback (D, Dv <= 256, not multiples of 32 allowed): one wave per
@@ -515,8 +544,18 @@ int g_decode_mode = 0;  // 0 = workgroup-shared split (default: faster at batch 
 
 template <typename T, int D, int KVB>
 int launch_mfma(const DecodeParams& p, hipStream_t st) {
-  const int hchunks = (p.group + 15) / 16;
-  if (g_decode_mode == 0) {
+  const int hchunks = ((p.shared_reqs > 0 ? p.shared_reqs * p.group : p.group) + 15) / 16;
+  if (p.shared_reqs > 0 || p.split_base > 0) {   // cascade passes: MODE 0 only (checked by the entry point)
+    constexpr int NW = 4;
+    constexpr int smem = NW * 2 * kTile * D * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)decode_attn_stage1<T, D, NW, 0, KVB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+      attr_set = true;
+    }
+    dim3 grid(p.hkv * hchunks, p.bs, p.shared_reqs > 0 ? p.prefix_splits : p.max_kv_splits - p.split_base);
+    hipLaunchKernelGGL((decode_attn_stage1<T, D, NW, 0, KVB, true>), grid, dim3(NW * 64), smem, st, p);
+  } else if (g_decode_mode == 0) {
     constexpr int NW = 4;
     constexpr int smem = NW * 2 * kTile * D * 2;
     static bool attr_set = false;
@@ -578,7 +617,7 @@ static int decode_entry(
     const int64_t* seq_lens, float* attn_logits, float* attn_lse, const int32_t* num_kv_splits, int max_kv_splits,
     int batch, int num_q_heads, int num_kv_heads, int head_dim, int v_head_dim, float sm_scale, float logit_cap,
     int dtype, int kv_dtype, float k_scale, float v_scale, int32_t* merge_cnt, void* mq_o, void* mq_q, float* mq_s,
-    void* stream) {
+    void* stream, int shared_reqs = 0, int prefix_len = 0, int prefix_splits = 0, int split_base = 0) {
   SGL_CHECK(batch >= 0, "decode_attention: negative batch %d", batch);
   if (batch == 0) return SGL_MI355_OK;
   SGL_CHECK(q && k_buffer && v_buffer, "decode_attention: null tensor pointer");  // o == NULL: split partials only
@@ -619,6 +658,18 @@ static int decode_entry(
   p.kv_fp8 = kv8 ? 1 : 0;
   p.k_scale = kv8 ? k_scale : 1.0f; p.v_scale = kv8 ? v_scale : 1.0f;
   p.merge_cnt = merge_cnt; p.mq_o = mq_o; p.mq_q = mq_q; p.mq_s = mq_s;
+  p.shared_reqs = shared_reqs; p.prefix_len = prefix_len; p.prefix_splits = prefix_splits; p.split_base = split_base;
+  if (shared_reqs > 0 || split_base > 0) {
+    SGL_CHECK(head_dim == v_head_dim && (head_dim == 128 || head_dim == 64) && g_decode_mode == 0,
+              "decode_attention_cascade: needs the MFMA kernel (head_dim 64 / 128) in its workgroup-per-split mode");
+    SGL_CHECK(prefix_len > 0 && prefix_splits >= 1 && prefix_splits < max_kv_splits,
+              "decode_attention_cascade: prefix_len=%d, prefix_splits=%d must be positive and leave split slots for the suffix (max_kv_splits=%d)",
+              prefix_len, prefix_splits, max_kv_splits);
+  }
+  if (shared_reqs > 0) {   // prefix pass: one virtual request, grid.y = 1
+    p.bs = 1;
+    p.kv_indptr = nullptr;   // (the range is [0, prefix_len) of kv_indices)
+  }
   if (merge_cnt != nullptr) {
     SGL_CHECK(head_dim == v_head_dim && (head_dim == 128 || head_dim == 64) && g_decode_mode == 0,
               "decode_attention_merge_quant: needs the MFMA kernel (head_dim 64 / 128) in its workgroup-per-split mode");
@@ -656,4 +707,32 @@ extern "C" int sgl_mi355_decode_attention_merge_quant(
                       kv_indices, nullptr, 0, nullptr, nullptr, attn_logits, attn_lse, num_kv_splits, max_kv_splits, batch,
                       num_q_heads, num_kv_heads, head_dim, v_head_dim, sm_scale, logit_cap, dtype, kv_dtype, k_scale, v_scale,
                       merge_counters, out_o, out_q, out_s, stream);
+}
+
+// Cascade shared-prefix decode: every request of the batch shares its first prefix_len slots (one radix-tree
+// node, radix_cache.py:370-412).  Two launches: (1) the prefix is attended ONCE per (kv head, 16-column chunk, split) for the
+// query heads of ALL requests (prefix_indices int32 [prefix_len], prefix_splits splits); (2) every request's private suffix
+// (kv_indptr / kv_indices over the slots after the prefix, num_kv_splits[b] splits) with the in-launch stage 2 merging prefix
+// + suffix partials by their log-sum-exp -- the math of merge_state (sgl-kernel/csrc/attention/merge_attn_states.cu) -- into
+// out_o (T, optional) and / or the per-token fp8 row out_q / out_s (optional).  attn_logits / attn_lse hold max_kv_splits
+// split slots per (request, head): prefix_splits + max(num_kv_splits) <= max_kv_splits.  merge_counters: int32 [batch], zero
+// on entry, left zero.
+extern "C" int sgl_mi355_decode_attention_cascade(
+    const void* q, int64_t q_stride_t, const void* k_buffer, const void* v_buffer, int64_t k_stride_t,
+    int64_t k_stride_h, int64_t v_stride_t, int64_t v_stride_h, const int32_t* prefix_indices, int prefix_len,
+    int prefix_splits, const int32_t* kv_indptr, const int32_t* kv_indices, float* attn_logits, float* attn_lse,
+    const int32_t* num_kv_splits, int max_kv_splits, int batch, int num_q_heads, int num_kv_heads, int head_dim,
+    int v_head_dim, float sm_scale, float logit_cap, int dtype, int kv_dtype, float k_scale, float v_scale,
+    int32_t* merge_counters, void* out_o, void* out_q, float* out_s, void* stream) {
+  SGL_CHECK(merge_counters != nullptr && kv_indptr != nullptr && prefix_indices != nullptr, "decode_attention_cascade: null pointer");
+  if (batch == 0) return SGL_MI355_OK;
+  int rc = decode_entry(q, q_stride_t, k_buffer, v_buffer, k_stride_t, k_stride_h, v_stride_t, v_stride_h, nullptr, 0, kv_indptr,
+                        prefix_indices, nullptr, 0, nullptr, nullptr, attn_logits, attn_lse, num_kv_splits, max_kv_splits, batch,
+                        num_q_heads, num_kv_heads, head_dim, v_head_dim, sm_scale, logit_cap, dtype, kv_dtype, k_scale, v_scale,
+                        nullptr, nullptr, nullptr, nullptr, stream, batch, prefix_len, prefix_splits, 0);
+  if (rc != SGL_MI355_OK) return rc;
+  return decode_entry(q, q_stride_t, k_buffer, v_buffer, k_stride_t, k_stride_h, v_stride_t, v_stride_h, nullptr, 0, kv_indptr,
+                      kv_indices, nullptr, 0, nullptr, nullptr, attn_logits, attn_lse, num_kv_splits, max_kv_splits, batch,
+                      num_q_heads, num_kv_heads, head_dim, v_head_dim, sm_scale, logit_cap, dtype, kv_dtype, k_scale, v_scale,
+                      merge_counters, out_o, out_q, out_s, stream, 0, prefix_len, prefix_splits, prefix_splits);
 }

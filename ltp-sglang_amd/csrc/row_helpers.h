@@ -89,9 +89,16 @@ __device__ __forceinline__ void quant_row(const float (&vals)[MAXV][8], int nvec
 template <typename T, int MAXV>
 __device__ __forceinline__ void merge_quant_row(int b, const float* attn_logits, const float* attn_lse, int seq_len, int nsplit,
                                                 int max_kv_splits, int hq, int dv, T* out_o, uint8_t* out_q, float* out_s,
-                                                float* red) {
+                                                float* red, int pre_len = 0, int pre_splits = 0) {
+  // cascade (shared-prefix) decode: split slots [0, pre_splits) hold the partials of the shared prefix (pre_len keys, its own
+  // split length), slots [pre_splits, pre_splits + nsplit) those of the request's private suffix (seq_len keys)
   const int per0 = (seq_len + nsplit - 1) / nsplit;
   const int per = (per0 + 31) / 32 * 32;
+  const int pper = pre_splits > 0 ? ((pre_len + pre_splits - 1) / pre_splits + 31) / 32 * 32 : 0;
+  const int total = pre_splits + nsplit;
+  auto live = [&](int sI) -> bool {
+    return sI < pre_splits ? sI * pper < pre_len : (sI < total && (sI - pre_splits) * per < seq_len);
+  };
   const int row_elems = hq * dv, nvec = row_elems / 8;
   float vals[MAXV][8];
 #pragma unroll
@@ -112,7 +119,7 @@ __device__ __forceinline__ void merge_quant_row(int b, const float* attn_logits,
       f32x4_t a0_pf[PF], a1_pf[PF];
 #pragma unroll
       for (int sI = 0; sI < PF; ++sI) {
-        const int sc = sI < nsplit ? sI : 0;  // clamped: a split that does not exist re-reads split 0 (never used)
+        const int sc = sI < total ? sI : 0;  // clamped: a split that does not exist re-reads split 0 (never used)
         lse_pf[sI] = attn_lse[slot0 + sc];
         const float* lp = attn_logits + (slot0 + sc) * dv + d0;
         a0_pf[sI] = *(const f32x4_t*)lp;
@@ -120,7 +127,7 @@ __device__ __forceinline__ void merge_quant_row(int b, const float* attn_logits,
       }
 #pragma unroll
       for (int sI = 0; sI < PF; ++sI) {
-        if (sI < nsplit && sI * per < seq_len) {
+        if (live(sI)) {
           mg.begin(lse_pf[sI]);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -129,8 +136,8 @@ __device__ __forceinline__ void merge_quant_row(int b, const float* attn_logits,
           }
         }
       }
-      for (int sI = PF; sI < nsplit; ++sI) {
-        if (sI * per < seq_len) {
+      for (int sI = PF; sI < total; ++sI) {
+        if (live(sI)) {
           mg.begin(attn_lse[slot0 + sI]);
           const float* lp = attn_logits + (slot0 + sI) * dv + d0;
           const f32x4_t a0 = *(const f32x4_t*)lp, a1 = *(const f32x4_t*)(lp + 4);

@@ -4,7 +4,7 @@ Export list follows sgl-kernel/python/sgl_kernel/__init__.py:12-96 restricted to
 the path, plus the attention and KV-index ops the reference only has as
 Triton / CPU kernels.
 """
-from .attention import (decode_attention, decode_attention_fwd, decode_attention_merge_quant, extend_attention,
+from .attention import (decode_attention, decode_attention_cascade, decode_attention_fwd, decode_attention_merge_quant, extend_attention,
                         extend_attention_fwd, merge_state, merge_state_v2)
 from .elementwise import (
     apply_rope_with_cos_sin_cache_inplace,

@@ -209,6 +209,33 @@ def decode_attention_merge_quant(q, k_buffer, v_buffer, kv_indptr, kv_indices, a
     return o, oq, osc
 
 
+def decode_attention_cascade(q, k_buffer, v_buffer, prefix_indices, prefix_splits, kv_indptr, kv_indices, attn_logits, attn_lse,
+                             num_kv_splits, max_kv_splits, sm_scale, merge_counters, logit_cap=0.0, k_scale=1.0, v_scale=1.0,
+                             want_o=True, want_quant=False):
+    """Shared-prefix ("cascade") decode: all requests of the batch share the KV slots ``prefix_indices`` (int32 [P], one radix
+    node); ``kv_indptr`` / ``kv_indices`` cover each request's private slots after the prefix.  The prefix is read once for all
+    requests' heads, the suffixes per request, and the two partial states are merged by LSE (``merge_state`` math) inside the
+    second launch.  Same result as decode_attention_fwd over the full sequences, up to the order of the softmax sums.
+    Returns (o or None, o_q or None, o_scale or None) like decode_attention_merge_quant."""
+    _require_cuda(q, k_buffer, v_buffer, prefix_indices, kv_indptr, kv_indices, attn_logits, attn_lse, num_kv_splits, merge_counters)
+    bs, hq, d = q.shape
+    hkv, dv = v_buffer.shape[1], v_buffer.shape[2]
+    assert prefix_indices.dtype == torch.int32 and prefix_indices.is_contiguous()
+    assert merge_counters.dtype == torch.int32 and merge_counters.numel() >= bs and max_kv_splits == attn_logits.shape[2]
+    assert q.stride(2) == 1 and q.stride(1) == d and attn_logits.is_contiguous() and attn_lse.is_contiguous()
+    kst, ksh = _row_strides(k_buffer)
+    vst, vsh = _row_strides(v_buffer)
+    o = torch.empty((bs, hq * dv), dtype=q.dtype, device=q.device) if want_o else None
+    oq = torch.empty((bs, hq * dv), dtype=torch.float8_e4m3fn, device=q.device) if want_quant else None
+    osc = torch.empty((bs, 1), dtype=torch.float32, device=q.device) if want_quant else None
+    check(lib.sgl_mi355_decode_attention_cascade(
+        ptr(q), q.stride(0), ptr(k_buffer), ptr(v_buffer), kst, ksh, vst, vsh, ptr(prefix_indices), int(prefix_indices.numel()),
+        int(prefix_splits), ptr(kv_indptr), ptr(kv_indices), ptr(attn_logits), ptr(attn_lse), ptr(num_kv_splits), int(max_kv_splits),
+        bs, hq, hkv, d, dv, float(sm_scale), float(logit_cap), dtype_code(q.dtype), dtype_code(k_buffer.dtype), float(k_scale),
+        float(v_scale), ptr(merge_counters), ptr(o), ptr(oq), ptr(osc), current_stream()))
+    return o, oq, osc
+
+
 def merge_state(v_a: torch.Tensor, s_a: torch.Tensor, v_b: torch.Tensor, s_b: torch.Tensor,
                 v_merged: Optional[torch.Tensor] = None, s_merged: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """LSE-weighted merge of two attention partials (sgl_kernel.merge_state, attention.py:12-28): v [n, h, d], s [n, h]."""

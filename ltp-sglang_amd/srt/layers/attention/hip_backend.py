@@ -33,6 +33,10 @@ class ForwardMetadata:
     window_kv_indptr: Optional[torch.Tensor] = None
     window_kv_indices: Optional[torch.Tensor] = None
     window_num_kv_splits: Optional[torch.Tensor] = None
+    # cascade shared-prefix decode: every request's first len(cascade_prefix_indices) slots are these (one radix node);
+    # kv_indptr / kv_indices / num_kv_splits then describe the private suffixes only
+    cascade_prefix_indices: Optional[torch.Tensor] = None
+    cascade_prefix_splits: int = 0
 
 
 def _rows(t):
@@ -117,6 +121,32 @@ class HipAttnBackend(AttentionBackend):
             md.window_kv_indptr, md.window_kv_indices, md.window_num_kv_splits = self._window_metadata(
                 bs, req_pool_indices, seq_lens, True, wi, ws)
         return md
+
+    def init_forward_metadata_cascade(self, forward_batch, shared_prefix_len: int, prefix_splits: Optional[int] = None):
+        """Decode metadata for a batch whose requests all share their first ``shared_prefix_len`` KV slots (they matched the
+        same RadixCache node, radix_cache.py:370-412; the scheduler knows the length from match_prefix).  The shared rows are
+        then streamed once per kv head for the whole batch instead of once per request.  Falls back to the
+        ordinary metadata when the prefix is too short to pay for the second launch."""
+        bs = forward_batch.batch_size
+        group = self.num_head // self.num_kv_head
+        if not forward_batch.forward_mode.is_decode() or shared_prefix_len < 64 or bs < 2 or self.v_head_dim not in (64, 128):
+            return self.init_forward_metadata(forward_batch)
+        chunks = self.num_kv_head * ((bs * group + 15) // 16)
+        if prefix_splits is None:   # about one round of resident workgroups (2 per CU), at least 64 keys per split
+            prefix_splits = max(1, min(2 * self.device_core_count // max(chunks, 1), shared_prefix_len // 64, self.max_kv_splits // 2))
+        suffix_lens = forward_batch.seq_lens - shared_prefix_len
+        kv_indptr = self.kv_indptr[: bs + 1]
+        num_kv_splits = torch.empty((bs,), dtype=torch.int32, device=self.device)
+        K.decode_metadata(kv_indptr, num_kv_splits, suffix_lens, 1, self.num_head, self.num_kv_head,
+                          self.max_kv_splits - prefix_splits, self.device_core_count, self.static_kv_splits)
+        kv_indices = torch.empty(max(int(forward_batch.seq_lens_sum) - bs * shared_prefix_len, 1), dtype=torch.int32, device=self.device)
+        K.create_kv_indices(self.req_to_token, forward_batch.req_pool_indices, suffix_lens, kv_indptr,
+                            torch.full_like(suffix_lens, shared_prefix_len), kv_indices)
+        attn_logits = torch.empty((bs, self.num_head, self.max_kv_splits, self.v_head_dim), dtype=torch.float32, device=self.device)
+        attn_lse = torch.empty((bs, self.num_head, self.max_kv_splits), dtype=torch.float32, device=self.device)
+        prefix = self.req_to_token[forward_batch.req_pool_indices[0], :shared_prefix_len].contiguous()
+        self.forward_metadata = ForwardMetadata(attn_logits, attn_lse, None, num_kv_splits, kv_indptr, kv_indices, None,
+                                                cascade_prefix_indices=prefix, cascade_prefix_splits=int(prefix_splits))
 
     def _target_verify_metadata(self, forward_batch):
         """Speculative-decoding verification (triton_backend.py:224-258): every request extends by num_draft_tokens over its
@@ -233,10 +263,12 @@ class HipAttnBackend(AttentionBackend):
     def forward_decode(self, q, k, v, layer, forward_batch, save_kv_cache=True):
         kv_indptr, kv_indices, num_kv_splits, _ = self._layer_kv(layer)
         q = q.reshape(-1, layer.tp_q_head_num * layer.qk_head_dim)
-        o = q.new_empty((q.shape[0], layer.tp_q_head_num * layer.v_head_dim))
         if save_kv_cache:  # decode reads the new token from the pool, so this must precede the attention launch
             forward_batch.token_to_kv_pool.set_kv_buffer(layer, forward_batch.out_cache_loc, k, v, layer.k_scale, layer.v_scale)
         md = self.forward_metadata
+        if md.cascade_prefix_indices is not None:
+            return self._forward_decode_cascade(q, layer, forward_batch, want_o=True, want_quant=False)[0]
+        o = q.new_empty((q.shape[0], layer.tp_q_head_num * layer.v_head_dim))
         K.decode_attention_fwd(
             q.view(-1, layer.tp_q_head_num, layer.qk_head_dim),
             forward_batch.token_to_kv_pool.get_key_buffer(layer.layer_id),
@@ -246,6 +278,23 @@ class HipAttnBackend(AttentionBackend):
             layer.scaling, layer.logit_cap, layer.k_scale_float or 1.0, layer.v_scale_float or 1.0,
         )
         return o
+
+    def _merge_counter_buf(self, q):
+        if self._merge_counters is None or self._merge_counters.device != q.device or self._merge_counters.numel() < q.shape[0]:
+            self._merge_counters = torch.zeros(max(self.max_bs_hint, q.shape[0]), dtype=torch.int32, device=q.device)
+        return self._merge_counters
+
+    def _forward_decode_cascade(self, q, layer, forward_batch, want_o, want_quant):
+        md = self.forward_metadata
+        if layer.sliding_window_size is not None and layer.sliding_window_size > -1:
+            raise RuntimeError("HipAttnBackend: cascade decode metadata cannot serve a sliding-window layer")
+        return K.decode_attention_cascade(
+            q.reshape(-1, layer.tp_q_head_num, layer.qk_head_dim),
+            forward_batch.token_to_kv_pool.get_key_buffer(layer.layer_id),
+            forward_batch.token_to_kv_pool.get_value_buffer(layer.layer_id),
+            md.cascade_prefix_indices, md.cascade_prefix_splits, md.kv_indptr, md.kv_indices, md.attn_logits, md.attn_lse,
+            md.num_kv_splits, self.max_kv_splits, layer.scaling, self._merge_counter_buf(q), layer.logit_cap,
+            layer.k_scale_float or 1.0, layer.v_scale_float or 1.0, want_o=want_o, want_quant=want_quant)
 
     def forward_decode_partial(self, q, layer, forward_batch):
         """Stage 1 only (the caller has already written K/V and will merge the split partials itself, e.g. fused with
@@ -266,10 +315,9 @@ class HipAttnBackend(AttentionBackend):
         w8a8 decode step in one kernel).  Returns (o or None, o_q, o_scale)."""
         kv_indptr, kv_indices, num_kv_splits, _ = self._layer_kv(layer)
         md = self.forward_metadata
-        if self._merge_counters is None or self._merge_counters.device != q.device:
-            self._merge_counters = torch.zeros(max(self.max_bs_hint, q.shape[0]), dtype=torch.int32, device=q.device)
-        if self._merge_counters.numel() < q.shape[0]:
-            self._merge_counters = torch.zeros(q.shape[0], dtype=torch.int32, device=q.device)
+        if md.cascade_prefix_indices is not None:
+            return self._forward_decode_cascade(q, layer, forward_batch, want_o=want_o, want_quant=True)
+        self._merge_counter_buf(q)
         return K.decode_attention_merge_quant(
             q.reshape(-1, layer.tp_q_head_num, layer.qk_head_dim),
             forward_batch.token_to_kv_pool.get_key_buffer(layer.layer_id),

@@ -320,3 +320,137 @@ def test_decode_config5_shard_shape_bs128_ragged(pkg):
         ref = oa.decode_attention_f64(q[b:b + 1], k, v, r2t, rpi[b:b + 1], seq[b:b + 1], d ** -0.5)
         for o in outs:
             assert (o[b].double() - ref[0]).abs().max().item() <= 2e-2
+
+
+# ---------------------------------------------------------------- f3: cascade shared-prefix decode
+def _shared_prefix_problem(bs, hq, hkv, d, prefix, suffix, dtype, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    total = prefix + sum(suffix)
+    pool = total + 17
+    perm = (torch.randperm(pool - 1, generator=g) + 1).int()
+    pre_slots = perm[:prefix]
+    seq = torch.tensor([prefix + s for s in suffix], dtype=torch.int64)
+    r2t = torch.zeros(bs + 2, int(seq.max()) + 4, dtype=torch.int32)
+    rpi = torch.randperm(bs + 2, generator=g)[:bs]
+    cur = prefix
+    for i in range(bs):
+        r2t[rpi[i], :prefix] = pre_slots
+        r2t[rpi[i], prefix:prefix + suffix[i]] = perm[cur:cur + suffix[i]]
+        cur += suffix[i]
+    q = torch.randn(bs, hq, d, generator=g).to(dtype)
+    k = torch.randn(pool, hkv, d, generator=g).to(dtype)
+    v = torch.randn(pool, hkv, d, generator=g).to(dtype)
+    return dict(q=q, k=k, v=v, r2t=r2t, rpi=rpi, seq=seq, pre_slots=pre_slots, prefix=prefix, suffix=suffix)
+
+
+@pytest.mark.parametrize("hq,hkv,d", [(32, 8, 128), (8, 1, 128), (28, 4, 128), (12, 12, 64)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("prefix_splits", [1, 3])
+def test_cascade_decode_matches_plain_and_oracle(hq, hkv, d, dtype, prefix_splits, pkg):
+    """Shared-prefix cascade (prefix attended once for all requests + private suffixes + in-launch LSE merge) against the
+    float64 oracle over the FULL sequences and against the plain kernel; also the quantised output form, byte-exact against
+    per-token quantisation of the cascade's own rounded rows."""
+    from ltp_sglang_amd import sgl_kernel
+    from oracle import quant as oq
+
+    dev = torch.device("cuda:0")
+    bs = 7
+    P = _shared_prefix_problem(bs, hq, hkv, d, prefix=200, suffix=[1, 33, 64, 7, 130, 2, 32], dtype=dtype, seed=hq + d)
+    S = 8
+    suf = torch.tensor(P["suffix"], dtype=torch.int32)
+    kv_indptr = torch.zeros(bs + 1, dtype=torch.int32)
+    kv_indptr[1:] = torch.cumsum(suf, 0)
+    kv_indices = torch.cat([P["r2t"][P["rpi"][i], P["prefix"]:int(P["seq"][i])] for i in range(bs)]).int()
+    logits = torch.full((bs, hq, S, d), float("nan"), dtype=torch.float32, device=dev)
+    lse = torch.full((bs, hq, S), float("nan"), dtype=torch.float32, device=dev)
+    nsplit = torch.tensor([1, 2, 3, 1, 4, 5, 2], dtype=torch.int32, device=dev)   # (5 > tiles of a 2-token suffix: empty splits)
+    cnt = torch.zeros(bs, dtype=torch.int32, device=dev)
+    qd, kd, vd = P["q"].to(dev), P["k"].to(dev), P["v"].to(dev)
+    o, oq_, os_ = sgl_kernel.decode_attention_cascade(qd, kd, vd, P["pre_slots"].to(dev), prefix_splits, kv_indptr.to(dev),
+                                                      kv_indices.to(dev), logits, lse, nsplit, S, d ** -0.5, cnt,
+                                                      want_o=True, want_quant=True)
+    torch.cuda.synchronize()
+    assert int(cnt.abs().sum()) == 0   # counters left zero
+    ref = oa.decode_attention_f64(P["q"], P["k"], P["v"], P["r2t"], P["rpi"], P["seq"], d ** -0.5)
+    got = o.view(bs, hq, d).cpu()
+    assert (got.double() - ref).abs().max().item() <= TOL_F64[dtype]
+    # plain kernel over the full sequences
+    full_indptr = torch.zeros(bs + 1, dtype=torch.int32)
+    full_indptr[1:] = torch.cumsum(P["seq"], 0)
+    full_idx = torch.cat([P["r2t"][P["rpi"][i], :int(P["seq"][i])] for i in range(bs)]).int()
+    o2 = torch.empty(bs, hq, d, dtype=dtype, device=dev)
+    sgl_kernel.decode_attention_fwd(qd, kd, vd, o2, full_indptr.to(dev), full_idx.to(dev), logits, lse,
+                                    torch.full((bs,), 2, dtype=torch.int32, device=dev), S, d ** -0.5)
+    assert (got.float() - o2.cpu().float()).abs().max().item() <= (1.6e-2 if dtype == torch.bfloat16 else 2e-3)
+    # quantised form == per-token quantisation of the rounded rows
+    rq, rs = oq.per_token_quant_fp8(o.cpu())
+    assert torch.equal(oq_.cpu().view(torch.uint8), rq.view(torch.uint8)) and torch.equal(os_.cpu(), rs)
+
+
+def test_cascade_decode_fp8_kv_and_logit_cap(pkg):
+    from ltp_sglang_amd import sgl_kernel
+
+    dev = torch.device("cuda:0")
+    bs, hq, hkv, d = 5, 32, 8, 128
+    P = _shared_prefix_problem(bs, hq, hkv, d, prefix=96, suffix=[40, 1, 70, 33, 5], dtype=torch.bfloat16, seed=3)
+    ks, vs = 0.5, 0.25
+    k8, v8 = (P["k"].float() / ks).to(torch.float8_e4m3fn), (P["v"].float() / vs).to(torch.float8_e4m3fn)
+    suf = torch.tensor(P["suffix"], dtype=torch.int32)
+    kv_indptr = torch.zeros(bs + 1, dtype=torch.int32)
+    kv_indptr[1:] = torch.cumsum(suf, 0)
+    kv_indices = torch.cat([P["r2t"][P["rpi"][i], P["prefix"]:int(P["seq"][i])] for i in range(bs)]).int()
+    S = 6
+    logits = torch.empty(bs, hq, S, d, dtype=torch.float32, device=dev)
+    lse = torch.empty(bs, hq, S, dtype=torch.float32, device=dev)
+    cnt = torch.zeros(bs, dtype=torch.int32, device=dev)
+    o, _, _ = sgl_kernel.decode_attention_cascade(P["q"].to(dev), k8.to(dev), v8.to(dev), P["pre_slots"].to(dev), 2, kv_indptr.to(dev),
+                                                  kv_indices.to(dev), logits, lse, torch.full((bs,), 2, dtype=torch.int32, device=dev), S,
+                                                  d ** -0.5, cnt, logit_cap=25.0, k_scale=ks, v_scale=vs)
+    ref = oa.decode_attention_f64(P["q"], (k8.float() * ks), (v8.float() * vs), P["r2t"], P["rpi"], P["seq"], d ** -0.5, 25.0)
+    assert (o.view(bs, hq, d).cpu().double() - ref).abs().max().item() <= 2.5e-2
+
+
+def test_backend_cascade_metadata_and_forward(pkg):
+    """HipAttnBackend.init_forward_metadata_cascade: suffix-only kv_indices (create_kv_indices with start offsets), prefix slots
+    from req_to_token, then forward_decode / forward_decode_merged_quant through the cascade -- equal to the ordinary
+    metadata path within the kernel tolerance."""
+    from types import SimpleNamespace
+
+    from ltp_sglang_amd.srt.layers.attention.hip_backend import HipAttnBackend
+    from ltp_sglang_amd.srt.layers.radix_attention import RadixAttention
+    from ltp_sglang_amd.srt.mem_cache.memory_pool import MHATokenToKVPool
+    from ltp_sglang_amd.srt.model_executor.forward_batch_info import ForwardBatch, ForwardMode
+
+    dev = "cuda:0"
+    bs, hq, hkv, d = 6, 32, 8, 128
+    P = _shared_prefix_problem(bs, hq, hkv, d, prefix=300, suffix=[10, 64, 1, 200, 33, 97], dtype=torch.bfloat16, seed=9)
+    pool = MHATokenToKVPool(P["k"].shape[0] - 1, 1, torch.bfloat16, hkv, d, 1, dev, False)
+    pool.k_buffer[0].copy_(P["k"].to(dev))
+    pool.v_buffer[0].copy_(P["v"].to(dev))
+    r2t = P["r2t"].to(dev)
+    runner = SimpleNamespace(device=dev, gpu_id=0, req_to_token_pool=SimpleNamespace(size=r2t.shape[0], req_to_token=r2t),
+                             token_to_kv_pool=pool, sliding_window_size=None,
+                             model_config=SimpleNamespace(num_attention_heads=hq, get_num_kv_heads=lambda tp: hkv, context_len=r2t.shape[1],
+                                                          is_encoder_decoder=False),
+                             server_args=SimpleNamespace(triton_attention_num_kv_splits=16, speculative_num_draft_tokens=None,
+                                                         speculative_num_steps=None))
+    backend = HipAttnBackend(runner)
+    layer = RadixAttention(hq, d, d ** -0.5, hkv, 0)
+    fb = ForwardBatch(forward_mode=ForwardMode.DECODE, batch_size=bs, input_ids=torch.zeros(bs, dtype=torch.int64, device=dev),
+                      req_pool_indices=P["rpi"].to(dev), seq_lens=P["seq"].to(dev), out_cache_loc=torch.zeros(bs, dtype=torch.int64, device=dev),
+                      seq_lens_sum=int(P["seq"].sum()), token_to_kv_pool=pool, attn_backend=backend)
+    q = P["q"].reshape(bs, -1).to(dev)
+    backend.init_forward_metadata(fb)
+    plain = backend.forward(q, None, None, layer, fb, save_kv_cache=False).float().cpu()
+    backend.init_forward_metadata_cascade(fb, 300)
+    md = backend.forward_metadata
+    assert md.cascade_prefix_indices is not None and torch.equal(md.cascade_prefix_indices.cpu(), P["pre_slots"])
+    want_idx = torch.cat([P["r2t"][P["rpi"][i], 300:int(P["seq"][i])] for i in range(bs)]).int()
+    assert torch.equal(md.kv_indices[: want_idx.numel()].cpu(), want_idx)
+    casc = backend.forward(q, None, None, layer, fb, save_kv_cache=False).float().cpu()
+    assert (casc - plain).abs().max().item() <= 1.6e-2
+    ref = oa.decode_attention_f64(P["q"], P["k"], P["v"], P["r2t"], P["rpi"], P["seq"], d ** -0.5)
+    assert (casc.view(bs, hq, d).double() - ref).abs().max().item() <= TOL_F64[torch.bfloat16]
+    _, oq_, os_ = backend.forward_decode_merged_quant(q, layer, fb)
+    deq = oq_.float().cpu() * os_.cpu()
+    assert (deq - casc).abs().max().item() <= 0.07 * casc.abs().max().item()
