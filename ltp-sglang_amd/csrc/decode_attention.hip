@@ -59,7 +59,9 @@ struct DecodeParams {
   float* mq_s;
   // Cascade shared-prefix decode (the LSE merge is merge_attn_states.cu's): all `bs` requests share the first
   // prefix_len slots of their sequences.
-  //   prefix pass  (shared_reqs = bs > 0): ONE virtual request whose GQA group of kv head kh is the bs * group query heads
+  //   (a wide prefix kernel -- 64 columns per wave on every staged tile, 512-register budget -- was built and measured SLOWER:
+//   28 us against 19 us for the prefix pass at 64 requests x 1536 shared keys; a quarter of the workgroups, each latency-bound)
+//   prefix pass  (shared_reqs = bs > 0): ONE virtual request whose GQA group of kv head kh is the bs * group query heads
   //                {(request r, head kh * group + j)}: every K/V row of the prefix is read once per (kv head, 16-column chunk,
   //                split) for ALL requests -- the extra requests are extra MFMA columns.  Keys = kv_indices[0, prefix_len),
   //                prefix_splits splits, partials go to split slots [0, prefix_splits) of each request.

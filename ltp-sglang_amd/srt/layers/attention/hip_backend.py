@@ -132,8 +132,9 @@ class HipAttnBackend(AttentionBackend):
         if not forward_batch.forward_mode.is_decode() or shared_prefix_len < 64 or bs < 2 or self.v_head_dim not in (64, 128):
             return self.init_forward_metadata(forward_batch)
         chunks = self.num_kv_head * ((bs * group + 15) // 16)
-        if prefix_splits is None:   # about one round of resident workgroups (2 per CU), at least 64 keys per split
-            prefix_splits = max(1, min(2 * self.device_core_count // max(chunks, 1), shared_prefix_len // 64, self.max_kv_splits // 2))
+        if prefix_splits is None:   # one round of resident workgroups (2 per CU); every extra split is one more partial per
+            # (request, head) for the merging workgroup to read (measured: 4 splits 57 us, 8: 66 us, 12: 75 us per layer)
+            prefix_splits = max(1, min(2 * self.device_core_count // max(chunks, 1), shared_prefix_len // 128, 4))
         suffix_lens = forward_batch.seq_lens - shared_prefix_len
         kv_indptr = self.kv_indptr[: bs + 1]
         num_kv_splits = torch.empty((bs,), dtype=torch.int32, device=self.device)

@@ -39,9 +39,10 @@ def run(shared, bs=64, hq=32, hkv=8, d=128, pre=1536, uniq=512, nsplit=4, max_sp
     ts.sort()
     print(f"shared={shared} nsplit={nsplit}: {ts[len(ts)//2]*1e3:.1f} us/layer")
 
-for sh in (False, True):
-    for ns in (4, 8):
-        run(sh, nsplit=ns)
+if "--cascade-only" not in sys.argv:
+    for sh in (False, True):
+        for ns in (4, 8):
+            run(sh, nsplit=ns)
 
 
 def run_cascade(bs=64, hq=32, hkv=8, d=128, pre=1536, uniq=512, max_splits=16, layers=6, iters=10, prefix_splits=4, suffix_splits=2):
@@ -94,5 +95,5 @@ def run_cascade(bs=64, hq=32, hkv=8, d=128, pre=1536, uniq=512, max_splits=16, l
     print("max |cascade - plain| =", float((o1.float() - o2.float()).abs().max()))
 
 
-for ps, ss in ((2, 2), (4, 2), (4, 4), (8, 2), (4, 1)):
+for ps, ss in (((4, 1),) if "--cascade-only" in sys.argv else ((2, 1), (4, 1), (4, 2), (8, 1))):
     run_cascade(prefix_splits=ps, suffix_splits=ss)
