@@ -326,6 +326,23 @@ int sgl_mi355_awq_gemm(const void* x, int64_t x_stride_elems, const void* qpacke
  * the [N, K] the GEMMs stream; AWQLinearMethod.apply, layers/quantization/awq.py:401-418) */
 int sgl_mi355_transpose_2d(void* out, const void* in, int rows, int cols, void* stream);
 
+/* ---- one-shot P2P all-reduce over IPC-mapped peer buffers ------------------------------------
+ * The tensor-parallel all-reduce of the decode path (RowParallelLinear, python/sglang/srt/layers/linear.py:1302-1303 ->
+ * GroupCoordinator.all_reduce, distributed/parallel_state.py:480-500, which prefers the custom all-reduce for small
+ * messages): sgl-kernel/csrc/allreduce/custom_all_reduce_hip.cuh:261,294,543-549 (one-stage cross-device reduce) and
+ * python/sglang/srt/distributed/device_communicators/custom_all_reduce.py (buffer registration over IPC handles).
+ * car_alloc: one uncached device allocation per rank (signal block + two data halves of max_bytes) and its 64-byte IPC
+ * handle; car_open / car_close: map / unmap a peer's allocation; car_all_reduce: in-place sum over `world` ranks, every
+ * rank reads every peer once and adds in rank order with f32 accumulation (bit-identical on all ranks), HIP-graph capturable;
+ * car_error: 1 if a peer failed to arrive within the spin bound since the last query (the call's output is then undefined). */
+int sgl_mi355_car_alloc(int64_t max_bytes, void** ptr_out, void* handle_out);
+int sgl_mi355_car_open(const void* handle, void** ptr_out);
+int sgl_mi355_car_close(void* peer_ptr);
+int sgl_mi355_car_free(void* own_ptr);
+int sgl_mi355_car_error(void* own_ptr);
+int sgl_mi355_car_all_reduce(void* inout, int64_t num_elements, int dtype, const void* const* peer_bufs, int rank, int world,
+                             int64_t max_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,206 @@
+// One-shot P2P all-reduce over IPC-mapped peer buffers (xGMI between the 8 GPUs of a node; between processes of ONE GPU in
+// the validation rig), gfx950.
+//
+// Replaces, for the tensor-parallel decode path (two [M, hidden] bf16 sums per layer: 256 KiB at Llama-3-8B batch 32,
+// 2 MiB at Llama-3-70B batch 128), the reference's custom all-reduce
+//   sgl-kernel/csrc/allreduce/custom_all_reduce_hip.cuh:261,294 (cross_device_reduce_1stage), :543-549 (dispatch),
+//   python/sglang/srt/distributed/device_communicators/custom_all_reduce.py (buffer registration, should_custom_ar),
+// which GroupCoordinator.all_reduce prefers over RCCL for small messages (parallel_state.py:480-500): at these sizes a ring
+// collective is per-hop latency bound, a one-shot read of every peer is one xGMI round trip.
+//
+// Design (written for this hardware, not translated):
+//  * every rank owns ONE uncached device allocation (hipDeviceMallocUncached: neither the owner's nor a peer's L2 keeps its
+//    lines, so a peer's read always sees what the owner's drained stores wrote) = signal block + two data halves; peers map it
+//    with hipIpcOpenMemHandle;
+//  * a call copies the rank's input into its own half `epoch & 1`, drains, and block b raises flag[b][rank] = epoch in EVERY
+//    rank's signal block (system-scope release stores, one lane per peer); block b then waits until its own flag[b][r] has
+//    reached epoch for all r (system-scope acquire polls, one lane per peer) and sums the peers' halves IN RANK ORDER with f32
+//    accumulation -- every rank computes the same bits;
+//  * the two halves alternate by call, which removes the closing barrier: a rank can enter call n + 1 (writing the other
+//    half) while a slow peer still reads call n, but cannot pass call n + 1's opening barrier -- and so cannot touch half
+//    n & 1 again -- before every peer has arrived there, i.e. has finished reading call n;
+//  * epochs live in device memory and are advanced by the kernel, so a captured HIP graph replays correctly;
+//  * every spin is bounded: a peer that never arrives sets the signal block's error word instead of hanging the GPU.
+//  * block b of every rank copies and reduces the SAME element range, so a block only ever reads data that the matching block
+//    of a peer published before raising the flag it waits on.
+#include "common.h"
+
+namespace {
+
+constexpr int kMaxRanks = 8;
+constexpr int kMaxBlocks = 64;
+constexpr int kThreads = 512;
+constexpr uint32_t kSpinLimit = 1u << 26;  // polls of ~64 ns each: a few seconds, then give up
+
+struct alignas(128) CarSignal {
+  uint32_t flag[kMaxBlocks][kMaxRanks];  // written by the peers: flag[b][r] = last epoch rank r's block b has published
+  uint32_t epoch[kMaxBlocks];            // own counter per block
+  uint32_t error;                        // set when a spin ran out
+};
+
+struct CarParams {
+  char* buf[kMaxRanks];       // each rank's allocation (signal block first)
+  void* inout;
+  int64_t n16;                // 16-byte packets
+  int64_t half_bytes;
+  int64_t data_off;           // offset of the first data half inside an allocation
+  int rank, world;
+};
+
+template <typename T>
+__device__ __forceinline__ void accumulate(float (&acc)[8], const u32x4_t& v) {
+  struct P8 { T v[8]; };
+  const P8 x = __builtin_bit_cast(P8, v);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] += (float)x.v[j];
+}
+template <>
+__device__ __forceinline__ void accumulate<float>(float (&acc)[8], const u32x4_t& v) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] += __builtin_bit_cast(float, v[j]);
+}
+template <typename T>
+__device__ __forceinline__ u32x4_t pack(const float (&acc)[8]) {
+  struct P8 { T v[8]; };
+  P8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o.v[j] = (T)acc[j];
+  return __builtin_bit_cast(u32x4_t, o);
+}
+template <>
+__device__ __forceinline__ u32x4_t pack<float>(const float (&acc)[8]) {
+  return u32x4_t{__builtin_bit_cast(uint32_t, acc[0]), __builtin_bit_cast(uint32_t, acc[1]), __builtin_bit_cast(uint32_t, acc[2]),
+                 __builtin_bit_cast(uint32_t, acc[3])};
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void one_shot_all_reduce_kernel(const CarParams p) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  CarSignal* me = (CarSignal*)p.buf[p.rank];
+  const uint32_t epoch = me->epoch[b] + 1;
+  const int64_t half = p.data_off + (int64_t)(epoch & 1u) * p.half_bytes;
+  const int64_t stride = (int64_t)gridDim.x * kThreads;
+  // 1. publish this rank's operand in its own (uncached) half
+  u32x4_t* mine = (u32x4_t*)(p.buf[p.rank] + half);
+  for (int64_t i = (int64_t)b * kThreads + tid; i < p.n16; i += stride) mine[i] = ((const u32x4_t*)p.inout)[i];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: the stores above have left this GPU's write path
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  // 2. one lane per peer: raise my flag there, then wait for that peer's flag here
+  __shared__ int failed;
+  if (tid == 0) failed = 0;
+  __syncthreads();
+  if (tid < p.world) {
+    CarSignal* peer = (CarSignal*)p.buf[tid];
+    __hip_atomic_store(&peer->flag[b][p.rank], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    uint32_t spins = 0;
+    // (epochs only grow; "< epoch" tolerates a peer that is already one call ahead)
+    while ((int32_t)(__hip_atomic_load(&me->flag[b][tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > kSpinLimit) {
+        failed = 1;
+        me->error = 1u;
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  // 3. sum the peers' halves in rank order (identical arithmetic on every rank)
+  if (!failed) {
+    for (int64_t i = (int64_t)b * kThreads + tid; i < p.n16; i += stride) {
+      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int r = 0; r < p.world; ++r) {
+        const u32x4_t v = __builtin_nontemporal_load((const u32x4_t*)(p.buf[r] + half) + i);
+        accumulate<T>(acc, v);
+      }
+      ((u32x4_t*)p.inout)[i] = pack<T>(acc);
+    }
+  }
+  __syncthreads();
+  if (tid == 0) me->epoch[b] = epoch;
+}
+
+}  // namespace
+
+// Allocates a rank's uncached buffer (signal block + two data halves of max_bytes each), zeroes the signal block and
+// returns its 64-byte IPC handle.
+extern "C" int sgl_mi355_car_alloc(int64_t max_bytes, void** ptr_out, void* handle_out) {
+  SGL_CHECK(max_bytes > 0 && max_bytes % 16 == 0 && ptr_out && handle_out, "car_alloc: bad arguments");
+  const size_t total = sizeof(CarSignal) + 2 * (size_t)max_bytes;
+  void* ptr = nullptr;
+  hipError_t e = hipExtMallocWithFlags(&ptr, total, hipDeviceMallocUncached);
+  SGL_CHECK(e == hipSuccess, "car_alloc: hipExtMallocWithFlags(%zu, uncached) failed: %s", total, hipGetErrorString(e));
+  e = hipMemset(ptr, 0, sizeof(CarSignal));
+  SGL_CHECK(e == hipSuccess, "car_alloc: hipMemset failed: %s", hipGetErrorString(e));
+  hipIpcMemHandle_t h;
+  e = hipIpcGetMemHandle(&h, ptr);
+  SGL_CHECK(e == hipSuccess, "car_alloc: hipIpcGetMemHandle failed: %s (HSA_ENABLE_IPC_MODE_LEGACY=0 is required on this driver)",
+            hipGetErrorString(e));
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
+  memcpy(handle_out, &h, sizeof(h));
+  *ptr_out = ptr;
+  (void)hipDeviceSynchronize();
+  return SGL_MI355_OK;
+}
+
+extern "C" int sgl_mi355_car_open(const void* handle, void** ptr_out) {
+  SGL_CHECK(handle && ptr_out, "car_open: null pointer");
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle, sizeof(h));
+  void* ptr = nullptr;
+  const hipError_t e = hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess);
+  SGL_CHECK(e == hipSuccess, "car_open: hipIpcOpenMemHandle failed: %s", hipGetErrorString(e));
+  *ptr_out = ptr;
+  return SGL_MI355_OK;
+}
+
+extern "C" int sgl_mi355_car_close(void* peer_ptr) {
+  const hipError_t e = hipIpcCloseMemHandle(peer_ptr);
+  SGL_CHECK(e == hipSuccess, "car_close: hipIpcCloseMemHandle failed: %s", hipGetErrorString(e));
+  return SGL_MI355_OK;
+}
+
+extern "C" int sgl_mi355_car_free(void* own_ptr) {
+  const hipError_t e = hipFree(own_ptr);
+  SGL_CHECK(e == hipSuccess, "car_free: hipFree failed: %s", hipGetErrorString(e));
+  return SGL_MI355_OK;
+}
+
+// Reads (and clears) the error word of a rank's own signal block: non-zero = a spin ran out since the last call.
+extern "C" int sgl_mi355_car_error(void* own_ptr) {
+  uint32_t v = 0;
+  CarSignal* s = (CarSignal*)own_ptr;
+  if (hipMemcpy(&v, &s->error, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  if (v) (void)hipMemset(&s->error, 0, sizeof(v));
+  return (int)v;
+}
+
+// In-place sum of `inout` (num_elements of dtype bf16 / f16 / f32, 16-byte aligned, byte count a multiple of 16 and at most
+// the max_bytes of car_alloc) over the `world` ranks whose allocations are peer_bufs[0 .. world) (this rank's own pointer at
+// [rank], the others as returned by car_open).  Every rank must call with the same size, in the same order.
+extern "C" int sgl_mi355_car_all_reduce(void* inout, int64_t num_elements, int dtype, const void* const* peer_bufs, int rank,
+                                        int world, int64_t max_bytes, void* stream) {
+  SGL_CHECK(inout && peer_bufs, "car_all_reduce: null pointer");
+  SGL_CHECK(world >= 2 && world <= kMaxRanks && rank >= 0 && rank < world, "car_all_reduce: rank %d / world %d unsupported", rank, world);
+  SGL_CHECK(dtype == SGL_BF16 || dtype == SGL_F16 || dtype == SGL_F32, "car_all_reduce: dtype code %d unsupported", dtype);
+  const int64_t bytes = num_elements * (dtype == SGL_F32 ? 4 : 2);
+  SGL_CHECK(bytes > 0 && bytes % 16 == 0 && bytes <= max_bytes && ((uintptr_t)inout % 16) == 0,
+            "car_all_reduce: %lld bytes must be a positive multiple of 16, at most %lld, 16-byte aligned", (long long)bytes, (long long)max_bytes);
+  CarParams p;
+  for (int r = 0; r < kMaxRanks; ++r) p.buf[r] = (char*)(r < world ? peer_bufs[r] : peer_bufs[0]);
+  p.inout = inout;
+  p.n16 = bytes / 16;
+  p.half_bytes = max_bytes;
+  p.data_off = (int64_t)sizeof(CarSignal);
+  p.rank = rank;
+  p.world = world;
+  // the grid is a function of the size only: every rank launches the same number of blocks
+  const int64_t want = (p.n16 + kThreads - 1) / kThreads;
+  const unsigned blocks = (unsigned)(want < 1 ? 1 : (want > kMaxBlocks ? kMaxBlocks : want));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SGL_BF16) hipLaunchKernelGGL((one_shot_all_reduce_kernel<__bf16>), dim3(blocks), dim3(kThreads), 0, st, p);
+  else if (dtype == SGL_F16) hipLaunchKernelGGL((one_shot_all_reduce_kernel<_Float16>), dim3(blocks), dim3(kThreads), 0, st, p);
+  else hipLaunchKernelGGL((one_shot_all_reduce_kernel<float>), dim3(blocks), dim3(kThreads), 0, st, p);
+  SGL_HIP_LAUNCH_CHECK();
+  return SGL_MI355_OK;
+}

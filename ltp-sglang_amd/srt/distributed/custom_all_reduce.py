@@ -1,0 +1,99 @@
+"""CustomAllreduce: one-shot P2P all-reduce over IPC-mapped peer buffers (xGMI), the small-message path of the
+tensor-parallel all-reduce (python/sglang/srt/distributed/device_communicators/custom_all_reduce.py:46-430 over
+sgl-kernel/csrc/allreduce/custom_all_reduce_hip.cuh:261-549; chosen before RCCL by GroupCoordinator.all_reduce,
+parallel_state.py:480-500).
+
+One process per GPU.  At construction every rank allocates its uncached buffer through the C-ABI (``sgl_mi355_car_alloc``),
+the 64-byte IPC handles travel over a CPU (gloo) group exactly as the reference exchanges them
+(custom_all_reduce.py:_gather_ipc_meta), and each rank maps its peers' buffers.  ``all_reduce`` is then ONE kernel: publish,
+flag every peer, wait for every peer, sum in rank order (see csrc/custom_all_reduce.hip).  The validation rig runs 2 / 4
+processes on ONE GPU (tests/test_custom_all_reduce_gpu.py); on a node the same code path reads over xGMI.
+"""
+import ctypes
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+from ..._cabi import check, current_stream, dtype_code, lib
+
+_SUPPORTED_WORLD_SIZES = (2, 4, 6, 8)   # custom_all_reduce.py:52
+
+
+class CustomAllreduce:
+    def __init__(self, group: "dist.ProcessGroup", device: torch.device, max_size: int = 8 * 1024 * 1024):
+        """``group``: a CPU-capable (gloo) group used only to exchange the IPC handles; ``max_size``: largest message in bytes
+        (the reference's default is 8 MiB, custom_all_reduce.py:58)."""
+        self.disabled = True
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world_size = dist.get_world_size(group)
+        self.device = torch.device(device)
+        self.max_size = int(max_size) // 16 * 16
+        self._own = ctypes.c_void_p()
+        self._peers: List[Optional[int]] = []
+        if self.world_size == 1 or self.world_size not in _SUPPORTED_WORLD_SIZES:
+            return
+        torch.cuda.set_device(self.device)
+        handle = (ctypes.c_ubyte * 64)()
+        check(lib.sgl_mi355_car_alloc(self.max_size, ctypes.byref(self._own), handle))
+        handles = [None] * self.world_size
+        dist.all_gather_object(handles, bytes(handle), group=group)
+        ptrs = (ctypes.c_void_p * self.world_size)()
+        for r, h in enumerate(handles):
+            if r == self.rank:
+                ptrs[r] = self._own.value
+                self._peers.append(None)
+            else:
+                peer = ctypes.c_void_p()
+                buf = (ctypes.c_ubyte * 64).from_buffer_copy(h)
+                check(lib.sgl_mi355_car_open(buf, ctypes.byref(peer)))
+                ptrs[r] = peer.value
+                self._peers.append(peer.value)
+        self._ptrs = ptrs
+        dist.barrier(group=group)   # every rank has mapped every buffer before anyone launches
+        self.disabled = False
+
+    def should_use(self, inp: torch.Tensor) -> bool:
+        """should_custom_ar (custom_all_reduce.py:345-360): small, 16-byte multiples, contiguous."""
+        if self.disabled or not inp.is_cuda or not inp.is_contiguous():
+            return False
+        nbytes = inp.numel() * inp.element_size()
+        return (inp.dtype in (torch.bfloat16, torch.float16, torch.float32) and nbytes % 16 == 0 and 0 < nbytes <= self.max_size
+                and inp.data_ptr() % 16 == 0)
+
+    should_custom_ar = should_use
+
+    def all_reduce(self, inp: torch.Tensor) -> torch.Tensor:
+        """In-place sum over the group; returns ``inp``.  Capturable in a HIP graph (epochs live in device memory)."""
+        check(lib.sgl_mi355_car_all_reduce(inp.data_ptr(), inp.numel(), dtype_code(inp.dtype), self._ptrs, self.rank,
+                                           self.world_size, self.max_size, current_stream()))
+        return inp
+
+    custom_all_reduce = all_reduce
+
+    def check_error(self) -> None:
+        """Raises if a peer failed to arrive within the kernel's spin bound since the last check (synchronises)."""
+        if self.disabled:
+            return
+        torch.cuda.synchronize(self.device)
+        rc = lib.sgl_mi355_car_error(self._own)
+        if rc != 0:
+            raise RuntimeError("custom all-reduce: a peer rank did not arrive (spin bound reached); results are invalid")
+
+    def close(self) -> None:
+        if self.disabled:
+            return
+        self.disabled = True
+        torch.cuda.synchronize(self.device)
+        dist.barrier(group=self.group)   # nobody unmaps while a peer may still read
+        for p in self._peers:
+            if p is not None:
+                lib.sgl_mi355_car_close(ctypes.c_void_p(p))
+        lib.sgl_mi355_car_free(self._own)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
