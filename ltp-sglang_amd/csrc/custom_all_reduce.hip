@@ -56,8 +56,10 @@ __device__ __forceinline__ void accumulate(float (&acc)[8], const u32x4_t& v) {
 }
 template <>
 __device__ __forceinline__ void accumulate<float>(float (&acc)[8], const u32x4_t& v) {
+  struct F4 { float v[4]; };
+  const F4 x = __builtin_bit_cast(F4, v);   // (element-wise bit_cast of v[j] miscompiles: every lane reads element 0)
 #pragma unroll
-  for (int j = 0; j < 4; ++j) acc[j] += __builtin_bit_cast(float, v[j]);
+  for (int j = 0; j < 4; ++j) acc[j] += x.v[j];
 }
 template <typename T>
 __device__ __forceinline__ u32x4_t pack(const float (&acc)[8]) {
@@ -69,8 +71,21 @@ __device__ __forceinline__ u32x4_t pack(const float (&acc)[8]) {
 }
 template <>
 __device__ __forceinline__ u32x4_t pack<float>(const float (&acc)[8]) {
-  return u32x4_t{__builtin_bit_cast(uint32_t, acc[0]), __builtin_bit_cast(uint32_t, acc[1]), __builtin_bit_cast(uint32_t, acc[2]),
-                 __builtin_bit_cast(uint32_t, acc[3])};
+  struct F4 { float v[4]; };
+  const F4 o = {{acc[0], acc[1], acc[2], acc[3]}};
+  return __builtin_bit_cast(u32x4_t, o);
+}
+
+// 16-byte accesses that bypass every cache level that is not coherent with a peer (sc0 sc1 = system scope): the importing
+// process's mapping of a peer's allocation need not inherit the owner's uncached memory type, so neither side relies on it.
+constexpr int kSysScope = 1 | 16;  // buffer cache policy: sc0 (bit 0) + sc1 (bit 4)
+__device__ __forceinline__ u32x4_t load_sys(const char* base, int64_t byte_off) {
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(base + byte_off), 0, 16, 0x00020000);
+  return __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc, 0, 0, kSysScope));
+}
+__device__ __forceinline__ void store_sys(char* base, int64_t byte_off, const u32x4_t& v) {
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(base + byte_off), 0, 16, 0x00020000);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), rsrc, 0, 0, kSysScope);
 }
 
 template <typename T>
@@ -81,8 +96,8 @@ __global__ __launch_bounds__(kThreads) void one_shot_all_reduce_kernel(const Car
   const int64_t half = p.data_off + (int64_t)(epoch & 1u) * p.half_bytes;
   const int64_t stride = (int64_t)gridDim.x * kThreads;
   // 1. publish this rank's operand in its own (uncached) half
-  u32x4_t* mine = (u32x4_t*)(p.buf[p.rank] + half);
-  for (int64_t i = (int64_t)b * kThreads + tid; i < p.n16; i += stride) mine[i] = ((const u32x4_t*)p.inout)[i];
+  for (int64_t i = (int64_t)b * kThreads + tid; i < p.n16; i += stride)
+    store_sys(p.buf[p.rank], half + i * 16, ((const u32x4_t*)p.inout)[i]);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: the stores above have left this GPU's write path
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -110,8 +125,7 @@ __global__ __launch_bounds__(kThreads) void one_shot_all_reduce_kernel(const Car
     for (int64_t i = (int64_t)b * kThreads + tid; i < p.n16; i += stride) {
       float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       for (int r = 0; r < p.world; ++r) {
-        const u32x4_t v = __builtin_nontemporal_load((const u32x4_t*)(p.buf[r] + half) + i);
-        accumulate<T>(acc, v);
+        accumulate<T>(acc, load_sys(p.buf[r], half + i * 16));
       }
       ((u32x4_t*)p.inout)[i] = pack<T>(acc);
     }

@@ -59,6 +59,10 @@ def _worker(rank, world, port, q):
         car.check_error()
         assert out.data_ptr() == xd.data_ptr()
         same = torch.equal(out.cpu(), ref)
+        if not same:
+            bad = (out.cpu() != ref)
+            print(f"[rank {rank}] call {it} {shape} {dtype}: {int(bad.sum())} of {bad.numel()} elements differ; first at {bad.flatten().nonzero()[:4].flatten().tolist()}",
+                  flush=True)
         ok = ok and same
         worst = max(worst, float((out.cpu().float() - ref.float()).abs().max()))
     # back-to-back calls without host synchronisation in between (a rank may run one call ahead of its peers)
