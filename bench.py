@@ -46,6 +46,9 @@ def parse_args():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prefill-chunk", type=int, default=8, help="requests per prefill call")
+    ap.add_argument("--all-reduce", default="auto", choices=["auto", "rccl", "p2p"],
+                    help="N > 1: auto = the one-shot P2P all-reduce over IPC-mapped peer buffers when its start-up self-check against "
+                         "RCCL passes, else RCCL; rccl / p2p force one")
     ap.add_argument("--emulate-tp", type=int, default=0,
                     help="ONE process builds rank 0's shard of a tp-N model and replaces each collective by a same-size device copy: "
                          "per-rank compute ms/step without communication (TP-readiness measurement on a 1-GPU box; not the metric)")
@@ -172,6 +175,42 @@ def main():
     from ltp_sglang_amd.srt.model_executor.synthetic_llama import LlamaShape, SyntheticModelRunner
 
     comm.init_tensor_parallel()
+    ar_kind = "none" if world == 1 else "rccl"
+    if world > 1 and args.dist_backend == "nccl" and args.all_reduce != "rccl":
+        # one-shot P2P all-reduce / all-gather (custom_all_reduce_hip.cuh:261-294 in the reference): IPC handles travel over a
+        # gloo side group; before it is trusted, one all-reduce and one all-gather are compared with RCCL's results on every rank
+        import torch.distributed as dist
+
+        from ltp_sglang_amd.srt.distributed.custom_all_reduce import CustomAllreduce
+
+        ok, why = True, ""
+        try:
+            car = CustomAllreduce(dist.new_group(backend="gloo"), torch.device(dev))
+            ok = not car.disabled
+            why = "" if ok else f"world size {world} unsupported"
+            if ok:
+                probe = torch.randn(32, 4096, device=dev, generator=torch.Generator(device=dev).manual_seed(rank)).to(torch.bfloat16)
+                want = probe.float()
+                dist.all_reduce(want)   # f32 sum over RCCL; the P2P kernel also accumulates in f32 and rounds once
+                got = car.all_reduce(probe.clone())
+                car.check_error()
+                ok = bool(((got.float() - want).abs() <= 0.02 * want.abs() + 0.05).all())
+                shard = torch.full((4, 64), float(rank), device=dev, dtype=torch.bfloat16)
+                gathered = car.all_gather_last_dim(shard)
+                car.check_error()
+                ok = ok and all(bool((gathered[:, r * 64:(r + 1) * 64] == float(r)).all()) for r in range(world))
+                why = "" if ok else "self-check against RCCL failed"
+        except Exception as e:   # IPC not available between these devices, driver limits, ...
+            ok, why = False, f"{type(e).__name__}: {e}"
+        flag = torch.tensor([1 if ok else 0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)   # all ranks or none
+        if int(flag.item()) == 1:
+            comm.set_custom_all_reduce(car)
+            ar_kind = "p2p-one-shot"
+        elif args.all_reduce == "p2p":
+            raise SystemExit(f"[bench] rank {rank}: --all-reduce p2p requested but unusable ({why or 'a peer failed'})")
+        elif rank == 0:
+            print(f"[bench] one-shot P2P all-reduce not used ({why or 'a peer failed'}); RCCL instead", file=sys.stderr)
     if args.emulate_tp > 1:
         if world > 1:
             raise SystemExit("--emulate-tp is a single-process measurement")
@@ -320,7 +359,7 @@ def main():
         "config": {"workload": f"{args.model} {args.quant} decode, batch {bs} x context {seq} (+{args.warmup}+{args.steps} steps), "
                                f"KV pool filled by a real {bs}x{seq} prefill", "global_batch": bs, "seq_len": seq,
                    "parallelism": f"tp{tp}" + (" (EMULATED: rank 0's shard in one process, collectives = same-size device copies)" if args.emulate_tp > 1 else ""),
-                   "hip_graph": bool(use_graph), "layers": L, "kv_cache_dtype": args.kv_cache_dtype,
+                   "all_reduce": ar_kind, "hip_graph": bool(use_graph), "layers": L, "kv_cache_dtype": args.kv_cache_dtype,
                    "act_dtype": args.dtype},
         "prefill": {"tflops": prefill_flops / prefill_s / 1e12, "seconds": prefill_s, "tokens": bs * seq,
                     "tokens_per_s": bs * seq / prefill_s, "flops": prefill_flops},

@@ -342,6 +342,10 @@ int sgl_mi355_car_free(void* own_ptr);
 int sgl_mi355_car_error(void* own_ptr);
 int sgl_mi355_car_all_reduce(void* inout, int64_t num_elements, int dtype, const void* const* peer_bufs, int rank, int world,
                              int64_t max_bytes, void* stream);
+/* all-gather along the last dimension with the same buffers and protocol (the logits all-gather of a vocab-sharded lm_head,
+ * python/sglang/srt/layers/logits_processor.py:471-500): out [rows, world * row_bytes] <- rank r's in [rows, row_bytes] */
+int sgl_mi355_car_all_gather(const void* in, void* out, int64_t rows, int64_t row_bytes, const void* const* peer_bufs, int rank,
+                             int world, int64_t max_bytes, void* stream);
 
 #ifdef __cplusplus
 }

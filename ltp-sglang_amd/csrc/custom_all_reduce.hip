@@ -41,6 +41,8 @@ struct alignas(128) CarSignal {
 struct CarParams {
   char* buf[kMaxRanks];       // each rank's allocation (signal block first)
   void* inout;
+  void* gather_out;           // all-gather: [rows, world * row_bytes] output; NULL = all-reduce
+  int64_t row16;              // all-gather: 16-byte packets per input row
   int64_t n16;                // 16-byte packets
   int64_t half_bytes;
   int64_t data_off;           // offset of the first data half inside an allocation
@@ -120,8 +122,16 @@ __global__ __launch_bounds__(kThreads) void one_shot_all_reduce_kernel(const Car
     }
   }
   __syncthreads();
+  // 3a. all-gather along the last dimension: out[row][r * row_bytes + ...] = rank r's input row
+  if (!failed && p.gather_out != nullptr) {
+    for (int64_t i = (int64_t)b * kThreads + tid; i < p.n16; i += stride) {
+      const int64_t row = i / p.row16, col = i - row * p.row16;
+      for (int r = 0; r < p.world; ++r)
+        ((u32x4_t*)p.gather_out)[(row * p.world + r) * p.row16 + col] = load_sys(p.buf[r], half + i * 16);
+    }
+  }
   // 3. sum the peers' halves in rank order (identical arithmetic on every rank)
-  if (!failed) {
+  if (!failed && p.gather_out == nullptr) {
     for (int64_t i = (int64_t)b * kThreads + tid; i < p.n16; i += stride) {
       float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       for (int r = 0; r < p.world; ++r) {
@@ -203,6 +213,8 @@ extern "C" int sgl_mi355_car_all_reduce(void* inout, int64_t num_elements, int d
   CarParams p;
   for (int r = 0; r < kMaxRanks; ++r) p.buf[r] = (char*)(r < world ? peer_bufs[r] : peer_bufs[0]);
   p.inout = inout;
+  p.gather_out = nullptr;
+  p.row16 = 1;
   p.n16 = bytes / 16;
   p.half_bytes = max_bytes;
   p.data_off = (int64_t)sizeof(CarSignal);
@@ -215,6 +227,34 @@ extern "C" int sgl_mi355_car_all_reduce(void* inout, int64_t num_elements, int d
   if (dtype == SGL_BF16) hipLaunchKernelGGL((one_shot_all_reduce_kernel<__bf16>), dim3(blocks), dim3(kThreads), 0, st, p);
   else if (dtype == SGL_F16) hipLaunchKernelGGL((one_shot_all_reduce_kernel<_Float16>), dim3(blocks), dim3(kThreads), 0, st, p);
   else hipLaunchKernelGGL((one_shot_all_reduce_kernel<float>), dim3(blocks), dim3(kThreads), 0, st, p);
+  SGL_HIP_LAUNCH_CHECK();
+  return SGL_MI355_OK;
+}
+
+// All-gather along the last dimension through the same buffers and protocol: out [rows, world * row_bytes] receives rank r's
+// contiguous input [rows, row_bytes] at column offset r * row_bytes (the logits all-gather of a vocab-sharded lm_head,
+// python/sglang/srt/layers/logits_processor.py:471-500).  row_bytes % 16 == 0, rows * row_bytes <= max_bytes.
+extern "C" int sgl_mi355_car_all_gather(const void* in, void* out, int64_t rows, int64_t row_bytes, const void* const* peer_bufs,
+                                        int rank, int world, int64_t max_bytes, void* stream) {
+  SGL_CHECK(in && out && peer_bufs, "car_all_gather: null pointer");
+  SGL_CHECK(world >= 2 && world <= kMaxRanks && rank >= 0 && rank < world, "car_all_gather: rank %d / world %d unsupported", rank, world);
+  const int64_t bytes = rows * row_bytes;
+  SGL_CHECK(rows > 0 && row_bytes > 0 && row_bytes % 16 == 0 && bytes <= max_bytes && ((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0,
+            "car_all_gather: rows=%lld row_bytes=%lld must give 16-byte packets within %lld bytes", (long long)rows, (long long)row_bytes,
+            (long long)max_bytes);
+  CarParams p;
+  for (int r = 0; r < kMaxRanks; ++r) p.buf[r] = (char*)(r < world ? peer_bufs[r] : peer_bufs[0]);
+  p.inout = (void*)in;
+  p.gather_out = out;
+  p.row16 = row_bytes / 16;
+  p.n16 = bytes / 16;
+  p.half_bytes = max_bytes;
+  p.data_off = (int64_t)sizeof(CarSignal);
+  p.rank = rank;
+  p.world = world;
+  const int64_t want = (p.n16 + kThreads - 1) / kThreads;
+  const unsigned blocks = (unsigned)(want < 1 ? 1 : (want > kMaxBlocks ? kMaxBlocks : want));
+  hipLaunchKernelGGL((one_shot_all_reduce_kernel<__bf16>), dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, p);
   SGL_HIP_LAUNCH_CHECK();
   return SGL_MI355_OK;
 }

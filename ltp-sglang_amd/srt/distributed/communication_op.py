@@ -85,6 +85,8 @@ def tensor_model_parallel_all_gather(input_: torch.Tensor, dim: int = -1) -> tor
         out = torch.empty(shape, dtype=input_.dtype, device=input_.device)
         out.narrow(dim, 0, input_.shape[dim]).copy_(input_)   # the bytes one rank contributes; the peers' slices stay unwritten
         return out
+    if _CUSTOM_AR is not None and dim == input_.dim() - 1 and _CUSTOM_AR.should_use_gather(input_):
+        return _CUSTOM_AR.all_gather_last_dim(input_)
     if _HOST_STAGED and input_.is_cuda:
         host = input_.contiguous().cpu()
         parts = [torch.empty_like(host) for _ in range(_TP_SIZE)]

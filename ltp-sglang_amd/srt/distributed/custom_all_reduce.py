@@ -72,6 +72,20 @@ class CustomAllreduce:
 
     custom_all_reduce = all_reduce
 
+    def should_use_gather(self, inp: torch.Tensor) -> bool:
+        if self.disabled or not inp.is_cuda or not inp.is_contiguous() or inp.dim() < 1:
+            return False
+        row_bytes = inp.shape[-1] * inp.element_size()
+        return row_bytes % 16 == 0 and 0 < inp.numel() * inp.element_size() <= self.max_size and inp.data_ptr() % 16 == 0
+
+    def all_gather_last_dim(self, inp: torch.Tensor) -> torch.Tensor:
+        """Concatenation of every rank's ``inp`` along the last dimension (one kernel, same buffers and flags)."""
+        rows = inp.numel() // inp.shape[-1]
+        out = torch.empty(inp.shape[:-1] + (inp.shape[-1] * self.world_size,), dtype=inp.dtype, device=inp.device)
+        check(lib.sgl_mi355_car_all_gather(inp.data_ptr(), out.data_ptr(), rows, inp.shape[-1] * inp.element_size(), self._ptrs,
+                                           self.rank, self.world_size, self.max_size, current_stream()))
+        return out
+
     def check_error(self) -> None:
         """Raises if a peer failed to arrive within the kernel's spin bound since the last check (synchronises)."""
         if self.disabled:

@@ -79,6 +79,14 @@ def _worker(rank, world, port, q):
     y = comm.tensor_model_parallel_all_reduce(y)
     car.check_error()
     ok = ok and bool((y == float(world * (world + 1) // 2)).all())
+    # all-gather along the last dimension (the vocab-sharded logits), through the call site as well
+    for shape in ((32, 16032), (3, 8), (128, 2048)):
+        part = torch.randn(shape, generator=torch.Generator().manual_seed(7 + rank)).to(torch.bfloat16)
+        parts = [torch.empty_like(part) for _ in range(world)]
+        dist.all_gather(parts, part)
+        got = comm.tensor_model_parallel_all_gather(part.to(dev))
+        car.check_error()
+        ok = ok and torch.equal(got.cpu(), torch.cat(parts, dim=-1))
     # HIP graph: capture one all-reduce, replay it on fresh operands
     z = torch.zeros((32, 4096), dtype=torch.bfloat16, device=dev)
     side = torch.cuda.Stream()
