@@ -176,7 +176,7 @@ def main():
 
     comm.init_tensor_parallel()
     ar_kind = "none" if world == 1 else "rccl"
-    if world > 1 and args.dist_backend == "nccl" and args.all_reduce != "rccl":
+    if world > 1 and args.all_reduce != "rccl" and (args.dist_backend == "nccl" or args.all_reduce == "p2p"):
         # one-shot P2P all-reduce / all-gather (custom_all_reduce_hip.cuh:261-294 in the reference): IPC handles travel over a
         # gloo side group; before it is trusted, one all-reduce and one all-gather are compared with RCCL's results on every rank
         import torch.distributed as dist
@@ -185,13 +185,14 @@ def main():
 
         ok, why = True, ""
         try:
-            car = CustomAllreduce(dist.new_group(backend="gloo"), torch.device(dev))
+            # (gloo rehearsal on one GPU: the WORLD group is already a CPU group)
+            car = CustomAllreduce(dist.new_group(backend="gloo") if args.dist_backend == "nccl" else dist.group.WORLD, torch.device(dev))
             ok = not car.disabled
             why = "" if ok else f"world size {world} unsupported"
             if ok:
                 probe = torch.randn(32, 4096, device=dev, generator=torch.Generator(device=dev).manual_seed(rank)).to(torch.bfloat16)
                 want = probe.float()
-                dist.all_reduce(want)   # f32 sum over RCCL; the P2P kernel also accumulates in f32 and rounds once
+                want = comm.tensor_model_parallel_all_reduce(want)   # f32 sum over RCCL (gloo rehearsal: host-staged); the P2P kernel also accumulates in f32
                 got = car.all_reduce(probe.clone())
                 car.check_error()
                 ok = bool(((got.float() - want).abs() <= 0.02 * want.abs() + 0.05).all())
@@ -202,7 +203,7 @@ def main():
                 why = "" if ok else "self-check against RCCL failed"
         except Exception as e:   # IPC not available between these devices, driver limits, ...
             ok, why = False, f"{type(e).__name__}: {e}"
-        flag = torch.tensor([1 if ok else 0], device=dev)
+        flag = torch.tensor([1 if ok else 0], device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)   # all ranks or none
         if int(flag.item()) == 1:
             comm.set_custom_all_reduce(car)
