@@ -100,6 +100,12 @@ __device__ __forceinline__ float softcap_log2(float s_scaled, float cap) {
   return cap * t * kLog2e;
 }
 
+// Memory-model note: the hand-off below is the first row of the "hand-offs measured with sc1 loads / one agent-scope atomic
+// add per storing workgroup" table of the CDNA4 guide (MI355X_MICROARCH.md, Workgroup dispatch ... inter-workgroup visibility)
+// with the consumer's acquire KEPT (two workgroups per CU are resident, outside that table's one-per-CU cell): every byte is
+// stored sc1 (write-through), every storing wave drains vmcnt before the workgroup barrier, ONE lane then adds to the counter,
+// and the workgroup whose add returned total - 1 runs ONE agent-scope acquire before any wave loads the partials.  The counters
+// are re-zeroed by the host side once per decode step (HipAttnBackend._decode_metadata), so a stale count cannot persist.
 // In-launch stage 2 (cross-workgroup hand-off in its counter form): every workgroup of request b publishes its split
 // partial -- WRITE-THROUGH (sc1) stores, so no release fence (a release per workgroup writes back the XCD's L2 and made the
 // launch 35 us slower); every wave drains vmcnt, barrier, then lane 0 draws a ticket -- and the workgroup that draws the

@@ -79,6 +79,7 @@ class HipAttnBackend(AttentionBackend):
         gpu_id = getattr(model_runner, "gpu_id", 0)
         self.device_core_count = lib.sgl_mi355_device_cu_count(int(gpu_id))  # 256 on MI355X
         self.forward_metadata: Optional[ForwardMetadata] = None
+        self.merge_in_launch = True   # forward_decode: stage 2 by the last workgroup of each request (False = two kernels)
         self._graph = None
         # counters of the in-launch stage-2 merge (one per request slot; allocated eagerly so graph capture never allocates)
         self.max_bs_hint = int(model_runner.req_to_token_pool.size)
@@ -109,6 +110,10 @@ class HipAttnBackend(AttentionBackend):
             attn_lse = torch.empty((bs, self.num_head, self.max_kv_splits), dtype=torch.float32, device=self.device)
         else:
             num_kv_splits, attn_logits, attn_lse = scratch
+        # the in-launch merge leaves its per-request tickets at zero; re-zeroing them once per step makes that self-healing
+        # (an aborted launch or a foreign write would otherwise disable the merge of that request for good)
+        if self._merge_counters is not None:
+            self._merge_counters.zero_()
         # one launch: kv_indptr[1:bs+1] = cumsum(seq_lens) and the per-request split heuristic
         K.decode_metadata(kv_indptr, num_kv_splits, seq_lens, 1, self.num_head, self.num_kv_head, self.max_kv_splits,
                           self.device_core_count, self.static_kv_splits)
@@ -269,6 +274,17 @@ class HipAttnBackend(AttentionBackend):
         md = self.forward_metadata
         if md.cascade_prefix_indices is not None:
             return self._forward_decode_cascade(q, layer, forward_batch, want_o=True, want_quant=False)[0]
+        if self.merge_in_launch and layer.qk_head_dim == layer.v_head_dim and layer.v_head_dim in (64, 128) \
+                and layer.tp_q_head_num * layer.v_head_dim <= 16384:
+            # stage 2 inside the stage-1 launch (the last workgroup of each request merges its splits): one launch instead of
+            # two, bit-identical to the two-kernel sequence (tests/test_decode_attention_gpu.py)
+            return K.decode_attention_merge_quant(
+                q.view(-1, layer.tp_q_head_num, layer.qk_head_dim),
+                forward_batch.token_to_kv_pool.get_key_buffer(layer.layer_id),
+                forward_batch.token_to_kv_pool.get_value_buffer(layer.layer_id),
+                kv_indptr, kv_indices, md.attn_logits, md.attn_lse, num_kv_splits, self.max_kv_splits, layer.scaling,
+                self._merge_counter_buf(q), layer.logit_cap, layer.k_scale_float or 1.0, layer.v_scale_float or 1.0,
+                want_o=True, want_quant=False)[0]
         o = q.new_empty((q.shape[0], layer.tp_q_head_num * layer.v_head_dim))
         K.decode_attention_fwd(
             q.view(-1, layer.tp_q_head_num, layer.qk_head_dim),
