@@ -342,6 +342,13 @@ int sgl_mi355_car_free(void* own_ptr);
 int sgl_mi355_car_error(void* own_ptr);
 int sgl_mi355_car_all_reduce(void* inout, int64_t num_elements, int dtype, const void* const* peer_bufs, int rank, int world,
                              int64_t max_bytes, void* stream);
+/* The all-reduce of a row-parallel linear fused with what follows it on the decode path (linear.py:1302-1303 ->
+ * layernorm.py:135-171 -> per_token_quant_fp8.cu): x = all_reduce(partial); residual += x; y = rmsnorm(residual) * weight;
+ * optional out_norm (T) and out_q / out_s.  Bit-identical to sgl_mi355_car_all_reduce + sgl_mi355_fused_add_rmsnorm_quant_fp8. */
+int sgl_mi355_car_all_reduce_add_rmsnorm_quant(const void* partial, void* residual, const void* weight, float eps,
+                                               void* out_norm, void* out_q, float* out_s, int rows, int hidden, int dtype,
+                                               const void* const* peer_bufs, int rank, int world, int64_t max_bytes,
+                                               void* stream);
 /* all-gather along the last dimension with the same buffers and protocol (the logits all-gather of a vocab-sharded lm_head,
  * python/sglang/srt/layers/logits_processor.py:471-500): out [rows, world * row_bytes] <- rank r's in [rows, row_bytes] */
 int sgl_mi355_car_all_gather(const void* in, void* out, int64_t rows, int64_t row_bytes, const void* const* peer_bufs, int rank,

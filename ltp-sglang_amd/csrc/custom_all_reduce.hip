@@ -23,7 +23,7 @@
 //  * every spin is bounded: a peer that never arrives sets the signal block's error word instead of hanging the GPU.
 //  * block b of every rank copies and reduces the SAME element range, so a block only ever reads data that the matching block
 //    of a peer published before raising the flag it waits on.
-#include "common.h"
+#include "row_helpers.h"
 
 namespace {
 
@@ -144,6 +144,117 @@ __global__ __launch_bounds__(kThreads) void one_shot_all_reduce_kernel(const Car
   if (tid == 0) me->epoch[b] = epoch;
 }
 
+// All-reduce fused with the op sequence that follows it on the decode path (linear.py:1302-1303 -> layernorm.py:135-171 ->
+// per_token_quant_fp8.cu): x = all_reduce(partial); residual += x; y = rmsnorm(residual) * w; (y_q, y_s) = per-token fp8 quant.
+// One 256-thread workgroup per token row (rows beyond the grid are walked with a stride); block b exchanges flags with block b
+// of every peer exactly as the plain kernel does, so the row a block sums is the row the peers' matching blocks published.
+// Arithmetic = the plain all-reduce's (f32 sum in rank order, one rounding to T) followed by add_rmsnorm_quant_kernel's, so the
+// result is bit-identical to the unfused pair; what it removes is one launch and one [M, hidden] round trip per all-reduce site.
+struct CarNormParams {
+  char* buf[kMaxRanks];
+  const void* partial;   // [rows, hidden] T: this rank's partial sums
+  void* residual;        // [rows, hidden] T, updated in place (may be NULL: no residual add)
+  const void* weight;    // [hidden] T
+  void* out_norm;        // optional [rows, hidden] T
+  uint8_t* out_q;        // optional [rows, hidden] e4m3
+  float* out_s;          // [rows]
+  int64_t half_bytes, data_off;
+  int rows, hidden;
+  float eps;
+  int rank, world;
+};
+
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256) void all_reduce_add_rmsnorm_quant_kernel(const CarNormParams p) {
+  __shared__ float red[4];
+  __shared__ int failed;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  CarSignal* me = (CarSignal*)p.buf[p.rank];
+  const uint32_t epoch = me->epoch[b] + 1;
+  const int64_t half = p.data_off + (int64_t)(epoch & 1u) * p.half_bytes;
+  const int nvec = p.hidden / 8;
+  // 1. publish this rank's rows b, b + grid, ...
+  for (int row = b; row < p.rows; row += gridDim.x)
+#pragma unroll
+    for (int it = 0; it < MAXV; ++it) {
+      const int i = tid + it * 256;
+      if (i < nvec) store_sys(p.buf[p.rank], half + ((int64_t)row * nvec + i) * 16, *((const u32x4_t*)p.partial + (int64_t)row * nvec + i));
+    }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (tid == 0) failed = 0;
+  __syncthreads();
+  if (tid < p.world) {
+    CarSignal* peer = (CarSignal*)p.buf[tid];
+    __hip_atomic_store(&peer->flag[b][p.rank], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    uint32_t spins = 0;
+    while ((int32_t)(__hip_atomic_load(&me->flag[b][tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > kSpinLimit) {
+        failed = 1;
+        me->error = 1u;
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  if (!failed) {
+    for (int row = b; row < p.rows; row += gridDim.x) {
+      // operands first (norm weight, residual, every peer's packet), then the arithmetic of the two unfused kernels
+      V8<T> wreg[MAXV], rreg[MAXV];
+      float vals[MAXV][8];
+      float ss = 0.f;
+#pragma unroll
+      for (int it = 0; it < MAXV; ++it) {
+        const int i = tid + it * 256;
+        const int ic = i < nvec ? i : 0;
+        wreg[it] = ld8((const T*)p.weight + ic * 8);
+        if (p.residual) rreg[it] = ld8((const T*)p.residual + (int64_t)row * p.hidden + ic * 8);
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < p.world; ++r) accumulate<T>(acc, load_sys(p.buf[r], half + ((int64_t)row * nvec + ic) * 16));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) vals[it][j] = round_via<T>(acc[j]);   // = the all-reduce's output element
+      }
+#pragma unroll
+      for (int it = 0; it < MAXV; ++it) {
+        const int i = tid + it * 256;
+        if (i < nvec) {
+          if (p.residual) {
+            V8<T> ro;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              vals[it][j] += (float)rreg[it].v[j];
+              ro.v[j] = (T)vals[it][j];
+            }
+            st8((T*)p.residual + (int64_t)row * p.hidden + i * 8, ro);
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) ss += vals[it][j] * vals[it][j];
+        }
+      }
+      const float var = block_sum(ss, red) / (float)p.hidden;
+      const float rs = 1.0f / sqrtf(var + p.eps);
+#pragma unroll
+      for (int it = 0; it < MAXV; ++it) {
+        const int i = tid + it * 256;
+        if (i < nvec) {
+          V8<T> o;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            vals[it][j] = round_via<T>((vals[it][j] * rs) * (float)wreg[it].v[j]);
+            o.v[j] = (T)vals[it][j];
+          }
+          if (p.out_norm) st8((T*)p.out_norm + (int64_t)row * p.hidden + i * 8, o);
+        }
+      }
+      if (p.out_q) quant_row<MAXV>(vals, nvec, p.out_q + (int64_t)row * p.hidden, p.out_s + row, red);
+      __syncthreads();   // red is reused by the next row
+    }
+  }
+  __syncthreads();
+  if (tid == 0) me->epoch[b] = epoch;
+}
+
 }  // namespace
 
 // Allocates a rank's uncached buffer (signal block + two data halves of max_bytes each), zeroes the signal block and
@@ -255,6 +366,39 @@ extern "C" int sgl_mi355_car_all_gather(const void* in, void* out, int64_t rows,
   const int64_t want = (p.n16 + kThreads - 1) / kThreads;
   const unsigned blocks = (unsigned)(want < 1 ? 1 : (want > kMaxBlocks ? kMaxBlocks : want));
   hipLaunchKernelGGL((one_shot_all_reduce_kernel<__bf16>), dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, p);
+  SGL_HIP_LAUNCH_CHECK();
+  return SGL_MI355_OK;
+}
+
+// x = all_reduce(partial) ; residual += x (in place, when given) ; y = rmsnorm(residual or x) * weight ; optional outputs
+// out_norm (T) and out_q / out_s (per-token e4m3 + f32 scale): sgl_mi355_car_all_reduce followed by
+// sgl_mi355_fused_add_rmsnorm_quant_fp8 in one launch, bit-identical to that pair.  rows * hidden * 2 <= max_bytes,
+// hidden % 8 == 0, hidden <= 8192.
+extern "C" int sgl_mi355_car_all_reduce_add_rmsnorm_quant(const void* partial, void* residual, const void* weight, float eps,
+                                                          void* out_norm, void* out_q, float* out_s, int rows, int hidden,
+                                                          int dtype, const void* const* peer_bufs, int rank, int world,
+                                                          int64_t max_bytes, void* stream) {
+  SGL_CHECK(partial && weight && peer_bufs && (out_norm || out_q) && (!out_q || out_s), "car_all_reduce_add_rmsnorm_quant: null pointer");
+  SGL_CHECK(world >= 2 && world <= kMaxRanks && rank >= 0 && rank < world, "car_all_reduce_add_rmsnorm_quant: rank %d / world %d unsupported", rank, world);
+  SGL_CHECK(dtype == SGL_BF16 || dtype == SGL_F16, "car_all_reduce_add_rmsnorm_quant: dtype must be bf16 or f16");
+  SGL_CHECK(rows > 0 && hidden > 0 && hidden % 8 == 0 && hidden <= 8192 && (int64_t)rows * hidden * 2 <= max_bytes &&
+                ((uintptr_t)partial % 16) == 0,
+            "car_all_reduce_add_rmsnorm_quant: rows=%d hidden=%d unsupported (hidden %% 8, <= 8192, rows * hidden * 2 <= %lld)", rows,
+            hidden, (long long)max_bytes);
+  CarNormParams p;
+  for (int r = 0; r < kMaxRanks; ++r) p.buf[r] = (char*)(r < world ? peer_bufs[r] : peer_bufs[0]);
+  p.partial = partial; p.residual = residual; p.weight = weight; p.out_norm = out_norm; p.out_q = (uint8_t*)out_q; p.out_s = out_s;
+  p.half_bytes = max_bytes; p.data_off = (int64_t)sizeof(CarSignal);
+  p.rows = rows; p.hidden = hidden; p.eps = eps; p.rank = rank; p.world = world;
+  const unsigned blocks = (unsigned)(rows > kMaxBlocks ? kMaxBlocks : rows);
+  hipStream_t st = (hipStream_t)stream;
+#define SGL_CARN(Tt, MV) hipLaunchKernelGGL((all_reduce_add_rmsnorm_quant_kernel<Tt, MV>), dim3(blocks), dim3(256), 0, st, p)
+  if (dtype == SGL_BF16) {
+    if (hidden <= 2048) SGL_CARN(__bf16, 1); else if (hidden <= 4096) SGL_CARN(__bf16, 2); else SGL_CARN(__bf16, 4);
+  } else {
+    if (hidden <= 2048) SGL_CARN(_Float16, 1); else if (hidden <= 4096) SGL_CARN(_Float16, 2); else SGL_CARN(_Float16, 4);
+  }
+#undef SGL_CARN
   SGL_HIP_LAUNCH_CHECK();
   return SGL_MI355_OK;
 }

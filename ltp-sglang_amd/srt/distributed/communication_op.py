@@ -73,6 +73,19 @@ def tensor_model_parallel_all_reduce(input_: torch.Tensor) -> torch.Tensor:
     return input_
 
 
+def tensor_model_parallel_all_reduce_add_rmsnorm_quant(partial, residual, weight, eps, want_norm=False, want_quant=True):
+    """The all-reduce of a row-parallel linear together with the fused add + RMSNorm (+ per-token fp8 quant) that consumes it
+    on the decode path: one launch when the one-shot P2P communicator can take the message, the unfused pair otherwise (same
+    bits either way).  ``residual`` is updated in place.  Returns (y or None, y_q or None, y_scale or None)."""
+    from ...sgl_kernel import fused_add_rmsnorm_quant_fp8
+
+    if _TP_SIZE > 1 and not _EMULATED and _CUSTOM_AR is not None and _CUSTOM_AR.should_use_fused_norm(partial):
+        return _CUSTOM_AR.all_reduce_add_rmsnorm_quant(partial, residual, weight, eps, want_norm, want_quant)
+    if not _EMULATED:   # (emulated TP: the fused kernel's cost is the norm kernel's -- the stand-in copy is dropped with the launch)
+        partial = tensor_model_parallel_all_reduce(partial)
+    return fused_add_rmsnorm_quant_fp8(partial, residual, weight, eps, want_norm=want_norm, want_quant=want_quant)
+
+
 def tensor_model_parallel_all_gather(input_: torch.Tensor, dim: int = -1) -> torch.Tensor:
     """Concatenate shards along ``dim`` (logits all-gather, logits_processor.py:471-500)."""
     if _TP_SIZE == 1:

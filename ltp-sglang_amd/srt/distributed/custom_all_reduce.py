@@ -72,6 +72,25 @@ class CustomAllreduce:
 
     custom_all_reduce = all_reduce
 
+    def should_use_fused_norm(self, partial: torch.Tensor) -> bool:
+        return (self.should_use(partial) and partial.dim() == 2 and partial.dtype in (torch.bfloat16, torch.float16)
+                and partial.shape[1] % 8 == 0 and partial.shape[1] <= 8192)
+
+    def all_reduce_add_rmsnorm_quant(self, partial, residual, weight, eps, want_norm=False, want_quant=True):
+        """all_reduce(partial) -> residual += . -> rmsnorm * weight -> per-token fp8 quant, ONE launch, bit-identical to the
+        unfused pair.  Returns (y or None, y_q or None, y_scale [M, 1] or None); ``residual`` is updated in place."""
+        m, h = partial.shape
+        dev = partial.device
+        out_norm = torch.empty((m, h), dtype=partial.dtype, device=dev) if want_norm else None
+        out_q = torch.empty((m, h), dtype=torch.float8_e4m3fn, device=dev) if want_quant else None
+        out_s = torch.empty((m, 1), dtype=torch.float32, device=dev) if want_quant else None
+        check(lib.sgl_mi355_car_all_reduce_add_rmsnorm_quant(
+            partial.data_ptr(), None if residual is None else residual.data_ptr(), weight.data_ptr(), float(eps),
+            None if out_norm is None else out_norm.data_ptr(), None if out_q is None else out_q.data_ptr(),
+            None if out_s is None else out_s.data_ptr(), m, h, dtype_code(partial.dtype), self._ptrs, self.rank, self.world_size,
+            self.max_size, current_stream()))
+        return out_norm, out_q, out_s
+
     def should_use_gather(self, inp: torch.Tensor) -> bool:
         if self.disabled or not inp.is_cuda or not inp.is_contiguous() or inp.dim() < 1:
             return False

@@ -260,7 +260,8 @@ class LlamaForCausalLM(nn.Module):
         sequence it replaces, so this path and forward() give the same logits.  Under tensor parallelism the two
         row-parallel outputs are materialised and all-reduced at the reference's call sites (linear.py:1302-1303); the
         split-K slab hand-off is a single-rank shortcut."""
-        from ..distributed.communication_op import tensor_model_parallel_all_gather, tensor_model_parallel_all_reduce
+        from ..distributed.communication_op import (tensor_model_parallel_all_gather,
+                                                    tensor_model_parallel_all_reduce_add_rmsnorm_quant as ar_norm_quant)
 
         tp = self.tp_size
         pool = forward_batch.token_to_kv_pool
@@ -274,6 +275,10 @@ class LlamaForCausalLM(nn.Module):
             if residual is None:
                 _, xq, xs = K.fused_add_rmsnorm_quant_fp8(hidden, None, ln1.weight.data, ln1.variance_epsilon)
                 residual = hidden
+            elif slabs is None and tp > 1:
+                # `hidden` is this rank's PARTIAL down_proj output: its all-reduce (linear.py:1302-1303) rides in the same
+                # launch as the add + RMSNorm + quant that consumes it (one-shot P2P communicator; else the unfused pair)
+                _, xq, xs = ar_norm_quant(hidden, residual, ln1.weight.data, ln1.variance_epsilon)
             elif slabs is None:
                 _, xq, xs = K.fused_add_rmsnorm_quant_fp8(hidden, residual, ln1.weight.data, ln1.variance_epsilon)
             else:
@@ -304,10 +309,11 @@ class LlamaForCausalLM(nn.Module):
                 _, oq, osc = K.decode_merge_quant_fp8(md.attn_logits, md.attn_lse, md.kv_indptr, md.num_kv_splits,
                                                       backend.max_kv_splits, self.dtype)
             attn_out = K.fp8_scaled_mm(oq, attn.o_proj.weight, osc.view(-1), attn.o_proj.weight_scale.view(-1), self.dtype)
-            if tp > 1:
-                attn_out = tensor_model_parallel_all_reduce(attn_out)
             ln2 = layer.post_attention_layernorm
-            _, hq2, hs2 = K.fused_add_rmsnorm_quant_fp8(attn_out, residual, ln2.weight.data, ln2.variance_epsilon)
+            if tp > 1:   # partial sums: all-reduce + add + RMSNorm + quant in one launch
+                _, hq2, hs2 = ar_norm_quant(attn_out, residual, ln2.weight.data, ln2.variance_epsilon)
+            else:
+                _, hq2, hs2 = K.fused_add_rmsnorm_quant_fp8(attn_out, residual, ln2.weight.data, ln2.variance_epsilon)
             if fw is not None:   # gate_up GEMM with the SiluAndMul epilogue, then the per-token quantisation
                 act = K.fp8_gemm_silu_mul(hq2, hs2.view(-1), fw["gu_w"], fw["gu_s"], self.dtype, fw["gu_tile"])
                 aq, asc = K.sglang_per_token_quant_fp8(act)
@@ -319,12 +325,14 @@ class LlamaForCausalLM(nn.Module):
                 slabs = K.fp8_linear_slabs(aq, wd.t(), m, wd.shape[1], wd.shape[0])
                 slab_sx, slab_sw = asc.view(-1), mlp.down_proj.weight_scale.view(-1)
             else:
-                hidden = K.fp8_scaled_mm(aq, wd, asc.view(-1), mlp.down_proj.weight_scale.view(-1), self.dtype)
-                hidden = tensor_model_parallel_all_reduce(hidden)
+                hidden = K.fp8_scaled_mm(aq, wd, asc.view(-1), mlp.down_proj.weight_scale.view(-1), self.dtype)   # (tp > 1: partial)
         if slabs is not None:
             hidden, _, _ = K.fused_add_rmsnorm_quant_fp8(None, residual, self.norm.weight.data, self.norm.variance_epsilon,
                                                          slabs=slabs, slab_sx=slab_sx, slab_sw=slab_sw, want_norm=True,
                                                          want_quant=False, dtype=self.dtype)
+        elif tp > 1:
+            hidden, _, _ = ar_norm_quant(hidden, residual, self.norm.weight.data, self.norm.variance_epsilon, want_norm=True,
+                                         want_quant=False)
         else:
             hidden, _, _ = K.fused_add_rmsnorm_quant_fp8(hidden, residual, self.norm.weight.data, self.norm.variance_epsilon,
                                                          want_norm=True, want_quant=False)

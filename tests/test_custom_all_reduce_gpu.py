@@ -79,6 +79,29 @@ def _worker(rank, world, port, q):
     y = comm.tensor_model_parallel_all_reduce(y)
     car.check_error()
     ok = ok and bool((y == float(world * (world + 1) // 2)).all())
+    # all-reduce fused with add + RMSNorm + per-token quant == the unfused pair, bit for bit (both TP all-reduce sites of a layer)
+    from ltp_sglang_amd import sgl_kernel as K
+
+    for (m, h), dtype in (((32, 4096), torch.bfloat16), ((7, 1024), torch.float16), ((128, 8192), torch.bfloat16), ((70, 512), torch.bfloat16)):
+        g = torch.Generator().manual_seed(31 * m + rank)
+        part = torch.randn(m, h, generator=g).to(dtype).to(dev)
+        g2 = torch.Generator().manual_seed(5)   # residual and weight are replicated across ranks
+        res0 = torch.randn(m, h, generator=g2).to(dtype).to(dev)
+        w = (1 + 0.1 * torch.randn(h, generator=g2)).to(dtype).to(dev)
+        summed = car.all_reduce(part.clone())
+        res_a = res0.clone()
+        ya, qa, sa = K.fused_add_rmsnorm_quant_fp8(summed, res_a, w, 1e-5, want_norm=True, want_quant=True)
+        res_b = res0.clone()
+        yb, qb, sb = comm.tensor_model_parallel_all_reduce_add_rmsnorm_quant(part.clone(), res_b, w, 1e-5, want_norm=True, want_quant=True)
+        car.check_error()
+        same = (torch.equal(ya, yb) and torch.equal(qa.view(torch.uint8), qb.view(torch.uint8)) and torch.equal(sa, sb)
+                and torch.equal(res_a, res_b))
+        if not same:
+            print(f"[rank {rank}] fused all-reduce + norm differs at {(m, h)} {dtype}", flush=True)
+        ok = ok and same
+        yc, _, _ = comm.tensor_model_parallel_all_reduce_add_rmsnorm_quant(part.clone(), None, w, 1e-5, want_norm=True, want_quant=False)
+        yd, _, _ = K.fused_add_rmsnorm_quant_fp8(summed, None, w, 1e-5, want_norm=True, want_quant=False)
+        ok = ok and torch.equal(yc, yd)
     # all-gather along the last dimension (the vocab-sharded logits), through the call site as well
     for shape in ((32, 16032), (3, 8), (128, 2048)):
         part = torch.randn(shape, generator=torch.Generator().manual_seed(7 + rank)).to(torch.bfloat16)
