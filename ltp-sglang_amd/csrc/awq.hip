@@ -194,7 +194,7 @@ __global__ __launch_bounds__(kAwqWaves * 64, 1) void awq_gemm_kernel(const AwqGe
       const bool bok = w + kAwqWaves * bi < nb;
       const int b = b0 + (bok ? w + kAwqWaves * bi : 0);
       const unsigned off = (j < cnt && bok) ? (unsigned)((((int64_t)t * p.KB + b) * 64 + lane) * 16) : 0xFFFFFFF0u;
-      wreg[slot][bi] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off, 0, 0));
+      wreg[slot][bi] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off, 0, 2));  // nt: read once
 #pragma unroll
       for (int q = 0; q < SG; ++q) {
         const int grp = (128 * b + (128 / SG) * q) / p.G;

@@ -303,7 +303,9 @@ __global__ __launch_bounds__(NWV * 64, 1) void skinny_gemm_v2_kernel(const Skinn
     for (int i = 0; i < DS; ++i) {
       const int row = (i < nload) ? lr + RPI * i : lr;  // (8-row tiles: the upper half re-reads row lr, an L1 hit)
       const unsigned off = (j < cnt && kok) ? (unsigned)((int64_t)min(n0t + row, p.N - 1) * p.w_stride) + koff : 0xFFFFFFF0u;
-      wreg[slot][i] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off, 0, 0));
+      // cache policy 2 = nt: each weight byte is read by ONE CU, once per decode step (MI355X_MICROARCH.md "nt-weights").
+      // Same-box A/B (round 2): decode step 4.58 -> 4.49 ms from this alone, 4.58 -> 4.28 ms together with the nt K/V gather.
+      wreg[slot][i] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off, 0, 2));
     }
   };
 #pragma unroll
