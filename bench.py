@@ -46,6 +46,7 @@ def parse_args():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prefill-chunk", type=int, default=8, help="requests per prefill call")
+    ap.add_argument("--gemm-hook", type=int, default=0, help="measurement hook: value passed to sgl_mi355_fp8_gemm_force_tile")
     ap.add_argument("--max-kv-splits", type=int, default=16, help="triton_attention_num_kv_splits (16 = the reference's HIP default)")
     ap.add_argument("--all-reduce", default="auto", choices=["auto", "rccl", "p2p"],
                     help="N > 1: auto = the one-shot P2P all-reduce over IPC-mapped peer buffers when its start-up self-check against "
@@ -217,6 +218,10 @@ def main():
         if world > 1:
             raise SystemExit("--emulate-tp is a single-process measurement")
         comm.init_emulated_tensor_parallel(args.emulate_tp)
+    if args.gemm_hook:
+        from ltp_sglang_amd import _cabi
+
+        _cabi.check(_cabi.lib.sgl_mi355_fp8_gemm_force_tile(args.gemm_hook))
     if args.decode_attn_mode >= 0:
         from ltp_sglang_amd import _cabi
 
