@@ -350,7 +350,9 @@ __device__ __forceinline__ void epilogue_scaled_lds(const GemmParams& p, const f
     const int row = 8 * it + rsub;
     const u32x4_t v = *(const u32x4_t*)(wave_lds + row * kEpiRowB + ((c16 ^ (row & 7)) << 4));
     const int m = mrow_base + row;
-    if (m < p.M && col_ok) *(u32x4_t*)((OutT*)p.y + (int64_t)m * p.y_stride + ncol_base + 8 * c16) = v;
+    // NON-TEMPORAL stores: the output (hundreds of MB per prefill GEMM) is not read again by this launch and would otherwise
+    // displace the X / W panels that the other tiles of the XCD re-read from L2.  Same-box A/B (round 2): prefill 1 946 -> 2 000 TFLOP/s.
+    if (m < p.M && col_ok) __builtin_nontemporal_store(v, (u32x4_t*)((OutT*)p.y + (int64_t)m * p.y_stride + ncol_base + 8 * c16));
   }
 }
 
