@@ -47,6 +47,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prefill-chunk", type=int, default=8, help="requests per prefill call")
     ap.add_argument("--gemm-hook", type=int, default=0, help="measurement hook: value passed to sgl_mi355_fp8_gemm_force_tile")
+    ap.add_argument("--kv-split-rule", type=int, default=2, help="0 = the reference's heuristic, 1 = max splits everywhere, 2 = the MI355X balance rule")
     ap.add_argument("--max-kv-splits", type=int, default=16, help="triton_attention_num_kv_splits (16 = the reference's HIP default)")
     ap.add_argument("--all-reduce", default="auto", choices=["auto", "rccl", "p2p"],
                     help="N > 1: auto = the one-shot P2P all-reduce over IPC-mapped peer buffers when its start-up self-check against "
@@ -237,7 +238,7 @@ def main():
                                   max_total_tokens=bs * (seq + total_steps) + 64, device=dev, seed=0,
                                   dtype=torch.float16 if args.dtype == "f16" else torch.bfloat16,
                                   kv_cache_dtype=torch.float8_e4m3fn if args.kv_cache_dtype == "fp8_e4m3" else None,
-                                  max_kv_splits=args.max_kv_splits)
+                                  max_kv_splits=args.max_kv_splits, kv_split_rule=args.kv_split_rule)
     kv_es = 1 if args.kv_cache_dtype == "fp8_e4m3" else 2
     tp = comm.get_tensor_model_parallel_world_size()
 
