@@ -161,9 +161,10 @@ __device__ __forceinline__ void cvt16_fp8(const u32x4_t& in, u32x4_t& lo, u32x4_
 //         units of one request with the kv head fastest, so they read ADJACENT 256-byte pieces of the same token rows
 //         at about the same time (whole 2-KiB token rows per workgroup instead of scattered 256-byte pieces) and no
 //         barrier or cross-wave merge exists at all.
-// KVB: bytes per pool element (1 = e4m3 KV cache, converted on the way into LDS).  CASC: the cascade (shared-prefix) forms of
+// KVB: bytes per pool element (1 = e4m3 KV cache, converted on the way into LDS).  CASC: 1 = the cascade (shared-prefix) PREFIX
+// pass (its rows are re-read by every 16-column chunk of a kv head: default cache policy), 2 = the SUFFIX pass; the forms of
 // MODE 0 -- their extra index arithmetic stays out of the ordinary instantiation (it cost 28 spilled SGPRs there).
-template <typename T, int D, int NW, int MODE, int KVB = 2, bool CASC = false>
+template <typename T, int D, int NW, int MODE, int KVB = 2, int CASC = 0>
 __global__ __launch_bounds__(NW * 64, 2) void decode_attn_stage1(const DecodeParams p) {
   using Tr = ElemTraits<T>;
   using vec8 = typename Tr::vec8;
@@ -187,8 +188,8 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attn_stage1(const DecodePar
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool shared = CASC && p.shared_reqs > 0;                  // cascade prefix pass (wave-uniform)
-  const int split_base = CASC ? p.split_base : 0;
+  constexpr bool shared = CASC == 1;                              // cascade prefix pass
+  const int split_base = CASC == 2 ? p.split_base : 0;
   const int vgroup = shared ? p.shared_reqs * p.group : p.group;  // query columns that share one kv head's K/V rows
   const int hchunks = (vgroup + 15) >> 4;
   int khc, split;
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attn_stage1(const DecodePar
   const int end = min(start + per, seq_len);
   if (start >= end) {
     if constexpr (MODE == 0) {  // an empty split still counts as arrived for the in-launch merge (uniform per workgroup)
-      if (p.merge_cnt) arrive_and_merge<T, CASC>(p, b, seq_len, nsplit, hchunks, smem);
+      if (p.merge_cnt) arrive_and_merge<T, CASC != 0>(p, b, seq_len, nsplit, hchunks, smem);
     }
     return;
   }
@@ -282,8 +283,13 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attn_stage1(const DecodePar
       // NON-TEMPORAL loads: every K/V row is read once per decode step, so keeping it in L2 / the Infinity Cache only
       // evicts what the step re-reads (activations, split partials) and lengthens the miss path.  Same-box A/B at the
       // BASELINE shape (round 2): stage 1 55.0 -> 50.3 us per launch (4.9 -> 5.4 TB/s), decode step 4.55 -> 4.39 ms.
-      kreg[i] = __builtin_nontemporal_load((const u32x4_t*)(kbase + (int64_t)id * kst));
-      vreg[i] = __builtin_nontemporal_load((const u32x4_t*)(vbase + (int64_t)id * vst));
+      if constexpr (CASC == 1) {   // shared prefix rows: 16 workgroup chunks per kv head re-read them -- keep them cached
+        kreg[i] = *(const u32x4_t*)(kbase + (int64_t)id * kst);
+        vreg[i] = *(const u32x4_t*)(vbase + (int64_t)id * vst);
+      } else {
+        kreg[i] = __builtin_nontemporal_load((const u32x4_t*)(kbase + (int64_t)id * kst));
+        vreg[i] = __builtin_nontemporal_load((const u32x4_t*)(vbase + (int64_t)id * vst));
+      }
     }
   };
 
@@ -457,7 +463,7 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attn_stage1(const DecodePar
       if (d == 0) p.attn_lse[slot] = lv;
     }
   }
-  if (p.merge_cnt) arrive_and_merge<T, CASC>(p, b, seq_len, nsplit, hchunks, smem);
+  if (p.merge_cnt) arrive_and_merge<T, CASC != 0>(p, b, seq_len, nsplit, hchunks, smem);
 }
 
 // Any-head-dim fallback (D, Dv <= 256, not multiples of 32 allowed): one wave per
@@ -556,16 +562,26 @@ int g_decode_mode = 0;  // 0 = workgroup-shared split (default: faster at batch 
 template <typename T, int D, int KVB>
 int launch_mfma(const DecodeParams& p, hipStream_t st) {
   const int hchunks = ((p.shared_reqs > 0 ? p.shared_reqs * p.group : p.group) + 15) / 16;
-  if (p.shared_reqs > 0 || p.split_base > 0) {   // cascade passes: MODE 0 only (checked by the entry point)
+  if (p.shared_reqs > 0) {   // cascade prefix pass: MODE 0 only (checked by the entry point)
     constexpr int NW = 4;
     constexpr int smem = NW * 2 * kTile * D * 2;
     static bool attr_set = false;
     if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)decode_attn_stage1<T, D, NW, 0, KVB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+      (void)hipFuncSetAttribute((const void*)decode_attn_stage1<T, D, NW, 0, KVB, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
       attr_set = true;
     }
-    dim3 grid(p.hkv * hchunks, p.bs, p.shared_reqs > 0 ? p.prefix_splits : p.max_kv_splits - p.split_base);
-    hipLaunchKernelGGL((decode_attn_stage1<T, D, NW, 0, KVB, true>), grid, dim3(NW * 64), smem, st, p);
+    dim3 grid(p.hkv * hchunks, 1, p.prefix_splits);
+    hipLaunchKernelGGL((decode_attn_stage1<T, D, NW, 0, KVB, 1>), grid, dim3(NW * 64), smem, st, p);
+  } else if (p.split_base > 0) {   // cascade suffix pass
+    constexpr int NW = 4;
+    constexpr int smem = NW * 2 * kTile * D * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)decode_attn_stage1<T, D, NW, 0, KVB, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+      attr_set = true;
+    }
+    dim3 grid(p.hkv * hchunks, p.bs, p.max_kv_splits - p.split_base);
+    hipLaunchKernelGGL((decode_attn_stage1<T, D, NW, 0, KVB, 2>), grid, dim3(NW * 64), smem, st, p);
   } else if (g_decode_mode == 0) {
     constexpr int NW = 4;
     constexpr int smem = NW * 2 * kTile * D * 2;

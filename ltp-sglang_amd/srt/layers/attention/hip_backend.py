@@ -80,6 +80,7 @@ class HipAttnBackend(AttentionBackend):
         self.device_core_count = lib.sgl_mi355_device_cu_count(int(gpu_id))  # 256 on MI355X
         self.forward_metadata: Optional[ForwardMetadata] = None
         self.merge_in_launch = True   # forward_decode: stage 2 by the last workgroup of each request (False = two kernels)
+        self.cascade_shared_prefix_len = 0   # > 0: the graph hooks build cascade (shared-prefix) decode metadata
         self._graph = None
         # counters of the in-launch stage-2 merge (one per request slot; allocated eagerly so graph capture never allocates)
         self.max_bs_hint = int(model_runner.req_to_token_pool.size)
@@ -127,32 +128,56 @@ class HipAttnBackend(AttentionBackend):
                 bs, req_pool_indices, seq_lens, True, wi, ws)
         return md
 
+    def _cascade_prefix_splits(self, bs: int, shared_prefix_len: int) -> int:
+        group = self.num_head // self.num_kv_head
+        chunks = self.num_kv_head * ((bs * group + 15) // 16)
+        # one round of resident workgroups (2 per CU); every extra split is one more partial per (request, head) for the
+        # merging workgroup to read (measured: 4 splits 57 us, 8: 66 us, 12: 75 us per layer at 64 x (1536 + 512))
+        return max(1, min(2 * self.device_core_count // max(chunks, 1), shared_prefix_len // 128, 4))
+
+    def _cascade_ok(self, bs: int, shared_prefix_len: int) -> bool:
+        return shared_prefix_len >= 64 and bs >= 2 and self.v_head_dim in (64, 128)
+
+    def _cascade_metadata(self, bs, req_pool_indices, seq_lens, seq_lens_sum, shared_prefix_len, prefix_splits, kv_indices=None,
+                          scratch=None, prefix_buf=None):
+        suffix_lens = seq_lens - shared_prefix_len
+        kv_indptr = self.kv_indptr[: bs + 1]
+        if scratch is None:
+            num_kv_splits = torch.empty((bs,), dtype=torch.int32, device=self.device)
+            attn_logits = torch.empty((bs, self.num_head, self.max_kv_splits, self.v_head_dim), dtype=torch.float32, device=self.device)
+            attn_lse = torch.empty((bs, self.num_head, self.max_kv_splits), dtype=torch.float32, device=self.device)
+        else:
+            num_kv_splits, attn_logits, attn_lse = scratch
+        if self._merge_counters is not None:
+            self._merge_counters.zero_()
+        K.decode_metadata(kv_indptr, num_kv_splits, suffix_lens, 1, self.num_head, self.num_kv_head,
+                          self.max_kv_splits - prefix_splits, self.device_core_count, self.static_kv_splits)
+        if kv_indices is None:
+            kv_indices = torch.empty(max(int(seq_lens_sum) - bs * shared_prefix_len, 1), dtype=torch.int32, device=self.device)
+        K.create_kv_indices(self.req_to_token, req_pool_indices, suffix_lens, kv_indptr,
+                            torch.full_like(suffix_lens, shared_prefix_len), kv_indices)
+        row0 = self.req_to_token[req_pool_indices[0], :shared_prefix_len]
+        if prefix_buf is None:
+            prefix = row0.contiguous()
+        else:   # HIP graph: the kernel arguments hold this buffer's address
+            prefix = prefix_buf[:shared_prefix_len]
+            prefix.copy_(row0)
+        return ForwardMetadata(attn_logits, attn_lse, None, num_kv_splits, kv_indptr, kv_indices, None,
+                               cascade_prefix_indices=prefix, cascade_prefix_splits=int(prefix_splits))
+
     def init_forward_metadata_cascade(self, forward_batch, shared_prefix_len: int, prefix_splits: Optional[int] = None):
         """Decode metadata for a batch whose requests all share their first ``shared_prefix_len`` KV slots (they matched the
         same RadixCache node, radix_cache.py:370-412; the scheduler knows the length from match_prefix).  The shared rows are
         then streamed once per kv head for the whole batch instead of once per request.  Falls back to the
-        ordinary metadata when the prefix is too short to pay for the second launch."""
+        ordinary metadata when the prefix is too short to pay for the second launch.  For the HIP-graph hooks set
+        ``cascade_shared_prefix_len`` before capture / replay instead (the length is baked into the captured launches)."""
         bs = forward_batch.batch_size
-        group = self.num_head // self.num_kv_head
-        if not forward_batch.forward_mode.is_decode() or shared_prefix_len < 64 or bs < 2 or self.v_head_dim not in (64, 128):
+        if not forward_batch.forward_mode.is_decode() or not self._cascade_ok(bs, shared_prefix_len):
             return self.init_forward_metadata(forward_batch)
-        chunks = self.num_kv_head * ((bs * group + 15) // 16)
-        if prefix_splits is None:   # one round of resident workgroups (2 per CU); every extra split is one more partial per
-            # (request, head) for the merging workgroup to read (measured: 4 splits 57 us, 8: 66 us, 12: 75 us per layer)
-            prefix_splits = max(1, min(2 * self.device_core_count // max(chunks, 1), shared_prefix_len // 128, 4))
-        suffix_lens = forward_batch.seq_lens - shared_prefix_len
-        kv_indptr = self.kv_indptr[: bs + 1]
-        num_kv_splits = torch.empty((bs,), dtype=torch.int32, device=self.device)
-        K.decode_metadata(kv_indptr, num_kv_splits, suffix_lens, 1, self.num_head, self.num_kv_head,
-                          self.max_kv_splits - prefix_splits, self.device_core_count, self.static_kv_splits)
-        kv_indices = torch.empty(max(int(forward_batch.seq_lens_sum) - bs * shared_prefix_len, 1), dtype=torch.int32, device=self.device)
-        K.create_kv_indices(self.req_to_token, forward_batch.req_pool_indices, suffix_lens, kv_indptr,
-                            torch.full_like(suffix_lens, shared_prefix_len), kv_indices)
-        attn_logits = torch.empty((bs, self.num_head, self.max_kv_splits, self.v_head_dim), dtype=torch.float32, device=self.device)
-        attn_lse = torch.empty((bs, self.num_head, self.max_kv_splits), dtype=torch.float32, device=self.device)
-        prefix = self.req_to_token[forward_batch.req_pool_indices[0], :shared_prefix_len].contiguous()
-        self.forward_metadata = ForwardMetadata(attn_logits, attn_lse, None, num_kv_splits, kv_indptr, kv_indices, None,
-                                                cascade_prefix_indices=prefix, cascade_prefix_splits=int(prefix_splits))
+        if prefix_splits is None:
+            prefix_splits = self._cascade_prefix_splits(bs, shared_prefix_len)
+        self.forward_metadata = self._cascade_metadata(bs, forward_batch.req_pool_indices, forward_batch.seq_lens,
+                                                       forward_batch.seq_lens_sum, shared_prefix_len, prefix_splits)
 
     def _target_verify_metadata(self, forward_batch):
         """Speculative-decoding verification (triton_backend.py:224-258): every request extends by num_draft_tokens over its
@@ -211,6 +236,7 @@ class HipAttnBackend(AttentionBackend):
             attn_lse=torch.zeros((max_num_tokens, self.num_head, self.max_kv_splits), dtype=torch.float32, device=self.device),
             num_kv_splits=torch.full((max_num_tokens,), self.max_kv_splits, dtype=torch.int32, device=self.device),
         )
+        self._graph["cascade_prefix"] = torch.zeros((self.max_context_len,), dtype=torch.int32, device=self.device)
         if self._has_window():   # triton_backend.py:371-392
             self._graph["window_kv_indices"] = torch.zeros((max_num_tokens * (self.sliding_window_size + 1),), dtype=torch.int32, device=self.device)
             self._graph["window_num_kv_splits"] = torch.full((max_num_tokens,), self.max_kv_splits, dtype=torch.int32, device=self.device)
@@ -221,6 +247,11 @@ class HipAttnBackend(AttentionBackend):
             raise ValueError(f"Invalid forward mode: {forward_mode=} for HIP graph capture.")
         g = self._graph
         scratch = (g["num_kv_splits"][:bs], g["attn_logits"][:bs], g["attn_lse"][:bs])
+        if self.cascade_shared_prefix_len > 0 and self._cascade_ok(bs, self.cascade_shared_prefix_len):
+            p_len = self.cascade_shared_prefix_len   # (the capture buffers hold seq_lens = p_len + 1)
+            self.forward_metadata = self._cascade_metadata(bs, req_pool_indices, seq_lens, 0, p_len, self._cascade_prefix_splits(bs, p_len),
+                                                           g["kv_indices"], scratch, g["cascade_prefix"])
+            return
         wb = (g["window_kv_indices"], g["window_num_kv_splits"][:bs]) if self._has_window() else None
         self.forward_metadata = self._decode_metadata(bs, req_pool_indices, seq_lens, 0, g["kv_indices"], scratch, wb)
 
@@ -230,6 +261,12 @@ class HipAttnBackend(AttentionBackend):
             raise ValueError(f"Invalid forward mode: {forward_mode=} for HIP graph replay.")
         g = self._graph
         scratch = (g["num_kv_splits"][:bs], g["attn_logits"][:bs], g["attn_lse"][:bs])
+        if self.cascade_shared_prefix_len > 0 and self._cascade_ok(bs, self.cascade_shared_prefix_len):
+            p_len = self.cascade_shared_prefix_len
+            self.forward_metadata = self._cascade_metadata(bs, req_pool_indices[:bs], seq_lens[:bs], seq_lens_sum, p_len,
+                                                           self._cascade_prefix_splits(bs, p_len), g["kv_indices"], scratch,
+                                                           g["cascade_prefix"])
+            return
         wb = (g["window_kv_indices"], g["window_num_kv_splits"][:bs]) if self._has_window() else None
         self.forward_metadata = self._decode_metadata(bs, req_pool_indices[:bs], seq_lens[:bs], seq_lens_sum,
                                                       g["kv_indices"], scratch, wb)

@@ -502,21 +502,28 @@ class SyntheticModelRunner:
                                      seq_lens_cpu=torch.tensor(state.seq_lens_cpu, dtype=torch.int64))
 
     @torch.no_grad()
-    def decode(self, state, next_ids: torch.Tensor):
+    def decode(self, state, next_ids: torch.Tensor, shared_prefix_len: int = 0):
+        """shared_prefix_len > 0: every request of the batch shares its first slots (one radix node): cascade decode attention."""
         fb = self._prepare_decode(state, next_ids)
-        self.attn_backend.init_forward_metadata(fb)
+        if shared_prefix_len > 0:
+            self.attn_backend.init_forward_metadata_cascade(fb, shared_prefix_len)
+        else:
+            self.attn_backend.init_forward_metadata(fb)
         return self.model(next_ids, fb.positions, fb)
 
     # ---- HIP-graph decode (cuda_graph_runner.py:280,618,760 hooks) ------------------------------------------
     @torch.no_grad()
-    def capture_decode_graph(self, bs: int):
+    def capture_decode_graph(self, bs: int, shared_prefix_len: int = 0):
+        """shared_prefix_len > 0 captures the cascade (shared-prefix) decode step: the length is baked into the launches, so the
+        graph serves exactly the batches whose requests share that many leading slots."""
         dev = self.device
         if self.attn_backend._graph is None:
             self.attn_backend.init_cuda_graph_state(bs, bs)
+        self.attn_backend.cascade_shared_prefix_len = int(shared_prefix_len)
         buf = SimpleNamespace(
             input_ids=torch.zeros(bs, dtype=torch.int64, device=dev),
             req_pool_indices=torch.zeros(bs, dtype=torch.int64, device=dev),
-            seq_lens=torch.full((bs,), 1, dtype=torch.int64, device=dev),
+            seq_lens=torch.full((bs,), 1 + int(shared_prefix_len), dtype=torch.int64, device=dev),
             out_cache_loc=torch.zeros(bs, dtype=torch.int64, device=dev),
             positions=torch.zeros(bs, dtype=torch.int64, device=dev),
         )
@@ -536,12 +543,14 @@ class SyntheticModelRunner:
         # thread_local: the RCCL watchdog thread of torch.distributed may touch the device while this thread captures (TP > 1)
         with torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
             buf.logits = self.model(buf.input_ids, buf.positions, fb)
-        self._graphs[bs] = (graph, buf)
+        self._graphs[(bs, int(shared_prefix_len))] = (graph, buf)
+        self.attn_backend.cascade_shared_prefix_len = 0
 
     @torch.no_grad()
-    def decode_graph(self, state, next_ids: torch.Tensor):
+    def decode_graph(self, state, next_ids: torch.Tensor, shared_prefix_len: int = 0):
         bs = len(state.seq_lens_cpu)
-        graph, buf = self._graphs[bs]
+        graph, buf = self._graphs[(bs, int(shared_prefix_len))]
+        self.attn_backend.cascade_shared_prefix_len = int(shared_prefix_len)
         if not self.fused_decode_prepare:
             fb = self._prepare_decode(state, next_ids)
             buf.input_ids.copy_(next_ids)
@@ -563,4 +572,5 @@ class SyntheticModelRunner:
         self.attn_backend.init_forward_metadata_replay_cuda_graph(bs, buf.req_pool_indices, buf.seq_lens, seq_sum,
                                                                   None, ForwardMode.DECODE, None, seq_cpu)
         graph.replay()
+        self.attn_backend.cascade_shared_prefix_len = 0
         return buf.logits

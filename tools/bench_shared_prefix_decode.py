@@ -41,11 +41,12 @@ def run(shared, bs=64, hq=32, hkv=8, d=128, pre=1536, uniq=512, nsplit=4, max_sp
 
 if "--cascade-only" not in sys.argv:
     for sh in (False, True):
-        for ns in (4, 8):
+        for ns in (1, 2, 4, 8):
             run(sh, nsplit=ns)
 
 
-def run_cascade(bs=64, hq=32, hkv=8, d=128, pre=1536, uniq=512, max_splits=16, layers=6, iters=10, prefix_splits=4, suffix_splits=2):
+def run_cascade(bs=64, hq=32, hkv=8, d=128, pre=1536, uniq=512, max_splits=16, layers=6, iters=10, prefix_splits=4, suffix_splits=2,
+                plain_splits=1):
     """The same shared-prefix problem through the cascade kernel (prefix once for all requests + private suffixes, merged in
     the second launch, T output) and, for reference, the plain kernel with the in-launch merge (merge + T output as well)."""
     dev = torch.device("cuda:0")
@@ -64,7 +65,7 @@ def run_cascade(bs=64, hq=32, hkv=8, d=128, pre=1536, uniq=512, max_splits=16, l
     lse = torch.empty(bs, hq, max_splits, dtype=torch.float32, device=dev)
     cnt = torch.zeros(bs, dtype=torch.int32, device=dev)
     ssp = torch.full((bs,), suffix_splits, dtype=torch.int32, device=dev)
-    fsp = torch.full((bs,), 4, dtype=torch.int32, device=dev)
+    fsp = torch.full((bs,), plain_splits, dtype=torch.int32, device=dev)
 
     def casc():
         for l in range(layers):
@@ -86,7 +87,7 @@ def run_cascade(bs=64, hq=32, hkv=8, d=128, pre=1536, uniq=512, max_splits=16, l
             e0.record(); fn(); e1.record(); torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1) / layers)
         ts.sort()
-        print(f"{name} prefix_splits={prefix_splits} suffix_splits={suffix_splits}: {ts[len(ts)//2]*1e3:.1f} us/layer "
+        print(f"{name} prefix_splits={prefix_splits} suffix_splits={suffix_splits} plain_splits={plain_splits}: {ts[len(ts)//2]*1e3:.1f} us/layer "
               f"(unique bytes {(pre + bs * uniq) * hkv * d * 4 / 1e6:.0f} MB)")
     o1 = sgl_kernel.decode_attention_cascade(q, ks[0], vs[0], prefix, prefix_splits, kv_indptr, suffix_idx, logits, lse, ssp, max_splits,
                                              d ** -0.5, cnt)[0]

@@ -27,7 +27,7 @@ runner.capture_decode_graph(bs)
 for _ in range(4):
     nxt = torch.argmax(runner.decode_graph(state, nxt).float(), dim=-1)
 torch.cuda.synchronize()
-graph, buf = runner._graphs[bs]
+graph, buf = runner._graphs[(bs, 0)]
 N = 32
 t0 = time.perf_counter()
 for _ in range(N):
