@@ -199,7 +199,8 @@ int sgl_mi355_skinny_gemm(const void* x, int64_t x_stride_elems, const void* w, 
 int sgl_mi355_skinny_gemm_num_kranges(int M, int N, int K, int in_dtype);
 /* Producer half of the launch-boundary split-K reduce: raw f32 partial sums [kranges, M, N], scales left to the consumer
  * (sgl_mi355_fused_add_rmsnorm_quant_fp8 with slabs != NULL). fp8, M <= 64. */
-/* how many slabs the next function writes (the same k-range partition as sgl_mi355_skinny_gemm's, so both sum identically) */
+/* how many slabs the next function writes for rows of K BYTES (K elements for fp8, 2 K for bf16 / f16): the same k-range
+ * partition as sgl_mi355_skinny_gemm's, so both sum identically.  in_dtype of the next function: fp8 / bf16 / f16. */
 int sgl_mi355_skinny_gemm_slabs_count(int M, int K);
 int sgl_mi355_skinny_gemm_slabs(const void* x, int64_t x_stride_elems, const void* w, int64_t w_stride_elems, float* slabs,
                                 int M, int N, int K, int in_dtype, void* stream);
@@ -265,6 +266,18 @@ int sgl_mi355_fp8_qkv_rope_set_kv(const void* x, int64_t x_stride_elems, const v
                                   void* v_buffer, int64_t k_slot_stride, int64_t v_slot_stride, int M, int num_q_heads,
                                   int num_kv_heads, int head_dim, int K, int out_dtype, int tile_rows,
                                   void* stream);
+/* The same two fusions for either operand type: in_dtype SGL_FP8_E4M3 (both scale vectors, out bf16 / f16) or SGL_BF16 /
+ * SGL_F16 (UnquantizedLinearMethod.apply, quantization/unquant.py: scales NULL, out_dtype == in_dtype).  K must fit one
+ * k-range of the weight-streaming kernel: 4096 bytes per row, 8192 at M <= 32. */
+int sgl_mi355_gemm_silu_mul(const void* x, int64_t x_stride_elems, const void* w_interleaved, int64_t w_stride_elems, void* act,
+                            int64_t act_stride_elems, const float* scales_x, const float* scales_w_interleaved, int M, int N,
+                            int K, int in_dtype, int out_dtype, int tile_rows, void* stream);
+int sgl_mi355_qkv_rope_set_kv(const void* x, int64_t x_stride_elems, const void* w_interleaved, int64_t w_stride_elems,
+                              void* q_out, int64_t q_stride_elems, const float* scales_x, const float* scales_w_interleaved,
+                              const void* bias_interleaved, const int64_t* positions, const float* cos_sin_cache,
+                              const int64_t* loc, void* k_buffer, void* v_buffer, int64_t k_slot_stride, int64_t v_slot_stride,
+                              int M, int num_q_heads, int num_kv_heads, int head_dim, int K, int in_dtype, int out_dtype,
+                              int tile_rows, void* stream);
 /* silu_and_mul (activation.py:60-63) -> sgl_per_token_quant_fp8 */
 int sgl_mi355_silu_and_mul_quant_fp8(const void* x, void* out_q, float* out_s, int tokens, int d, int dtype, void* stream);
 /* rotary_embedding (rotary_embedding.py:138-165) on q, k in place -> set_kv_buffer (memory_pool.py:369-407) of (k, v) */

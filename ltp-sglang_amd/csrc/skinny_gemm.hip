@@ -571,7 +571,7 @@ extern "C" int sgl_mi355_skinny_gemm_num_kranges(int M, int N, int K, int in_dty
   return (kbytes + range - 1) / range;
 }
 
-// number of f32 [M, N] slabs sgl_mi355_skinny_gemm_slabs writes for this K (fp8)
+// number of f32 [M, N] slabs sgl_mi355_skinny_gemm_slabs writes for K fp8 elements (K bytes of every row)
 extern "C" int sgl_mi355_skinny_gemm_slabs_count(int M, int K) {
   const int ds = K <= 1024 ? 2 : (K <= 2048 ? 4 : ((K <= 4096 || M > 32 || K > 8192) ? 8 : 16));
   const int range = kV2Waves * ds * 64;
@@ -609,94 +609,166 @@ extern "C" int sgl_mi355_skinny_gemm(const void* x, int64_t x_stride_elems, cons
                                : launch_mt<ES_F16, _Float16>(p, workspace, workspace_floats, st);
 }
 
-// Raw split-K partial sums only: slabs f32 [kranges, M, N] (kranges = sgl_mi355_skinny_gemm_num_kranges), no scales;
-// the consumer kernel (sgl_mi355_fused_add_rmsnorm_quant_fp8 with slabs) combines them at its own launch boundary.
+// Raw split-K partial sums only: slabs f32 [kranges, M, N] (kranges = sgl_mi355_skinny_gemm_slabs_count(M, K * element size)),
+// no scales; the consumer kernel (sgl_mi355_fused_add_rmsnorm_quant_fp8 with slabs) combines them at its own launch boundary.
+// in_dtype SGL_FP8_E4M3 / SGL_BF16 / SGL_F16 (X and W share it); strides in elements.
 extern "C" int sgl_mi355_skinny_gemm_slabs(const void* x, int64_t x_stride_elems, const void* w, int64_t w_stride_elems,
                                            float* slabs, int M, int N, int K, int in_dtype, void* stream) {
   SGL_CHECK(M > 0 && M <= 64 && N > 0 && K > 0, "skinny_gemm_slabs: needs 0 < M <= 64");
   SGL_CHECK(x && w && slabs, "skinny_gemm_slabs: null pointer");
-  SGL_CHECK(in_dtype == SGL_FP8_E4M3, "skinny_gemm_slabs: fp8 only");
-  SGL_CHECK(K % 64 == 0 && x_stride_elems % 16 == 0 && w_stride_elems % 16 == 0 && ((uintptr_t)x % 16) == 0 &&
-                ((uintptr_t)w % 16) == 0 && (int64_t)N * w_stride_elems < 0xFFFFFFF0ll,
+  SGL_CHECK(in_dtype == SGL_FP8_E4M3 || in_dtype == SGL_BF16 || in_dtype == SGL_F16, "skinny_gemm_slabs: bad in_dtype %d", in_dtype);
+  const int es = in_dtype == SGL_FP8_E4M3 ? 1 : 2;
+  SGL_CHECK((K * es) % 64 == 0 && (x_stride_elems * es) % 16 == 0 && (w_stride_elems * es) % 16 == 0 && ((uintptr_t)x % 16) == 0 &&
+                ((uintptr_t)w % 16) == 0 && (int64_t)N * w_stride_elems * es < 0xFFFFFFF0ll,
             "skinny_gemm_slabs: unsupported shape/alignment (K=%d)", K);
   SkinnyParams p;
-  p.x = (const char*)x; p.x_stride = x_stride_elems;
-  p.w = (const char*)w; p.w_stride = w_stride_elems;
+  p.x = (const char*)x; p.x_stride = x_stride_elems * es;
+  p.w = (const char*)w; p.w_stride = w_stride_elems * es;
   p.y = nullptr; p.y_stride = 0;
   p.sx = nullptr; p.sw = nullptr; p.bias = nullptr;  // slab mode never reads scales or bias
-  p.M = M; p.N = N; p.K = K; p.kbytes = K;
-  const int ds = K <= 1024 ? 2 : (K <= 2048 ? 4 : ((K <= 4096 || M > 32 || K > 8192) ? 8 : 16));  // = sgl_mi355_skinny_gemm's choice
+  p.M = M; p.N = N; p.K = K; p.kbytes = K * es;
+  const int kb = p.kbytes;
+  const int ds = kb <= 1024 ? 2 : (kb <= 2048 ? 4 : ((kb <= 4096 || M > 32 || kb > 8192) ? 8 : 16));  // = sgl_mi355_skinny_gemm's choice
   const int range = kV2Waves * ds * 64;
-  const int kranges = (K + range - 1) / range;
+  const int kranges = (kb + range - 1) / range;
   hipStream_t st = (hipStream_t)stream;
-  if (M <= 16) return launch_v2_ds<ES_FP8, 1, __bf16>(p, ds, kranges, slabs, st);
-  if (M <= 32) return launch_v2_ds<ES_FP8, 2, __bf16>(p, ds, kranges, slabs, st);
-  return launch_v2_ds<ES_FP8, 4, __bf16>(p, ds, kranges, slabs, st);
+#define SGL_SLABS_BY_M(ES, T)                                                      \
+  do {                                                                              \
+    if (M <= 16) return launch_v2_ds<ES, 1, T>(p, ds, kranges, slabs, st);          \
+    if (M <= 32) return launch_v2_ds<ES, 2, T>(p, ds, kranges, slabs, st);          \
+    return launch_v2_ds<ES, 4, T>(p, ds, kranges, slabs, st);                       \
+  } while (0)
+  if (in_dtype == SGL_FP8_E4M3) SGL_SLABS_BY_M(ES_FP8, __bf16);
+  if (in_dtype == SGL_BF16) SGL_SLABS_BY_M(ES_BF16, __bf16);
+  SGL_SLABS_BY_M(ES_F16, _Float16);
+#undef SGL_SLABS_BY_M
 }
 
 namespace {
-template <int MT, int DS, typename OutT, int EPI>
+template <int ES, int MT, int DS, typename OutT, int EPI>
 int launch_v2_epi(const SkinnyParams& p, const EpiParams& ep, int rpt, hipStream_t st) {
   const int cus = v2_cus();
   const int ntiles = p.N / rpt;
   const int gx = ntiles < cus ? ntiles : cus;
+  constexpr int TPP = (DS >= 16 || MT >= 4) ? 2 : 4;  // (the plain launcher's rule: LDS budget of the reduce buffer)
   if (ntiles <= gx)
-    hipLaunchKernelGGL((skinny_gemm_v2_kernel<ES_FP8, MT, DS, 1, 1, OutT, EPI>), dim3(gx, 1), dim3(kV2Waves * 64), 0, st, p, rpt,
+    hipLaunchKernelGGL((skinny_gemm_v2_kernel<ES, MT, DS, 1, 1, OutT, EPI>), dim3(gx, 1), dim3(kV2Waves * 64), 0, st, p, rpt,
                        ntiles, (float*)nullptr, ep);
   else
-    hipLaunchKernelGGL((skinny_gemm_v2_kernel<ES_FP8, MT, DS, 1, (MT >= 4 ? 2 : 4), OutT, EPI>), dim3(gx, 1), dim3(kV2Waves * 64), 0, st,
+    hipLaunchKernelGGL((skinny_gemm_v2_kernel<ES, MT, DS, 1, TPP, OutT, EPI>), dim3(gx, 1), dim3(kV2Waves * 64), 0, st,
                        p, rpt, ntiles, (float*)nullptr, ep);
   SGL_HIP_LAUNCH_CHECK();
   return SGL_MI355_OK;
 }
 
-template <int EPI>
-int run_epi(SkinnyParams& p, const EpiParams& ep, int out_dtype, int tile_rows, hipStream_t st, const char* who) {
-  SGL_CHECK(tile_rows == 16 || tile_rows == 8, "%s: tile_rows must be 16 or 8 (got %d)", who, tile_rows);
-  SGL_CHECK(p.M > 0 && p.M <= 64, "%s: needs 0 < M <= 64 (got %d)", who, p.M);
-  SGL_CHECK(p.kbytes % 64 == 0 && p.kbytes <= 4096, "%s: K=%d must be a multiple of 64 and <= 4096 (single k-range)", who, p.kbytes);
-  SGL_CHECK(p.N % 16 == 0 && (int64_t)p.N * p.w_stride < 0xFFFFFFF0ll, "%s: N=%d must be a multiple of 16", who, p.N);
-  SGL_CHECK(out_dtype == SGL_BF16 || out_dtype == SGL_F16, "%s: out_dtype must be bf16 or f16", who);
-  const int ds = p.kbytes <= 1024 ? 2 : (p.kbytes <= 2048 ? 4 : 8);
-#define SGL_EPI_CASE(MTv, DSv)                                                                                          \
-  return out_dtype == SGL_BF16 ? launch_v2_epi<MTv, DSv, __bf16, EPI>(p, ep, tile_rows, st) : launch_v2_epi<MTv, DSv, _Float16, EPI>(p, ep, tile_rows, st)
+// fp8 operands: either 16-bit output; 16-bit operands: the output has the operand dtype (the unquantised linear)
+template <int ES, int MT, int DS, int EPI>
+int launch_v2_epi_out(const SkinnyParams& p, const EpiParams& ep, int out_dtype, int rpt, hipStream_t st) {
+  if constexpr (ES == ES_FP8)
+    return out_dtype == SGL_BF16 ? launch_v2_epi<ES, MT, DS, __bf16, EPI>(p, ep, rpt, st)
+                                 : launch_v2_epi<ES, MT, DS, _Float16, EPI>(p, ep, rpt, st);
+  else if constexpr (ES == ES_BF16)
+    return launch_v2_epi<ES, MT, DS, __bf16, EPI>(p, ep, rpt, st);
+  else
+    return launch_v2_epi<ES, MT, DS, _Float16, EPI>(p, ep, rpt, st);
+}
+
+template <int ES, int EPI>
+int run_epi_es(SkinnyParams& p, const EpiParams& ep, int out_dtype, int tile_rows, hipStream_t st, const char* who) {
+  int ds = 0;
+  SGL_CHECK(v2_kranges<ES>(p, &ds) == 1,
+            "%s: K=%d (%d bytes) at M=%d does not fit one k-range of the weight-streaming kernel (<= 4096 bytes, <= 8192 at M <= 32)",
+            who, p.K, p.kbytes, p.M);
+#define SGL_EPI_CASE(MTv, DSv) return launch_v2_epi_out<ES, MTv, DSv, EPI>(p, ep, out_dtype, tile_rows, st)
+#define SGL_EPI_BY_DS(MTv)              \
+  if (ds == 8) { SGL_EPI_CASE(MTv, 8); } \
+  if (ds == 4) { SGL_EPI_CASE(MTv, 4); } \
+  if (ds == 2) { SGL_EPI_CASE(MTv, 2); }
   if (p.M <= 16) {
-    if (ds == 8) { SGL_EPI_CASE(1, 8); }
-    if (ds == 4) { SGL_EPI_CASE(1, 4); }
-    SGL_EPI_CASE(1, 2);
+    SGL_EPI_BY_DS(1)
+    SGL_EPI_CASE(1, 16);
   }
   if (p.M <= 32) {
-    if (ds == 8) { SGL_EPI_CASE(2, 8); }
-    if (ds == 4) { SGL_EPI_CASE(2, 4); }
-    SGL_EPI_CASE(2, 2);
+    SGL_EPI_BY_DS(2)
+    SGL_EPI_CASE(2, 16);
   }
-  if (ds == 8) { SGL_EPI_CASE(4, 8); }
-  if (ds == 4) { SGL_EPI_CASE(4, 4); }
-  SGL_EPI_CASE(4, 2);
+  SGL_EPI_BY_DS(4)
+  return SGL_MI355_EINVAL;  // (ds = 16 is never chosen for M > 32)
+#undef SGL_EPI_BY_DS
 #undef SGL_EPI_CASE
+}
+
+// in_dtype SGL_FP8_E4M3 (both scale vectors required, out bf16 / f16) or SGL_BF16 / SGL_F16 (no scales, out_dtype == in_dtype)
+template <int EPI>
+int run_epi(SkinnyParams& p, const EpiParams& ep, int in_dtype, int out_dtype, int tile_rows, hipStream_t st, const char* who) {
+  SGL_CHECK(tile_rows == 16 || tile_rows == 8, "%s: tile_rows must be 16 or 8 (got %d)", who, tile_rows);
+  SGL_CHECK(p.M > 0 && p.M <= 64, "%s: needs 0 < M <= 64 (got %d)", who, p.M);
+  SGL_CHECK(in_dtype == SGL_FP8_E4M3 || in_dtype == SGL_BF16 || in_dtype == SGL_F16, "%s: bad in_dtype %d", who, in_dtype);
+  SGL_CHECK(out_dtype == SGL_BF16 || out_dtype == SGL_F16, "%s: out_dtype must be bf16 or f16", who);
+  SGL_CHECK(in_dtype == SGL_FP8_E4M3 || out_dtype == in_dtype, "%s: 16-bit operands give an output of the same dtype", who);
+  SGL_CHECK((in_dtype == SGL_FP8_E4M3) == (p.sx != nullptr) && (!p.sx == !p.sw), "%s: scales go with fp8 operands, and only with them", who);
+  const int es = in_dtype == SGL_FP8_E4M3 ? 1 : 2;
+  p.kbytes = p.K * es;
+  p.x_stride *= es;
+  p.w_stride *= es;
+  SGL_CHECK(p.kbytes % 64 == 0 && p.x_stride % 16 == 0 && p.w_stride % 16 == 0 && ((uintptr_t)p.x % 16) == 0 && ((uintptr_t)p.w % 16) == 0,
+            "%s: rows must be 16-byte aligned and K a multiple of 64 bytes (K=%d)", who, p.K);
+  SGL_CHECK(p.N % 16 == 0 && (int64_t)p.N * p.w_stride < 0xFFFFFFF0ll, "%s: N=%d must be a multiple of 16", who, p.N);
+  if (in_dtype == SGL_FP8_E4M3) return run_epi_es<ES_FP8, EPI>(p, ep, out_dtype, tile_rows, st, who);
+  if (in_dtype == SGL_BF16) return run_epi_es<ES_BF16, EPI>(p, ep, out_dtype, tile_rows, st, who);
+  return run_epi_es<ES_F16, EPI>(p, ep, out_dtype, tile_rows, st, who);
 }
 }  // namespace
 
-// act[M, N/2] = T(T(silu(g)) * u) with [g | u] = fp8_scaled_mm(x, w_interleaved) -- gate_up_proj + SiluAndMul in one launch.
-// w_interleaved [N, K] / scales_w [N]: tile t of tile_rows = 2 H rows (16 or 8) = gate rows H t .. H t + H - 1 then the up rows
-// of the same indices.  8-row tiles balance the workgroups when N / 16 is between one and a few times the CU count.
+// act[M, N/2] = T(T(silu(g)) * u) with [g | u] = linear(x, w_interleaved) -- gate_up_proj + SiluAndMul in one launch.
+// in_dtype SGL_FP8_E4M3: fp8_scaled_mm operands with both scale vectors; SGL_BF16 / SGL_F16: the unquantised linear (scales null,
+// out_dtype == in_dtype).  w_interleaved [N, K] / scales_w [N]: tile t of tile_rows = 2 H rows (16 or 8) = gate rows H t .. H t + H - 1
+// then the up rows of the same indices.  8-row tiles balance the workgroups when N / 16 is between one and a few times the CU
+// count.  K must fit one k-range of the weight-streaming kernel (4096 bytes; 8192 at M <= 32).  Strides in elements.
+extern "C" int sgl_mi355_gemm_silu_mul(const void* x, int64_t x_stride_elems, const void* w_interleaved, int64_t w_stride_elems,
+                                       void* act, int64_t act_stride_elems, const float* scales_x,
+                                       const float* scales_w_interleaved, int M, int N, int K, int in_dtype, int out_dtype,
+                                       int tile_rows, void* stream) {
+  SGL_CHECK(x && w_interleaved && act, "gemm_silu_mul: null pointer");
+  SkinnyParams p;
+  p.x = (const char*)x; p.x_stride = x_stride_elems; p.w = (const char*)w_interleaved; p.w_stride = w_stride_elems;
+  p.y = act; p.y_stride = act_stride_elems; p.sx = scales_x; p.sw = scales_w_interleaved; p.bias = nullptr;
+  p.M = M; p.N = N; p.K = K; p.kbytes = 0;
+  return run_epi<EPI_SILU>(p, EpiParams{}, in_dtype, out_dtype, tile_rows, (hipStream_t)stream, "gemm_silu_mul");
+}
+
 extern "C" int sgl_mi355_fp8_gemm_silu_mul(const void* x, int64_t x_stride_elems, const void* w_interleaved,
                                            int64_t w_stride_elems, void* act, int64_t act_stride_elems,
                                            const float* scales_x, const float* scales_w_interleaved, int M, int N, int K,
                                            int out_dtype, int tile_rows, void* stream) {
-  SGL_CHECK(x && w_interleaved && act && scales_x && scales_w_interleaved, "fp8_gemm_silu_mul: null pointer");
-  SGL_CHECK(((uintptr_t)x % 16) == 0 && ((uintptr_t)w_interleaved % 16) == 0 && x_stride_elems % 16 == 0 && w_stride_elems % 16 == 0,
-            "fp8_gemm_silu_mul: rows must be 16-byte aligned");
-  SkinnyParams p;
-  p.x = (const char*)x; p.x_stride = x_stride_elems; p.w = (const char*)w_interleaved; p.w_stride = w_stride_elems;
-  p.y = act; p.y_stride = act_stride_elems; p.sx = scales_x; p.sw = scales_w_interleaved; p.bias = nullptr;
-  p.M = M; p.N = N; p.K = K; p.kbytes = K;
-  return run_epi<EPI_SILU>(p, EpiParams{}, out_dtype, tile_rows, (hipStream_t)stream, "fp8_gemm_silu_mul");
+  SGL_CHECK(scales_x && scales_w_interleaved, "fp8_gemm_silu_mul: null pointer");
+  return sgl_mi355_gemm_silu_mul(x, x_stride_elems, w_interleaved, w_stride_elems, act, act_stride_elems, scales_x,
+                                 scales_w_interleaved, M, N, K, SGL_FP8_E4M3, out_dtype, tile_rows, stream);
 }
 
-// qkv_proj + neox rotary embedding + set_kv_buffer in one launch.  w_interleaved / scales / bias rows: inside every q and k
-// head (128 rows) tile u of tile_rows = 2 H rows = rows H u .. H u + H - 1 then rows 64 + H u ..; v heads in natural order.  q (rotated) -> q_out
-// [M, Hq*128]; k (rotated) and v -> pool rows loc[m] of k_buffer / v_buffer ([slots, Hkv, 128], strides in elements).
+// qkv_proj + neox rotary embedding + set_kv_buffer in one launch (in_dtype as for sgl_mi355_gemm_silu_mul).  w_interleaved /
+// scales / bias rows: inside every q and k head (128 rows) tile u of tile_rows = 2 H rows = rows H u .. H u + H - 1 then rows
+// 64 + H u ..; v heads in natural order.  q (rotated) -> q_out [M, Hq*128]; k (rotated) and v -> pool rows loc[m] of k_buffer /
+// v_buffer ([slots, Hkv, 128], strides in elements).
+extern "C" int sgl_mi355_qkv_rope_set_kv(const void* x, int64_t x_stride_elems, const void* w_interleaved, int64_t w_stride_elems,
+                                         void* q_out, int64_t q_stride_elems, const float* scales_x,
+                                         const float* scales_w_interleaved, const void* bias_interleaved,
+                                         const int64_t* positions, const float* cos_sin_cache, const int64_t* loc,
+                                         void* k_buffer, void* v_buffer, int64_t k_slot_stride, int64_t v_slot_stride, int M,
+                                         int num_q_heads, int num_kv_heads, int head_dim, int K, int in_dtype, int out_dtype,
+                                         int tile_rows, void* stream) {
+  SGL_CHECK(x && w_interleaved && q_out && positions && cos_sin_cache && loc && k_buffer && v_buffer, "qkv_rope_set_kv: null pointer");
+  SGL_CHECK(head_dim == 128, "qkv_rope_set_kv: head_dim (= rotary_dim) must be 128, got %d", head_dim);
+  SkinnyParams p;
+  p.x = (const char*)x; p.x_stride = x_stride_elems; p.w = (const char*)w_interleaved; p.w_stride = w_stride_elems;
+  p.y = q_out; p.y_stride = q_stride_elems; p.sx = scales_x; p.sw = scales_w_interleaved; p.bias = bias_interleaved;
+  p.M = M; p.N = (num_q_heads + 2 * num_kv_heads) * 128; p.K = K; p.kbytes = 0;
+  EpiParams ep;
+  ep.positions = positions; ep.cos_sin = cos_sin_cache; ep.loc = loc; ep.k_buf = k_buffer; ep.v_buf = v_buffer;
+  ep.k_slot_stride = k_slot_stride; ep.v_slot_stride = v_slot_stride; ep.hq = num_q_heads; ep.hkv = num_kv_heads;
+  return run_epi<EPI_ROPE>(p, ep, in_dtype, out_dtype, tile_rows, (hipStream_t)stream, "qkv_rope_set_kv");
+}
+
 extern "C" int sgl_mi355_fp8_qkv_rope_set_kv(const void* x, int64_t x_stride_elems, const void* w_interleaved,
                                              int64_t w_stride_elems, void* q_out, int64_t q_stride_elems,
                                              const float* scales_x, const float* scales_w_interleaved,
@@ -705,17 +777,9 @@ extern "C" int sgl_mi355_fp8_qkv_rope_set_kv(const void* x, int64_t x_stride_ele
                                              int64_t k_slot_stride, int64_t v_slot_stride, int M, int num_q_heads,
                                              int num_kv_heads, int head_dim, int K, int out_dtype, int tile_rows,
                                              void* stream) {
-  SGL_CHECK(x && w_interleaved && q_out && scales_x && scales_w_interleaved && positions && cos_sin_cache && loc && k_buffer && v_buffer,
-            "fp8_qkv_rope_set_kv: null pointer");
-  SGL_CHECK(head_dim == 128, "fp8_qkv_rope_set_kv: head_dim (= rotary_dim) must be 128, got %d", head_dim);
-  SGL_CHECK(((uintptr_t)x % 16) == 0 && ((uintptr_t)w_interleaved % 16) == 0 && x_stride_elems % 16 == 0 && w_stride_elems % 16 == 0,
-            "fp8_qkv_rope_set_kv: rows must be 16-byte aligned");
-  SkinnyParams p;
-  p.x = (const char*)x; p.x_stride = x_stride_elems; p.w = (const char*)w_interleaved; p.w_stride = w_stride_elems;
-  p.y = q_out; p.y_stride = q_stride_elems; p.sx = scales_x; p.sw = scales_w_interleaved; p.bias = bias_interleaved;
-  p.M = M; p.N = (num_q_heads + 2 * num_kv_heads) * 128; p.K = K; p.kbytes = K;
-  EpiParams ep;
-  ep.positions = positions; ep.cos_sin = cos_sin_cache; ep.loc = loc; ep.k_buf = k_buffer; ep.v_buf = v_buffer;
-  ep.k_slot_stride = k_slot_stride; ep.v_slot_stride = v_slot_stride; ep.hq = num_q_heads; ep.hkv = num_kv_heads;
-  return run_epi<EPI_ROPE>(p, ep, out_dtype, tile_rows, (hipStream_t)stream, "fp8_qkv_rope_set_kv");
+  SGL_CHECK(scales_x && scales_w_interleaved, "fp8_qkv_rope_set_kv: null pointer");
+  return sgl_mi355_qkv_rope_set_kv(x, x_stride_elems, w_interleaved, w_stride_elems, q_out, q_stride_elems, scales_x,
+                                   scales_w_interleaved, bias_interleaved, positions, cos_sin_cache, loc, k_buffer, v_buffer,
+                                   k_slot_stride, v_slot_stride, M, num_q_heads, num_kv_heads, head_dim, K, SGL_FP8_E4M3, out_dtype,
+                                   tile_rows, stream);
 }

@@ -19,6 +19,8 @@ from .fused import (
     balanced_tile_rows,
     fp8_gemm_silu_mul,
     fp8_qkv_rope_set_kv,
+    gemm_silu_mul,
+    qkv_rope_set_kv,
     fused_add_rmsnorm_quant_fp8,
     interleave_gate_up_rows,
     interleave_rope_rows,
@@ -31,6 +33,7 @@ from .gemm import (
     awq_repack,
     awq_unpack_nk,
     dense_linear,
+    dense_linear_kranges,
     fp8_linear_slabs,
     fp8_scaled_mm,
     sgl_per_tensor_quant_fp8,

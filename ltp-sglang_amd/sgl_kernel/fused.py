@@ -107,6 +107,33 @@ def fp8_qkv_rope_set_kv(x_q, x_s, w_interleaved_nk, w_s_interleaved, bias_interl
     return q
 
 
+def gemm_silu_mul(x, w_interleaved_nk, tile_rows: int = 16):
+    """act [M, I] = SiluAndMul(F.linear(x, W)) for bf16 / f16 operands, W's rows interleaved by interleave_gate_up_rows."""
+    m, k = x.shape
+    n = w_interleaved_nk.shape[0]
+    assert x.dtype == w_interleaved_nk.dtype and x.stride(1) == 1 and w_interleaved_nk.stride(1) == 1
+    act = torch.empty((m, n // 2), dtype=x.dtype, device=x.device)
+    check(lib.sgl_mi355_gemm_silu_mul(ptr(x), x.stride(0), ptr(w_interleaved_nk), w_interleaved_nk.stride(0), ptr(act),
+                                      act.stride(0), None, None, m, n, k, dtype_code(x.dtype), dtype_code(x.dtype),
+                                      int(tile_rows), current_stream()))
+    return act
+
+
+def qkv_rope_set_kv(x, w_interleaved_nk, bias_interleaved, positions, cos_sin_cache, loc, k_buffer, v_buffer, num_q_heads,
+                    num_kv_heads, head_dim, tile_rows: int = 16):
+    """The bf16 / f16 form of fp8_qkv_rope_set_kv (unquantised qkv_proj): q [M, Hq*D] rotated; k, v -> pool rows ``loc``."""
+    m, k = x.shape
+    assert x.dtype == w_interleaved_nk.dtype and x.stride(1) == 1 and w_interleaved_nk.stride(1) == 1
+    q = torch.empty((m, num_q_heads * head_dim), dtype=x.dtype, device=x.device)
+    assert k_buffer[0].is_contiguous() and v_buffer[0].is_contiguous() and cos_sin_cache.shape[1] == head_dim
+    check(lib.sgl_mi355_qkv_rope_set_kv(ptr(x), x.stride(0), ptr(w_interleaved_nk), w_interleaved_nk.stride(0), ptr(q), q.stride(0),
+                                        None, None, ptr(bias_interleaved), ptr(positions), ptr(cos_sin_cache), ptr(loc),
+                                        ptr(k_buffer), ptr(v_buffer), k_buffer.stride(0), v_buffer.stride(0), m, num_q_heads,
+                                        num_kv_heads, head_dim, k, dtype_code(x.dtype), dtype_code(x.dtype), int(tile_rows),
+                                        current_stream()))
+    return q
+
+
 def balanced_tile_rows(n_rows: int) -> int:
     """16-row tiles, or 8-row tiles when 16-row tiles would leave the last round of the persistent workgroups mostly idle (the
     rule of the plain skinny GEMM's launcher): e.g. qkv_proj of Llama-3-8B, 384 tiles on 256 CUs."""

@@ -179,14 +179,21 @@ def fp8_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype, bias=None):
 
 def fp8_linear_slabs(x_q: torch.Tensor, weight_nk: torch.Tensor, m: int, n: int, k: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Raw f32 split-K partial sums [S, M, N] of x_q[M,K] @ weight_nk[N,K]^T (no scales): the producer half of the
-    launch-boundary split-K reduce; the consumer (fused_add_rmsnorm_quant_fp8 with ``slabs=``) applies the scales."""
+    launch-boundary split-K reduce; the consumer (fused_add_rmsnorm_quant_fp8 with ``slabs=``) applies the scales.
+    Operands fp8 (fp8_scaled_mm) or bf16 / f16 (the unquantised linear: the consumer gets no scales)."""
     _cuda(x_q, weight_nk)
-    kr = lib.sgl_mi355_skinny_gemm_slabs_count(m, k)
+    assert x_q.dtype == weight_nk.dtype
+    kr = lib.sgl_mi355_skinny_gemm_slabs_count(m, k * x_q.element_size())
     if out is None:
         out = torch.empty((kr, m, n), dtype=torch.float32, device=x_q.device)
     check(lib.sgl_mi355_skinny_gemm_slabs(ptr(x_q), x_q.stride(0), ptr(weight_nk), weight_nk.stride(0), ptr(out), m, n, k,
                                           dtype_code(x_q.dtype), current_stream()))
     return out
+
+
+def dense_linear_kranges(m: int, n: int, k: int, dtype) -> int:
+    """How many split-K ranges dense_linear / fp8_scaled_mm use for this shape at M <= 64 (1: no slabs; 0: generic kernel)."""
+    return int(lib.sgl_mi355_skinny_gemm_num_kranges(m, n, k, dtype_code(dtype))) if m <= 64 else 0
 
 
 def dense_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, out_dtype=None) -> torch.Tensor:

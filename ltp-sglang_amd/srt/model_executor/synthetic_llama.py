@@ -339,6 +339,75 @@ class LlamaForCausalLM(nn.Module):
         logits = K.dense_linear(hidden, self.lm_head, None, out_dtype=self.dtype)
         return tensor_model_parallel_all_gather(logits) if tp > 1 else logits
 
+    def _fused_dense_ok(self, forward_batch) -> bool:
+        return (self.fused_decode and forward_batch.forward_mode.is_decode() and self.quant_config is None
+                and self.tp_size == 1 and self.cfg.hidden_size <= 8192
+                and forward_batch.token_to_kv_pool.dtype != torch.float8_e4m3fn)
+
+    def _fused_weights_dense(self, layer, m: int):
+        """Row-interleaved copies of the unquantised qkv / gate_up weights for the GEMM epilogue fusions; None when the K
+        dimension does not fit one k-range of the weight-streaming kernel at this M (4096 bytes; 8192 at M <= 32)."""
+        if not self.fused_epilogues:
+            return None
+        attn, mlp = layer.self_attn, layer.mlp
+        kbytes = attn.qkv_proj.weight.shape[1] * attn.qkv_proj.weight.element_size()
+        if attn.head_dim != 128 or kbytes % 64 != 0 or not (kbytes <= 4096 or (kbytes <= 8192 and m <= 32)) or m > 64:
+            return None
+        cached = getattr(layer, "_fused_w", None)
+        if cached is None:
+            hq, hkv = attn.num_heads, attn.num_kv_heads
+            qw, gw = attn.qkv_proj.weight.data, mlp.gate_up_proj.weight.data   # [N, K]
+            tq, tg = K.balanced_tile_rows(qw.shape[0]), K.balanced_tile_rows(gw.shape[0])
+            cached = layer._fused_w = dict(
+                qkv_w=K.interleave_rope_rows(qw, hq, hkv, 128, tq),
+                qkv_b=None if attn.qkv_proj.bias is None else K.interleave_rope_rows(attn.qkv_proj.bias.data, hq, hkv, 128, tq),
+                gu_w=K.interleave_gate_up_rows(gw, tg), qkv_tile=tq, gu_tile=tg)
+        return cached
+
+    def forward_decode_fused_dense(self, input_ids, positions, forward_batch: ForwardBatch):
+        """The unquantised (bf16 / f16) decode step on fused kernels: 6 launches per layer instead of 10 -- add + RMSNorm
+        (consuming the previous down_proj's split-K partial sums), qkv GEMM with the RoPE + KV-write epilogue, attention with the
+        in-launch merge, o_proj, add + RMSNorm, gate_up GEMM with the SiluAndMul epilogue, down_proj (raw split-K slabs).  Every
+        fused kernel is bit-identical to the op sequence it replaces, so this path and forward() give the same logits."""
+        pool = forward_batch.token_to_kv_pool
+        m = input_ids.numel()
+        hidden = K.embedding(input_ids, self.embed_tokens)
+        residual, slabs = None, None
+        norm = lambda x, res, ln, sl=None: K.fused_add_rmsnorm_quant_fp8(
+            x, res, ln.weight.data, ln.variance_epsilon, slabs=sl, want_norm=True, want_quant=False, dtype=self.dtype)[0]
+        for layer in self.layers:
+            attn, mlp = layer.self_attn, layer.mlp
+            if residual is None:
+                x = norm(hidden, None, layer.input_layernorm)
+                residual = hidden
+            else:
+                x = norm(hidden if slabs is None else None, residual, layer.input_layernorm, slabs)
+            lid = attn.attn.layer_id
+            fw = self._fused_weights_dense(layer, m)
+            if fw is not None:
+                q = K.qkv_rope_set_kv(x, fw["qkv_w"], fw["qkv_b"], positions, attn.rotary_emb.cos_sin_cache,
+                                      forward_batch.out_cache_loc, pool.get_key_buffer(lid), pool.get_value_buffer(lid),
+                                      attn.num_heads, attn.num_kv_heads, attn.head_dim, fw["qkv_tile"])
+            else:
+                qkv = K.dense_linear(x, attn.qkv_proj.weight.data, attn.qkv_proj.bias)
+                q, k, v = qkv.split([attn.q_size, attn.kv_size, attn.kv_size], dim=-1)
+                K.rope_set_kv(positions, q, k, v, attn.head_dim, attn.rotary_emb.cos_sin_cache, True, pool.get_key_buffer(lid),
+                              pool.get_value_buffer(lid), forward_batch.out_cache_loc)
+            o = attn.attn(q, None, None, forward_batch, save_kv_cache=False)
+            attn_out = K.dense_linear(o, attn.o_proj.weight.data, None)
+            h2 = norm(attn_out, residual, layer.post_attention_layernorm)
+            if fw is not None:
+                act = K.gemm_silu_mul(h2, fw["gu_w"], fw["gu_tile"])
+            else:
+                act = K.silu_and_mul(K.dense_linear(h2, mlp.gate_up_proj.weight.data, None))
+            wd = mlp.down_proj.weight.data   # [N, K]
+            if m <= 64 and K.dense_linear_kranges(m, wd.shape[0], wd.shape[1], wd.dtype) > 1:
+                slabs = K.fp8_linear_slabs(act, wd, m, wd.shape[0], wd.shape[1])
+            else:
+                slabs, hidden = None, K.dense_linear(act, wd, None)
+        hidden = norm(hidden if slabs is None else None, residual, self.norm, slabs)
+        return K.dense_linear(hidden, self.lm_head, None, out_dtype=self.dtype)
+
     def _fused_extend_ok(self, forward_batch) -> bool:
         return (self.fused_extend and forward_batch.forward_mode.is_extend()
                 and self.quant_config is not None and self.quant_config.get_name() == "w8a8_fp8"
@@ -395,6 +464,8 @@ class LlamaForCausalLM(nn.Module):
     def forward(self, input_ids, positions, forward_batch: ForwardBatch, last_index: Optional[torch.Tensor] = None):
         if self._fused_decode_ok(forward_batch):
             return self.forward_decode_fused(input_ids, positions, forward_batch)
+        if self._fused_dense_ok(forward_batch):
+            return self.forward_decode_fused_dense(input_ids, positions, forward_batch)
         if self._fused_extend_ok(forward_batch):
             return self.forward_extend_fused(input_ids, positions, forward_batch, last_index)
         hidden_states = K.embedding(input_ids, self.embed_tokens)

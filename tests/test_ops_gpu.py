@@ -549,6 +549,74 @@ def test_fp8_qkv_rope_set_kv_bit_exact(m, hq, hkv, bias, tile_rows, sk):
     assert torch.equal(q2, q.contiguous()) and torch.equal(kb1, kb2) and torch.equal(vb1, vb2)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("m,k,tile_rows", [(32, 4096, 16), (32, 4096, 8), (9, 3584, 16), (48, 2048, 16), (64, 1024, 8), (3, 512, 16)])
+def test_dense_gemm_silu_mul_bit_exact(m, k, tile_rows, dtype, sk):
+    """The unquantised gate_up linear with the SiluAndMul epilogue == dense_linear -> silu_and_mul (K bytes up to 8192 at
+    M <= 32: the one-k-range instantiation with 1 KiB of K per wave)."""
+    i_dim = 1408
+    g = torch.Generator().manual_seed(m + k)
+    x = (torch.randn(m, k, generator=g) * 0.5).to(dtype).to(DEV)
+    w = (torch.randn(2 * i_dim, k, generator=g) * 0.05).to(dtype).to(DEV)
+    ref = sk.silu_and_mul(sk.dense_linear(x, w))
+    got = sk.gemm_silu_mul(x, sk.interleave_gate_up_rows(w, tile_rows), tile_rows)
+    assert torch.isfinite(ref.float()).all() and ref.float().abs().max() > 0
+    assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("m,hq,hkv,bias,k,tile_rows", [(32, 32, 8, False, 4096, 8), (32, 8, 2, True, 4096, 16), (5, 4, 4, True, 1024, 16),
+                                                      (17, 28, 4, True, 3584, 8), (48, 8, 2, False, 2048, 16)])
+def test_dense_qkv_rope_set_kv_bit_exact(m, hq, hkv, bias, k, tile_rows, dtype, sk):
+    """The unquantised qkv linear with the RoPE + KV-write epilogue == dense_linear -> rope -> set_kv_buffer."""
+    d = 128
+    n = (hq + 2 * hkv) * d
+    g = torch.Generator().manual_seed(m)
+    x = (torch.randn(m, k, generator=g) * 0.5).to(dtype).to(DEV)
+    w = (torch.randn(n, k, generator=g) * 0.05).to(dtype).to(DEV)
+    bvec = (torch.randn(n, generator=g) * 0.1).to(dtype).to(DEV) if bias else None
+    positions = torch.randint(0, 4096, (m,), generator=g).to(DEV)
+    cache = oe.rope_cache(d, d, 4096, 10000.0).to(DEV)
+    loc = (torch.randperm(99, generator=g)[:m] + 1).to(DEV)
+    qkv = sk.dense_linear(x, w, bvec)
+    q, kk, vv = qkv.split([hq * d, hkv * d, hkv * d], dim=-1)
+    kb1 = torch.zeros(100, hkv, d, dtype=dtype, device=DEV)
+    vb1 = torch.zeros_like(kb1)
+    sk.rope_set_kv(positions, q, kk, vv, d, cache, True, kb1, vb1, loc)
+    il = lambda t: sk.interleave_rope_rows(t, hq, hkv, d, tile_rows)
+    kb2, vb2 = torch.zeros_like(kb1), torch.zeros_like(kb1)
+    q2 = sk.qkv_rope_set_kv(x, il(w), None if bvec is None else il(bvec), positions, cache, loc, kb2, vb2, hq, hkv, d, tile_rows)
+    assert torch.equal(q2, q.contiguous()) and torch.equal(kb1, kb2) and torch.equal(vb1, vb2)
+
+
+def test_dense_fused_epilogue_rejects_two_k_ranges(sk):
+    """K = 4096 bf16 elements is 8 KiB per row: one k-range only at M <= 32; at M = 48 the call must fail loudly."""
+    x = torch.zeros(48, 4096, dtype=torch.bfloat16, device=DEV)
+    w = torch.zeros(256, 4096, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(RuntimeError, match="k-range"):
+        sk.gemm_silu_mul(x, w, 16)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("m,n,k", [(32, 4096, 14336), (7, 1024, 7168), (64, 896, 4864)])
+def test_dense_slabs_into_norm_bit_exact(m, n, k, dtype, sk):
+    """Unquantised down_proj as raw split-K slabs consumed by the next add + RMSNorm == dense_linear -> fused_add_rmsnorm."""
+    g = torch.Generator().manual_seed(k)
+    x = (torch.randn(m, k, generator=g) * 0.5).to(dtype).to(DEV)
+    w = (torch.randn(n, k, generator=g) * 0.05).to(dtype).to(DEV)
+    res = torch.randn(m, n, generator=g).to(dtype).to(DEV)
+    wn = (1 + 0.1 * torch.randn(n, generator=g)).to(dtype).to(DEV)
+    assert sk.dense_linear_kranges(m, n, k, dtype) > 1
+    y = sk.dense_linear(x, w)
+    r1 = res.clone()
+    sk.fused_add_rmsnorm(y, r1, wn, 1e-5)
+    slabs = sk.fp8_linear_slabs(x, w, m, n, k)
+    assert slabs.shape[0] == sk.dense_linear_kranges(m, n, k, dtype)
+    r2 = res.clone()
+    out, _, _ = sk.fused_add_rmsnorm_quant_fp8(None, r2, wn, 1e-5, slabs=slabs, want_norm=True, want_quant=False, dtype=dtype)
+    assert torch.equal(r1, r2) and torch.equal(out, y)
+
+
 def test_decode_prepare_matches_index_ops(sk):
     """prepare_for_decode + the graph runner's buffer copies in one launch == the separate index ops (bit-exact)."""
     g = torch.Generator().manual_seed(11)
