@@ -45,6 +45,7 @@ def parse_args():
                     help="nccl = RCCL over xGMI (the measured configuration); gloo = rehearsal of the N > 1 path on fewer GPUs")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fused-decode", action="store_true", help="measurement hook: the per-op decode path (same logits, more launches)")
     ap.add_argument("--prefill-chunk", type=int, default=8, help="requests per prefill call")
     ap.add_argument("--gemm-hook", type=int, default=0, help="measurement hook: value passed to sgl_mi355_fp8_gemm_force_tile")
     ap.add_argument("--kv-split-rule", type=int, default=2, help="0 = the reference's heuristic, 1 = max splits everywhere, 2 = the MI355X balance rule")
@@ -239,6 +240,8 @@ def main():
                                   dtype=torch.float16 if args.dtype == "f16" else torch.bfloat16,
                                   kv_cache_dtype=torch.float8_e4m3fn if args.kv_cache_dtype == "fp8_e4m3" else None,
                                   max_kv_splits=args.max_kv_splits, kv_split_rule=args.kv_split_rule)
+    if args.no_fused_decode:
+        runner.model.fused_decode = False
     kv_es = 1 if args.kv_cache_dtype == "fp8_e4m3" else 2
     tp = comm.get_tensor_model_parallel_world_size()
 

@@ -334,6 +334,22 @@ int sgl_mi355_awq_gemm_num_kranges(int K);
 int sgl_mi355_awq_gemm(const void* x, int64_t x_stride_elems, const void* qpacked, const void* sz, void* y,
                        int64_t y_stride_elems, const void* bias, int M, int N, int K, int group_size, int dtype,
                        float* workspace, int64_t workspace_floats, void* stream);
+/* Producer half of the launch-boundary split-K reduce for an int4 weight: raw f32 partial sums [kranges, M, N]
+ * (kranges = sgl_mi355_awq_gemm_num_kranges(K)); consumed by sgl_mi355_fused_add_rmsnorm_quant_fp8 (slabs, no scales). */
+int sgl_mi355_awq_gemm_slabs(const void* x, int64_t x_stride_elems, const void* qpacked, const void* sz, float* slabs, int M,
+                             int N, int K, int group_size, int dtype, void* stream);
+/* AWQLinearMethod.apply (awq.py:401-418) fused with the op that consumes it, bit-identical to awq_gemm followed by that op; the
+ * packed columns (8 per int32) are interleaved before sgl_mi355_awq_repack.  K <= 4096 (one k-range), M <= 32.
+ *   gate_up_proj + SiluAndMul (activation.py:60-63): 16-column tile t = [gate columns 8t..8t+7 | up columns 8t..8t+7] */
+int sgl_mi355_awq_gemm_silu_mul(const void* x, int64_t x_stride_elems, const void* qpacked_interleaved, const void* sz_interleaved,
+                                void* act, int64_t act_stride_elems, int M, int N, int K, int group_size, int dtype, void* stream);
+/*   qkv_proj + neox RoPE (rotary_embedding.py:49-72) + set_kv_buffer (memory_pool.py:401-407): inside every q / k head tile
+ *   u = [columns 8u..8u+7 | columns 64+8u..64+8u+7]; v heads in natural order; head_dim = rotary_dim = 128 */
+int sgl_mi355_awq_qkv_rope_set_kv(const void* x, int64_t x_stride_elems, const void* qpacked_interleaved,
+                                  const void* sz_interleaved, void* q_out, int64_t q_stride_elems, const void* bias_interleaved,
+                                  const int64_t* positions, const float* cos_sin_cache, const int64_t* loc, void* k_buffer,
+                                  void* v_buffer, int64_t k_slot_stride, int64_t v_slot_stride, int M, int num_q_heads,
+                                  int num_kv_heads, int head_dim, int K, int group_size, int dtype, void* stream);
 
 /* out[cols, rows] = in[rows, cols]^T for 16-bit elements (weight re-layout between awq_dequantize's [K, N] and
  * the [N, K] the GEMMs stream; AWQLinearMethod.apply, layers/quantization/awq.py:401-418) */

@@ -9,6 +9,7 @@
 // HBM-bound byte work: one int32 (8 weights) per thread -> 4-byte coalesced reads, 16-byte coalesced writes; the
 // AWQ nibble order means (q >> 4i) & 0x000F000F is already the pair of adjacent columns (2i, 2i+1).
 #include "common.h"
+#include "gemm_epilogue.h"
 
 namespace {
 
@@ -72,7 +73,20 @@ struct AwqGemmParams {
   int64_t y_stride;
   const void* bias;
   int M, N, K, G, KB;  // KB = K / 128
+#ifdef SGL_AWQ_TIMELINE
+  long long* tl;  // tools/microbench/awq_timeline.hip: s_memtime stamps [workgroup][wave][16]
+#endif
 };
+
+#ifdef SGL_AWQ_TIMELINE
+#define AWQ_STAMP(i)                                                                            \
+  do {                                                                                          \
+    const long long t_ = (long long)__builtin_amdgcn_s_memtime();                               \
+    if (lane == 0 && (i) < 16) p.tl[((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + w) * 16 + (i)] = t_; \
+  } while (0)
+#else
+#define AWQ_STAMP(i)
+#endif
 
 
 template <int B>
@@ -135,8 +149,11 @@ struct AwqDequant<__bf16> {
 constexpr int kAwqWaves = 8;
 constexpr int kAwqBpw = 4;  // k-blocks (128 k each) per wave and k-range
 
-template <typename T, int MT, int PD, int TPP, int SG>  // SG = scale groups per 128-k block (1: G % 128 == 0, 2: G = 64, 4: G = 32)
-__global__ __launch_bounds__(kAwqWaves * 64, 1) void awq_gemm_kernel(const AwqGemmParams p, int ntiles, float* slabs) {
+// SG = scale groups per 128-k block (1: G % 128 == 0, 2: G = 64, 4: G = 32); EPI: gemm_epilogue.h (single k-range, columns
+// interleaved at repack time so that the two values an output needs are 8 columns apart in one 16-column tile)
+template <typename T, int MT, int PD, int TPP, int SG, int EPI = EPI_NONE>
+__global__ __launch_bounds__(kAwqWaves * 64, 1) void awq_gemm_kernel(const AwqGemmParams p, int ntiles, float* slabs,
+                                                                     const EpiParams ep = EpiParams{}) {
   typedef ElemTraits<T> Tr;
   typedef typename Tr::vec8 vec8;
   static_assert(TPP == 1 || TPP % PD == 0, "static slot indices");
@@ -150,6 +167,7 @@ __global__ __launch_bounds__(kAwqWaves * 64, 1) void awq_gemm_kernel(const AwqGe
   const int nb = min(kAwqWaves * kAwqBpw, p.KB - b0);  // k-blocks of this range
   const int G_ = gridDim.x;
   const int cnt = (ntiles - (int)blockIdx.x + G_ - 1) / G_;  // tiles of this workgroup: blockIdx.x + j * G_
+  AWQ_STAMP(0);  // kernel entry
 
   // ---- X fragments of this wave's k-blocks, once: coalesced 256-byte row pieces -> swizzled wave-private LDS image ->
   // A-operand registers (lane (a, g) holds X[m = 16 mt + a][128 b + 32 s + 8 g .. + 7]) ----
@@ -182,6 +200,7 @@ __global__ __launch_bounds__(kAwqWaves * 64, 1) void awq_gemm_kernel(const AwqGe
     }
   }
 
+  AWQ_STAMP(1);  // X fragments built
   const int64_t wbytes64 = (int64_t)(p.N / 16) * p.KB * 1024;
   const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.qpacked, 0, (unsigned)min(wbytes64, (int64_t)0xFFFFFFF0ll), 0x00020000);
   u32x4_t wreg[PD][kAwqBpw];
@@ -208,6 +227,12 @@ __global__ __launch_bounds__(kAwqWaves * 64, 1) void awq_gemm_kernel(const AwqGe
   const int em = tid >> 4, en = tid & 15;  // this thread's output element of every tile
   const bool has_bias = p.bias != nullptr;
   const T* biasp = has_bias ? (const T*)p.bias : (const T*)p.sz;  // any readable address when absent
+  int64_t ep_loc = 0;
+  const float* ep_cs = nullptr;
+  if constexpr (EPI == EPI_ROPE) {
+    ep_loc = ep.loc[min(em, p.M - 1)];
+    ep_cs = ep.cos_sin + ep.positions[min(em, p.M - 1)] * 128;
+  }
 
   for (int j0 = 0; j0 < cnt; j0 += TPP) {
     uint16_t braw[TPP];
@@ -223,6 +248,7 @@ __global__ __launch_bounds__(kAwqWaves * 64, 1) void awq_gemm_kernel(const AwqGe
       const int j = j0 + jj;
       const int slot = (TPP == 1) ? 0 : (jj % PD);
       f32x4_t acc[MT];
+      AWQ_STAMP(2 + 7 * (j0 / TPP) + jj);  // tile jj of the phase starts
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -243,7 +269,9 @@ __global__ __launch_bounds__(kAwqWaves * 64, 1) void awq_gemm_kernel(const AwqGe
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[jj][w][mt * 16 + 4 * g + r][a] = acc[mt][r];
     }
+    AWQ_STAMP(6 + 7 * (j0 / TPP));  // this phase's tiles dequantised and multiplied, partial sums in LDS
     __syncthreads();
+    AWQ_STAMP(7 + 7 * (j0 / TPP));  // barrier passed
     if (em < MT * 16) {
 #pragma unroll
       for (int jj = 0; jj < TPP; ++jj) {
@@ -255,12 +283,23 @@ __global__ __launch_bounds__(kAwqWaves * 64, 1) void awq_gemm_kernel(const AwqGe
         const bool live = j < cnt && em < p.M && n0 + en < p.N;
         if (slabs != nullptr) {
           if (live) slabs[((int64_t)kr * p.M + em) * p.N + n0 + en] = v;
-        } else if (live) {
+        } else {
           if (has_bias) v += (float)__builtin_bit_cast(T, braw[jj]);
-          ((T*)p.y)[(int64_t)em * p.y_stride + n0 + en] = (T)v;
+          if constexpr (EPI == EPI_NONE) {
+            if (live) ((T*)p.y)[(int64_t)em * p.y_stride + n0 + en] = (T)v;
+          } else {
+            float cv = 0.f, sv = 0.f;
+            if constexpr (EPI == EPI_ROPE) {
+              const int i = 8 * ((n0 & 127) >> 4) + (en & 7);
+              cv = ep_cs[i];
+              sv = ep_cs[64 + i];
+            }
+            epi_store<T, EPI>(v, live, em, en, n0, 16, ep, p.y, p.y_stride, cv, sv, ep_loc);
+          }
         }
       }
     }
+    AWQ_STAMP(8 + 7 * (j0 / TPP));  // outputs stored
     if (TPP > 1) __syncthreads();  // the next phase overwrites red
   }
 }
@@ -330,17 +369,17 @@ inline int awq_cus() {
   return cus;
 }
 
-template <typename T, int MT, int SG>
-int awq_launch(const AwqGemmParams& p, int kranges, float* slabs, hipStream_t st) {
+template <typename T, int MT, int SG, int EPI = EPI_NONE>
+int awq_launch(const AwqGemmParams& p, int kranges, float* slabs, hipStream_t st, const EpiParams& ep = EpiParams{}) {
   const int cus = awq_cus();
   const int per_range = cus / kranges > 0 ? cus / kranges : 1;
   const int ntiles = p.N / 16;
   const int gx = ntiles < per_range ? ntiles : per_range;
   const dim3 grid(gx, kranges);
   if (ntiles <= gx)
-    hipLaunchKernelGGL((awq_gemm_kernel<T, MT, 1, 1, SG>), grid, dim3(kAwqWaves * 64), 0, st, p, ntiles, slabs);
+    hipLaunchKernelGGL((awq_gemm_kernel<T, MT, 1, 1, SG, EPI>), grid, dim3(kAwqWaves * 64), 0, st, p, ntiles, slabs, ep);
   else
-    hipLaunchKernelGGL((awq_gemm_kernel<T, MT, 2, 4, SG>), grid, dim3(kAwqWaves * 64), 0, st, p, ntiles, slabs);
+    hipLaunchKernelGGL((awq_gemm_kernel<T, MT, 2, 4, SG, EPI>), grid, dim3(kAwqWaves * 64), 0, st, p, ntiles, slabs, ep);
   SGL_HIP_LAUNCH_CHECK();
   return SGL_MI355_OK;
 }
@@ -373,13 +412,13 @@ __global__ __launch_bounds__(256) void awq_unpack_nk_kernel(const uint32_t* __re
   }
 }
 
-template <typename T>
-int awq_dispatch(const AwqGemmParams& p, int kranges, float* slabs, hipStream_t st) {
+template <typename T, int EPI = EPI_NONE>
+int awq_dispatch(const AwqGemmParams& p, int kranges, float* slabs, hipStream_t st, const EpiParams& ep = EpiParams{}) {
   const int sg = p.G % 128 == 0 ? 1 : 128 / p.G;
-#define SGL_AWQ_CASE(MTv)                                                   \
-  if (sg == 1) return awq_launch<T, MTv, 1>(p, kranges, slabs, st);         \
-  if (sg == 2) return awq_launch<T, MTv, 2>(p, kranges, slabs, st);         \
-  return awq_launch<T, MTv, 4>(p, kranges, slabs, st)
+#define SGL_AWQ_CASE(MTv)                                                            \
+  if (sg == 1) return awq_launch<T, MTv, 1, EPI>(p, kranges, slabs, st, ep);         \
+  if (sg == 2) return awq_launch<T, MTv, 2, EPI>(p, kranges, slabs, st, ep);         \
+  return awq_launch<T, MTv, 4, EPI>(p, kranges, slabs, st, ep)
   if (p.M <= 16) { SGL_AWQ_CASE(1); }
   SGL_AWQ_CASE(2);
 #undef SGL_AWQ_CASE
@@ -466,26 +505,37 @@ extern "C" int sgl_mi355_awq_repack(const void* qweight, const void* scales, con
 // f32 [M, N] slabs of workspace sgl_mi355_awq_gemm wants (1: none)
 extern "C" int sgl_mi355_awq_gemm_num_kranges(int K) { return (K / 128 + kAwqWaves * kAwqBpw - 1) / (kAwqWaves * kAwqBpw); }
 
-// y [M, N] = x [M, K] . dequant(qpacked, sz) (+ bias); M <= 32; dtype of x / y / bias / scales: SGL_BF16 or SGL_F16.
-extern "C" int sgl_mi355_awq_gemm(const void* x, int64_t x_stride_elems, const void* qpacked, const void* sz, void* y,
-                                  int64_t y_stride_elems, const void* bias, int M, int N, int K, int group_size, int dtype,
-                                  float* workspace, int64_t workspace_floats, void* stream) {
-  SGL_CHECK(M >= 0 && N > 0 && K > 0 && group_size > 0, "awq_gemm: bad shape");
-  if (M == 0) return SGL_MI355_OK;
-  SGL_CHECK(M <= 32, "awq_gemm: M=%d exceeds 32 (use awq_dequantize + the tiled GEMM)", M);
-  SGL_CHECK(x && qpacked && sz && y, "awq_gemm: null pointer");
-  SGL_CHECK(K % 128 == 0 && N % 16 == 0, "awq_gemm: needs K %% 128 == 0 and N %% 16 == 0 (K=%d N=%d)", K, N);
+namespace {
+// argument checks and parameter block shared by the awq_gemm entry points
+int awq_params(AwqGemmParams& p, const char* who, const void* x, int64_t x_stride_elems, const void* qpacked, const void* sz, void* y,
+               int64_t y_stride_elems, const void* bias, int M, int N, int K, int group_size, int dtype) {
+  SGL_CHECK(M > 0 && N > 0 && K > 0 && group_size > 0, "%s: bad shape", who);
+  SGL_CHECK(M <= 32, "%s: M=%d exceeds 32 (use awq_dequantize + the tiled GEMM)", who, M);
+  SGL_CHECK(x && qpacked && sz && y, "%s: null pointer", who);
+  SGL_CHECK(K % 128 == 0 && N % 16 == 0, "%s: needs K %% 128 == 0 and N %% 16 == 0 (K=%d N=%d)", who, K, N);
   SGL_CHECK(K % group_size == 0 && (group_size % 128 == 0 || group_size == 64 || group_size == 32),
-            "awq_gemm: group_size=%d must be 32, 64 or a multiple of 128 dividing K", group_size);
-  SGL_CHECK(dtype == SGL_BF16 || dtype == SGL_F16, "awq_gemm: dtype must be bf16 or f16");
+            "%s: group_size=%d must be 32, 64 or a multiple of 128 dividing K", who, group_size);
+  SGL_CHECK(dtype == SGL_BF16 || dtype == SGL_F16, "%s: dtype must be bf16 or f16", who);
   SGL_CHECK(x_stride_elems % 8 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)qpacked % 16) == 0,
-            "awq_gemm: x rows and qpacked must be 16-byte aligned");
-  SGL_CHECK((int64_t)K * N / 2 < 0xFFFFFFF0ll, "awq_gemm: weight larger than 4 GiB");
-  AwqGemmParams p;
+            "%s: x rows and qpacked must be 16-byte aligned", who);
+  SGL_CHECK((int64_t)K * N / 2 < 0xFFFFFFF0ll, "%s: weight larger than 4 GiB", who);
   p.x = (const char*)x; p.x_stride = x_stride_elems;
   p.qpacked = (const uint32_t*)qpacked; p.sz = (const uint32_t*)sz;
   p.y = y; p.y_stride = y_stride_elems; p.bias = bias;
   p.M = M; p.N = N; p.K = K; p.G = group_size; p.KB = K / 128;
+  return SGL_MI355_OK;
+}
+}  // namespace
+
+// y [M, N] = x [M, K] . dequant(qpacked, sz) (+ bias); M <= 32; dtype of x / y / bias / scales: SGL_BF16 or SGL_F16.
+extern "C" int sgl_mi355_awq_gemm(const void* x, int64_t x_stride_elems, const void* qpacked, const void* sz, void* y,
+                                  int64_t y_stride_elems, const void* bias, int M, int N, int K, int group_size, int dtype,
+                                  float* workspace, int64_t workspace_floats, void* stream) {
+  SGL_CHECK(M >= 0, "awq_gemm: bad shape");
+  if (M == 0) return SGL_MI355_OK;
+  AwqGemmParams p;
+  const int prc = awq_params(p, "awq_gemm", x, x_stride_elems, qpacked, sz, y, y_stride_elems, bias, M, N, K, group_size, dtype);
+  if (prc != SGL_MI355_OK) return prc;
   hipStream_t st = (hipStream_t)stream;
   const int kranges = sgl_mi355_awq_gemm_num_kranges(K);
   float* slabs = nullptr;
@@ -506,4 +556,55 @@ extern "C" int sgl_mi355_awq_gemm(const void* x, int64_t x_stride_elems, const v
                        (_Float16*)y, y_stride_elems, M, N);
   SGL_HIP_LAUNCH_CHECK();
   return SGL_MI355_OK;
+}
+
+// Producer half of the launch-boundary split-K reduce for an int4 weight: raw f32 partial sums [kranges, M, N]
+// (kranges = sgl_mi355_awq_gemm_num_kranges(K), also 1); the consumer (sgl_mi355_fused_add_rmsnorm_quant_fp8 with slabs and no
+// scales) sums them in the order awq_gemm's own reduce kernel does.
+extern "C" int sgl_mi355_awq_gemm_slabs(const void* x, int64_t x_stride_elems, const void* qpacked, const void* sz, float* slabs,
+                                        int M, int N, int K, int group_size, int dtype, void* stream) {
+  AwqGemmParams p;
+  const int prc = awq_params(p, "awq_gemm_slabs", x, x_stride_elems, qpacked, sz, slabs, N, nullptr, M, N, K, group_size, dtype);
+  if (prc != SGL_MI355_OK) return prc;
+  const int kranges = sgl_mi355_awq_gemm_num_kranges(K);
+  return dtype == SGL_BF16 ? awq_dispatch<__bf16>(p, kranges, slabs, (hipStream_t)stream)
+                           : awq_dispatch<_Float16>(p, kranges, slabs, (hipStream_t)stream);
+}
+
+// act [M, N/2] = SiluAndMul(awq_gemm(x, W)) in one launch (AWQLinearMethod.apply awq.py:401-418 -> SiluAndMul activation.py:60-63):
+// the weight's packed columns are interleaved BEFORE sgl_mi355_awq_repack so that 16-column tile t = [gate columns 8t..8t+7 | up
+// columns 8t..8t+7].  K <= 4096 (one k-range).  Bit-identical to awq_gemm followed by silu_and_mul.
+extern "C" int sgl_mi355_awq_gemm_silu_mul(const void* x, int64_t x_stride_elems, const void* qpacked_interleaved,
+                                           const void* sz_interleaved, void* act, int64_t act_stride_elems, int M, int N, int K,
+                                           int group_size, int dtype, void* stream) {
+  AwqGemmParams p;
+  const int prc = awq_params(p, "awq_gemm_silu_mul", x, x_stride_elems, qpacked_interleaved, sz_interleaved, act, act_stride_elems,
+                             nullptr, M, N, K, group_size, dtype);
+  if (prc != SGL_MI355_OK) return prc;
+  SGL_CHECK(sgl_mi355_awq_gemm_num_kranges(K) == 1, "awq_gemm_silu_mul: K=%d exceeds one k-range (4096)", K);
+  return dtype == SGL_BF16 ? awq_dispatch<__bf16, EPI_SILU>(p, 1, nullptr, (hipStream_t)stream)
+                           : awq_dispatch<_Float16, EPI_SILU>(p, 1, nullptr, (hipStream_t)stream);
+}
+
+// qkv_proj (int4) + neox RoPE + set_kv_buffer in one launch: columns interleaved before the repack so that inside every q / k
+// head tile u = [columns 8u..8u+7 | columns 64+8u..64+8u+7]; v heads in natural order.  head_dim = rotary_dim = 128, K <= 4096.
+// Bit-identical to awq_gemm -> rope_set_kv.
+extern "C" int sgl_mi355_awq_qkv_rope_set_kv(const void* x, int64_t x_stride_elems, const void* qpacked_interleaved,
+                                             const void* sz_interleaved, void* q_out, int64_t q_stride_elems,
+                                             const void* bias_interleaved, const int64_t* positions, const float* cos_sin_cache,
+                                             const int64_t* loc, void* k_buffer, void* v_buffer, int64_t k_slot_stride,
+                                             int64_t v_slot_stride, int M, int num_q_heads, int num_kv_heads, int head_dim, int K,
+                                             int group_size, int dtype, void* stream) {
+  SGL_CHECK(positions && cos_sin_cache && loc && k_buffer && v_buffer, "awq_qkv_rope_set_kv: null pointer");
+  SGL_CHECK(head_dim == 128, "awq_qkv_rope_set_kv: head_dim (= rotary_dim) must be 128, got %d", head_dim);
+  AwqGemmParams p;
+  const int prc = awq_params(p, "awq_qkv_rope_set_kv", x, x_stride_elems, qpacked_interleaved, sz_interleaved, q_out, q_stride_elems,
+                             bias_interleaved, M, (num_q_heads + 2 * num_kv_heads) * 128, K, group_size, dtype);
+  if (prc != SGL_MI355_OK) return prc;
+  SGL_CHECK(sgl_mi355_awq_gemm_num_kranges(K) == 1, "awq_qkv_rope_set_kv: K=%d exceeds one k-range (4096)", K);
+  EpiParams ep;
+  ep.positions = positions; ep.cos_sin = cos_sin_cache; ep.loc = loc; ep.k_buf = k_buffer; ep.v_buf = v_buffer;
+  ep.k_slot_stride = k_slot_stride; ep.v_slot_stride = v_slot_stride; ep.hq = num_q_heads; ep.hkv = num_kv_heads;
+  return dtype == SGL_BF16 ? awq_dispatch<__bf16, EPI_ROPE>(p, 1, nullptr, (hipStream_t)stream, ep)
+                           : awq_dispatch<_Float16, EPI_ROPE>(p, 1, nullptr, (hipStream_t)stream, ep);
 }

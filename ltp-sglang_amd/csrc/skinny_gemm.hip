@@ -15,6 +15,7 @@
 // straight into MFMA A-fragments.  The 4 waves of a workgroup split K; one LDS reduction and
 // the fused scale/bias epilogue finish the tile.
 #include "common.h"
+#include "gemm_epilogue.h"
 
 namespace {
 
@@ -196,36 +197,6 @@ int launch(const SkinnyParams& p, hipStream_t st) {
 //    slowest of the 8 waves' loads.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kV2Waves = 8;
-
-// Fused epilogues (single k-range only).  Both rely on an INTERLEAVED weight row order so that the two values an output
-// needs sit in one 16-row tile, 8 columns apart (thread en and en ^ 8 of the same row m exchange them with one shuffle):
-//   EPI_SILU: tile t = [gate rows 8t..8t+7 | up rows 8t..8t+7]  -> act[m][8t+j] = T(T(silu(gate)) * up)
-//             (gate_up_proj + SiluAndMul, models/llama.py:94-98, activation.py:60-63)
-//   EPI_ROPE: inside every q/k head, tile u = [rows 8u..8u+7 | rows 64+8u..64+8u+7] (the neox rotation pairs); q is
-//             written rotated to q_out, k rotated and v straight into the KV pool rows loc[m]
-//             (qkv_proj -> rotary_emb -> set_kv_buffer, models/llama.py:180-191, rotary_embedding.py:49-72,
-//             memory_pool.py:401-407).  head_dim = rot_dim = 128.
-// Every rounding point of the unfused op sequence is kept (GEMM output -> T, each product -> T), so results are
-// bit-identical to running the separate kernels.
-enum { EPI_NONE = 0, EPI_SILU = 1, EPI_ROPE = 2 };
-struct EpiParams {
-  const int64_t* positions;
-  const float* cos_sin;  // [max_pos, 128]: cos | sin
-  const int64_t* loc;
-  void* k_buf;
-  void* v_buf;
-  int64_t k_slot_stride, v_slot_stride;  // elements
-  int hq, hkv;
-};
-
-template <typename T>
-__device__ __forceinline__ float rnd_to(float x) {
-  asm volatile("" : "+v"(x));  // materialise the f32 first: no single-rounding v_fma_mix shortcut
-  const T t = (T)x;
-  uint16_t u = __builtin_bit_cast(uint16_t, t), v;
-  asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "v"(u));
-  return (float)__builtin_bit_cast(T, v);
-}
 
 template <int ES, int MT, int DS, int PD, int TPP, typename OutT, int EPI = EPI_NONE, int NWV = kV2Waves>
 __global__ __launch_bounds__(NWV * 64, 1) void skinny_gemm_v2_kernel(const SkinnyParams p, int rpt, int ntiles,
@@ -409,33 +380,9 @@ __global__ __launch_bounds__(NWV * 64, 1) void skinny_gemm_v2_kernel(const Skinn
           if constexpr (EPI == EPI_NONE) {
             if (live) ((OutT*)p.y)[(int64_t)em * p.y_stride + n0 + en] = (OutT)v;
           } else {
-            const float vr = rnd_to<OutT>(v);             // the GEMM's own output rounding
-            const int H = rpt >> 1;                       // rows of each half of an interleaved tile (8, or 4 for 8-row tiles)
-            const float pr = __shfl_xor(vr, H, WAVE);     // the partner column of the same row m
-            const bool lo = (en & H) == 0;                // first half of the tile (gate / rotation-pair index i)
-            if constexpr (EPI == EPI_SILU) {
-              if (live && lo) {
-                const float sg = rnd_to<OutT>(vr / (1.0f + expf(-vr)));
-                ((OutT*)p.y)[(int64_t)em * p.y_stride + (n0 >> 1) + en] = (OutT)rnd_to<OutT>(sg * pr);
-              }
-            } else {
-              const int head = n0 >> 7, u = (n0 & 127) / rpt;
-              if (live) {
-                if (head < ep.hq + ep.hkv) {
-                  const int i = H * u + (en & (H - 1));
-                  const float c = rnd_to<OutT>(csc[e][jj]), sn = rnd_to<OutT>(css[e][jj]);
-                  const float x1 = lo ? vr : pr, x2 = lo ? pr : vr;
-                  const float o = lo ? rnd_to<OutT>(x1 * c) - rnd_to<OutT>(x2 * sn) : rnd_to<OutT>(x2 * c) + rnd_to<OutT>(x1 * sn);
-                  const int col = i + (lo ? 0 : 64);
-                  if (head < ep.hq)
-                    ((OutT*)p.y)[(int64_t)em * p.y_stride + head * 128 + col] = (OutT)o;
-                  else
-                    ((OutT*)ep.k_buf)[ep_loc[e] * ep.k_slot_stride + (head - ep.hq) * 128 + col] = (OutT)o;
-                } else {
-                  ((OutT*)ep.v_buf)[ep_loc[e] * ep.v_slot_stride + (head - ep.hq - ep.hkv) * 128 + (n0 & 127) + en] = (OutT)vr;
-                }
-              }
-            }
+            float cv = 0.f, sv = 0.f;
+            if constexpr (EPI == EPI_ROPE) { cv = csc[e][jj]; sv = css[e][jj]; }
+            epi_store<OutT, EPI>(v, live, em, en, n0, rpt, ep, p.y, p.y_stride, cv, sv, ep_loc[e]);
           }
         }
       }

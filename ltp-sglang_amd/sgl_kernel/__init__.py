@@ -17,6 +17,12 @@ from .elementwise import (
 from .fused import (
     decode_merge_quant_fp8,
     balanced_tile_rows,
+    awq_gate_up_col_order,
+    awq_rope_col_order,
+    awq_permute_cols,
+    awq_gemm_silu_mul,
+    awq_qkv_rope_set_kv,
+    awq_gemm_slabs,
     fp8_gemm_silu_mul,
     fp8_qkv_rope_set_kv,
     gemm_silu_mul,
@@ -30,6 +36,7 @@ from .fused import (
 from .gemm import (
     awq_dequantize,
     awq_gemm,
+    awq_gemm_num_kranges,
     awq_repack,
     awq_unpack_nk,
     dense_linear,

@@ -134,6 +134,64 @@ def qkv_rope_set_kv(x, w_interleaved_nk, bias_interleaved, positions, cos_sin_ca
     return q
 
 
+def awq_gate_up_col_order(n: int, device=None) -> torch.Tensor:
+    """Order of the N/8 packed columns (8 weights per int32) of an AWQ gate_up weight for awq_gemm_silu_mul: 16-column tile t =
+    (gate columns 8t..8t+7, up columns 8t..8t+7)."""
+    c = n // 16
+    return torch.arange(2 * c, device=device).view(2, c).t().reshape(-1)
+
+
+def awq_rope_col_order(num_q_heads: int, num_kv_heads: int, device=None) -> torch.Tensor:
+    """Order of the packed columns of an AWQ qkv weight for awq_qkv_rope_set_kv: inside every q / k head (16 packed columns)
+    tile u = (columns 8u..8u+7, columns 64+8u..64+8u+7); v heads unchanged."""
+    head = torch.arange(16, device=device).view(2, 8).t().reshape(-1)
+    nrope = num_q_heads + num_kv_heads
+    qk = (torch.arange(nrope, device=device).view(-1, 1) * 16 + head.view(1, -1)).reshape(-1)
+    return torch.cat([qk, torch.arange(nrope * 16, (nrope + num_kv_heads) * 16, device=device)])
+
+
+def awq_permute_cols(order: torch.Tensor, qweight, qzeros, scales, bias=None):
+    """Applies a packed-column order to an AWQ weight: qweight [K, N/8], qzeros [K/G, N/8], scales [K/G, N], bias [N]."""
+    g, n = scales.shape
+    out = (qweight[:, order].contiguous(), qzeros[:, order].contiguous(), scales.view(g, n // 8, 8)[:, order].reshape(g, n).contiguous())
+    return out + ((None if bias is None else bias.view(n // 8, 8)[order].reshape(n).contiguous()),)
+
+
+def awq_gemm_silu_mul(x, qpacked_interleaved, sz_interleaved, group_size: int):
+    """act [M, I] = SiluAndMul(awq_gemm(x, W)); W's packed columns in awq_gate_up_col_order before awq_repack."""
+    m, k = x.shape
+    n = sz_interleaved.shape[1]
+    assert x.stride(1) == 1 and qpacked_interleaved.is_contiguous() and sz_interleaved.is_contiguous()
+    act = torch.empty((m, n // 2), dtype=x.dtype, device=x.device)
+    check(lib.sgl_mi355_awq_gemm_silu_mul(ptr(x), x.stride(0), ptr(qpacked_interleaved), ptr(sz_interleaved), ptr(act), act.stride(0),
+                                          m, n, k, int(group_size), dtype_code(x.dtype), current_stream()))
+    return act
+
+
+def awq_qkv_rope_set_kv(x, qpacked_interleaved, sz_interleaved, bias_interleaved, group_size, positions, cos_sin_cache, loc,
+                        k_buffer, v_buffer, num_q_heads, num_kv_heads, head_dim):
+    """The int4 form of qkv_rope_set_kv: q [M, Hq*D] rotated; rotated k and v -> pool rows ``loc``."""
+    m, k = x.shape
+    assert x.stride(1) == 1 and k_buffer[0].is_contiguous() and v_buffer[0].is_contiguous() and cos_sin_cache.shape[1] == head_dim
+    q = torch.empty((m, num_q_heads * head_dim), dtype=x.dtype, device=x.device)
+    check(lib.sgl_mi355_awq_qkv_rope_set_kv(ptr(x), x.stride(0), ptr(qpacked_interleaved), ptr(sz_interleaved), ptr(q), q.stride(0),
+                                            ptr(bias_interleaved), ptr(positions), ptr(cos_sin_cache), ptr(loc), ptr(k_buffer),
+                                            ptr(v_buffer), k_buffer.stride(0), v_buffer.stride(0), m, num_q_heads, num_kv_heads,
+                                            head_dim, k, int(group_size), dtype_code(x.dtype), current_stream()))
+    return q
+
+
+def awq_gemm_slabs(x, qpacked, sz, group_size: int):
+    """Raw f32 split-K partial sums [S, M, N] of awq_gemm (no bias): consumed by fused_add_rmsnorm_quant_fp8(slabs=...)."""
+    m, k = x.shape
+    n = sz.shape[1]
+    kr = lib.sgl_mi355_awq_gemm_num_kranges(k)
+    out = torch.empty((kr, m, n), dtype=torch.float32, device=x.device)
+    check(lib.sgl_mi355_awq_gemm_slabs(ptr(x), x.stride(0), ptr(qpacked), ptr(sz), ptr(out), m, n, k, int(group_size),
+                                       dtype_code(x.dtype), current_stream()))
+    return out
+
+
 def balanced_tile_rows(n_rows: int) -> int:
     """16-row tiles, or 8-row tiles when 16-row tiles would leave the last round of the persistent workgroups mostly idle (the
     rule of the plain skinny GEMM's launcher): e.g. qkv_proj of Llama-3-8B, 384 tiles on 256 CUs."""

@@ -109,6 +109,11 @@ def awq_gemm(x: torch.Tensor, qpacked: torch.Tensor, sz: torch.Tensor, group_siz
     return out
 
 
+def awq_gemm_num_kranges(k: int) -> int:
+    """Split-K ranges of awq_gemm for this K (1: no slabs)."""
+    return int(lib.sgl_mi355_awq_gemm_num_kranges(int(k)))
+
+
 def fp8_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype, bias=None):
     """out[M,N] = (mat_a[M,K] @ mat_b[K,N]) * scales_a[m] * scales_b[n] (+ bias[n]).
 

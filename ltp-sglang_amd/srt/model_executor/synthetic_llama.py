@@ -340,9 +340,17 @@ class LlamaForCausalLM(nn.Module):
         return tensor_model_parallel_all_gather(logits) if tp > 1 else logits
 
     def _fused_dense_ok(self, forward_batch) -> bool:
-        return (self.fused_decode and forward_batch.forward_mode.is_decode() and self.quant_config is None
-                and self.tp_size == 1 and self.cfg.hidden_size <= 8192
-                and forward_batch.token_to_kv_pool.dtype != torch.float8_e4m3fn)
+        """Unquantised (bf16 / f16) weights, or int4 AWQ weights at M <= 32 (the fused dequant GEMM's range)."""
+        if not (self.fused_decode and forward_batch.forward_mode.is_decode() and self.tp_size == 1
+                and self.cfg.hidden_size <= 8192 and forward_batch.token_to_kv_pool.dtype != torch.float8_e4m3fn):
+            return False
+        if self.quant_config is None:
+            return True
+        if self.quant_config.get_name() != "awq" or forward_batch.batch_size > 32:
+            return False
+        lin = self.layers[0]
+        return all(getattr(mod, "_awq_packed", None) is not None and mod.scales.dtype == self.dtype
+                   for mod in (lin.self_attn.qkv_proj, lin.self_attn.o_proj, lin.mlp.gate_up_proj, lin.mlp.down_proj))
 
     def _fused_weights_dense(self, layer, m: int):
         """Row-interleaved copies of the unquantised qkv / gate_up weights for the GEMM epilogue fusions; None when the K
@@ -364,17 +372,48 @@ class LlamaForCausalLM(nn.Module):
                 gu_w=K.interleave_gate_up_rows(gw, tg), qkv_tile=tq, gu_tile=tg)
         return cached
 
+    def _fused_weights_awq(self, layer):
+        """Column-interleaved re-packs of the int4 qkv / gate_up weights for the fused dequant GEMM's epilogues (built once; one
+        extra int4 copy of those two); None when K exceeds one k-range (4096) or head_dim is not 128."""
+        if not self.fused_epilogues:
+            return None
+        attn, mlp = layer.self_attn, layer.mlp
+        if attn.head_dim != 128 or attn.qkv_proj.qweight.shape[0] > 4096:
+            return None
+        cached = getattr(layer, "_fused_w", None)
+        if cached is None:
+            hq, hkv = attn.num_heads, attn.num_kv_heads
+            dev = attn.qkv_proj.qweight.device
+
+            def repack(mod, order, bias):
+                qw, qz, sc, b = K.awq_permute_cols(order, mod.qweight.data, mod.qzeros.data, mod.scales.data, bias)
+                return K.awq_repack(qw, sc, qz) + (b,)
+
+            q = repack(attn.qkv_proj, K.awq_rope_col_order(hq, hkv, dev), None if attn.qkv_proj.bias is None else attn.qkv_proj.bias.data)
+            g = repack(mlp.gate_up_proj, K.awq_gate_up_col_order(mlp.gate_up_proj.scales.shape[1], dev), None)
+            cached = layer._fused_w = dict(qkv_qp=q[0], qkv_sz=q[1], qkv_b=q[2], gu_qp=g[0], gu_sz=g[1])
+        return cached
+
     def forward_decode_fused_dense(self, input_ids, positions, forward_batch: ForwardBatch):
-        """The unquantised (bf16 / f16) decode step on fused kernels: 6 launches per layer instead of 10 -- add + RMSNorm
-        (consuming the previous down_proj's split-K partial sums), qkv GEMM with the RoPE + KV-write epilogue, attention with the
-        in-launch merge, o_proj, add + RMSNorm, gate_up GEMM with the SiluAndMul epilogue, down_proj (raw split-K slabs).  Every
-        fused kernel is bit-identical to the op sequence it replaces, so this path and forward() give the same logits."""
+        """The decode step of the 16-bit-activation linears -- unquantised bf16 / f16 weights (UnquantizedLinearMethod) or int4
+        AWQ weights (AWQLinearMethod at M <= 32) -- on fused kernels: 6 launches per layer instead of 10: add + RMSNorm (consuming
+        the previous down_proj's split-K partial sums), qkv GEMM with the RoPE + KV-write epilogue, attention with the in-launch
+        merge, o_proj, add + RMSNorm, gate_up GEMM with the SiluAndMul epilogue, down_proj (raw split-K slabs).  Every fused
+        kernel is bit-identical to the op sequence it replaces, so this path and forward() give the same logits."""
         pool = forward_batch.token_to_kv_pool
         m = input_ids.numel()
+        awq = self.quant_config is not None
+        gsz = self.quant_config.group_size if awq else 0
         hidden = K.embedding(input_ids, self.embed_tokens)
         residual, slabs = None, None
         norm = lambda x, res, ln, sl=None: K.fused_add_rmsnorm_quant_fp8(
             x, res, ln.weight.data, ln.variance_epsilon, slabs=sl, want_norm=True, want_quant=False, dtype=self.dtype)[0]
+
+        def linear(mod, x):
+            if awq:
+                return K.awq_gemm(x, mod._awq_packed[0], mod._awq_packed[1], gsz, mod.bias)
+            return K.dense_linear(x, mod.weight.data, mod.bias)
+
         for layer in self.layers:
             attn, mlp = layer.self_attn, layer.mlp
             if residual is None:
@@ -383,28 +422,33 @@ class LlamaForCausalLM(nn.Module):
             else:
                 x = norm(hidden if slabs is None else None, residual, layer.input_layernorm, slabs)
             lid = attn.attn.layer_id
-            fw = self._fused_weights_dense(layer, m)
-            if fw is not None:
-                q = K.qkv_rope_set_kv(x, fw["qkv_w"], fw["qkv_b"], positions, attn.rotary_emb.cos_sin_cache,
-                                      forward_batch.out_cache_loc, pool.get_key_buffer(lid), pool.get_value_buffer(lid),
-                                      attn.num_heads, attn.num_kv_heads, attn.head_dim, fw["qkv_tile"])
+            fw = self._fused_weights_awq(layer) if awq else self._fused_weights_dense(layer, m)
+            rope_args = (positions, attn.rotary_emb.cos_sin_cache, forward_batch.out_cache_loc, pool.get_key_buffer(lid),
+                         pool.get_value_buffer(lid), attn.num_heads, attn.num_kv_heads, attn.head_dim)
+            if fw is not None and awq:
+                q = K.awq_qkv_rope_set_kv(x, fw["qkv_qp"], fw["qkv_sz"], fw["qkv_b"], gsz, *rope_args)
+            elif fw is not None:
+                q = K.qkv_rope_set_kv(x, fw["qkv_w"], fw["qkv_b"], *rope_args, fw["qkv_tile"])
             else:
-                qkv = K.dense_linear(x, attn.qkv_proj.weight.data, attn.qkv_proj.bias)
+                qkv = linear(attn.qkv_proj, x)
                 q, k, v = qkv.split([attn.q_size, attn.kv_size, attn.kv_size], dim=-1)
                 K.rope_set_kv(positions, q, k, v, attn.head_dim, attn.rotary_emb.cos_sin_cache, True, pool.get_key_buffer(lid),
                               pool.get_value_buffer(lid), forward_batch.out_cache_loc)
             o = attn.attn(q, None, None, forward_batch, save_kv_cache=False)
-            attn_out = K.dense_linear(o, attn.o_proj.weight.data, None)
-            h2 = norm(attn_out, residual, layer.post_attention_layernorm)
-            if fw is not None:
+            h2 = norm(linear(attn.o_proj, o), residual, layer.post_attention_layernorm)
+            if fw is not None and awq:
+                act = K.awq_gemm_silu_mul(h2, fw["gu_qp"], fw["gu_sz"], gsz)
+            elif fw is not None:
                 act = K.gemm_silu_mul(h2, fw["gu_w"], fw["gu_tile"])
             else:
-                act = K.silu_and_mul(K.dense_linear(h2, mlp.gate_up_proj.weight.data, None))
-            wd = mlp.down_proj.weight.data   # [N, K]
-            if m <= 64 and K.dense_linear_kranges(m, wd.shape[0], wd.shape[1], wd.dtype) > 1:
-                slabs = K.fp8_linear_slabs(act, wd, m, wd.shape[0], wd.shape[1])
+                act = K.silu_and_mul(linear(mlp.gate_up_proj, h2))
+            down = mlp.down_proj
+            if awq and K.awq_gemm_num_kranges(act.shape[1]) > 1:
+                slabs = K.awq_gemm_slabs(act, down._awq_packed[0], down._awq_packed[1], gsz)
+            elif not awq and m <= 64 and K.dense_linear_kranges(m, down.weight.shape[0], down.weight.shape[1], down.weight.dtype) > 1:
+                slabs = K.fp8_linear_slabs(act, down.weight.data, m, down.weight.shape[0], down.weight.shape[1])
             else:
-                slabs, hidden = None, K.dense_linear(act, wd, None)
+                slabs, hidden = None, linear(down, act)
         hidden = norm(hidden if slabs is None else None, residual, self.norm, slabs)
         return K.dense_linear(hidden, self.lm_head, None, out_dtype=self.dtype)
 

@@ -320,6 +320,78 @@ def test_awq_gemm_exact_small_integers(sk):
     assert torch.equal(y.cpu(), ref)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("m,k,i_dim,g", [(32, 3584, 2368, 128), (7, 1024, 256, 64), (16, 4096, 1792, 128), (20, 512, 128, 32)])
+def test_awq_gemm_silu_mul_bit_exact(m, k, i_dim, g, dtype, sk):
+    """int4 gate_up GEMM with the SiluAndMul epilogue (packed columns interleaved before the repack) == awq_gemm -> silu_and_mul."""
+    n = 2 * i_dim
+    qw, qz, sc = (t.to(DEV) for t in _awq_case(k, n, g, dtype, seed=m + k))
+    x = (torch.randn(m, k, generator=torch.Generator().manual_seed(m)) * 3).to(dtype).to(DEV)
+    qp, sz = sk.awq_repack(qw, sc, qz)
+    ref = sk.silu_and_mul(sk.awq_gemm(x, qp, sz, g))
+    pq, pz, ps, _ = sk.awq_permute_cols(sk.awq_gate_up_col_order(n, DEV), qw, qz, sc)
+    qpi, szi = sk.awq_repack(pq, ps, pz)
+    got = sk.awq_gemm_silu_mul(x, qpi, szi, g)
+    assert torch.isfinite(ref.float()).all() and ref.float().abs().max() > 0
+    assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("m,hq,hkv,bias,k,g", [(32, 28, 4, True, 3584, 128), (5, 4, 4, True, 1024, 64), (17, 8, 2, False, 4096, 128),
+                                              (1, 2, 1, True, 512, 128)])
+def test_awq_qkv_rope_set_kv_bit_exact(m, hq, hkv, bias, k, g, dtype, sk):
+    """int4 qkv GEMM with the RoPE + KV-write epilogue == awq_gemm -> rope -> set_kv_buffer."""
+    d = 128
+    n = (hq + 2 * hkv) * d
+    qw, qz, sc = (t.to(DEV) for t in _awq_case(k, n, g, dtype, seed=m + k))
+    gen = torch.Generator().manual_seed(m)
+    x = (torch.randn(m, k, generator=gen) * 3).to(dtype).to(DEV)
+    bvec = (torch.randn(n, generator=gen) * 0.1).to(dtype).to(DEV) if bias else None
+    positions = torch.randint(0, 4096, (m,), generator=gen).to(DEV)
+    cache = oe.rope_cache(d, d, 4096, 10000.0).to(DEV)
+    loc = (torch.randperm(99, generator=gen)[:m] + 1).to(DEV)
+    qp, sz = sk.awq_repack(qw, sc, qz)
+    qkv = sk.awq_gemm(x, qp, sz, g, bvec)
+    q, kk, vv = qkv.split([hq * d, hkv * d, hkv * d], dim=-1)
+    kb1 = torch.zeros(100, hkv, d, dtype=dtype, device=DEV)
+    vb1 = torch.zeros_like(kb1)
+    sk.rope_set_kv(positions, q, kk, vv, d, cache, True, kb1, vb1, loc)
+    pq, pz, ps, pb = sk.awq_permute_cols(sk.awq_rope_col_order(hq, hkv, DEV), qw, qz, sc, bvec)
+    qpi, szi = sk.awq_repack(pq, ps, pz)
+    kb2, vb2 = torch.zeros_like(kb1), torch.zeros_like(kb1)
+    q2 = sk.awq_qkv_rope_set_kv(x, qpi, szi, pb, g, positions, cache, loc, kb2, vb2, hq, hkv, d)
+    assert torch.equal(q2, q.contiguous()) and torch.equal(kb1, kb2) and torch.equal(vb1, vb2)
+
+
+def test_awq_fused_epilogues_reject_two_k_ranges(sk):
+    qw, qz, sc = (t.to(DEV) for t in _awq_case(4224, 256, 128, torch.float16, seed=1))
+    qp, sz = sk.awq_repack(qw, sc, qz)
+    x = torch.zeros(4, 4224, dtype=torch.float16, device=DEV)
+    with pytest.raises(RuntimeError, match="k-range"):
+        sk.awq_gemm_silu_mul(x, qp, sz, 128)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("m,n,k", [(32, 3584, 18944), (9, 512, 4224)])
+def test_awq_slabs_into_norm_bit_exact(m, n, k, dtype, sk):
+    """int4 down_proj as raw split-K slabs consumed by the next add + RMSNorm == awq_gemm -> fused_add_rmsnorm."""
+    g = 128
+    qw, qz, sc = (t.to(DEV) for t in _awq_case(k, n, g, dtype, seed=m + n))
+    gen = torch.Generator().manual_seed(k)
+    x = (torch.randn(m, k, generator=gen) * 3).to(dtype).to(DEV)
+    res = torch.randn(m, n, generator=gen).to(dtype).to(DEV)
+    wn = (1 + 0.1 * torch.randn(n, generator=gen)).to(dtype).to(DEV)
+    qp, sz = sk.awq_repack(qw, sc, qz)
+    assert sk.awq_gemm_num_kranges(k) > 1
+    y = sk.awq_gemm(x, qp, sz, g)
+    r1 = res.clone()
+    sk.fused_add_rmsnorm(y, r1, wn, 1e-5)
+    slabs = sk.awq_gemm_slabs(x, qp, sz, g)
+    r2 = res.clone()
+    out, _, _ = sk.fused_add_rmsnorm_quant_fp8(None, r2, wn, 1e-5, slabs=slabs, want_norm=True, want_quant=False, dtype=dtype)
+    assert torch.equal(r1, r2) and torch.equal(out, y)
+
+
 def test_awq_linear_method_fused_matches_unfused(sk, pkg):
     from ltp_sglang_amd.srt.layers.quantization.awq import AWQConfig, AWQLinearMethod
     k, n, g = 1024, 256, 128

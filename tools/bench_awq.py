@@ -38,6 +38,9 @@ def run(m, k, n, g=128, dtype=torch.bfloat16, copies=8):
         ws.append((qw, qz, sc) + K.awq_repack(qw, sc, qz))
     x = torch.randn(m, k, device=dev).to(dtype)
     fused = graph_time([(lambda w=w: K.awq_gemm(x, w[3], w[4], g)) for w in ws])
+    if os.environ.get("AWQ_BENCH_FUSED_ONLY"):
+        print(f"M={m} K={k} N={n}: fused {fused*1e3:7.1f} us ({k*n/2/fused/1e6:6.0f} GB/s of int4)", flush=True)
+        return
     def unfused(w):
         wkn = K.awq_dequantize(w[0], w[2], w[1])
         wnk = torch.empty((n, k), dtype=dtype, device=dev)
