@@ -192,7 +192,7 @@ def main():
             # (gloo rehearsal on one GPU: the WORLD group is already a CPU group)
             car = CustomAllreduce(dist.new_group(backend="gloo") if args.dist_backend == "nccl" else dist.group.WORLD, torch.device(dev))
             ok = not car.disabled
-            why = "" if ok else f"world size {world} unsupported"
+            why = car.disabled_reason
             if ok:
                 probe = torch.randn(32, 4096, device=dev, generator=torch.Generator(device=dev).manual_seed(rank)).to(torch.bfloat16)
                 want = probe.float()

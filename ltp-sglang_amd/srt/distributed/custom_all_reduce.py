@@ -25,6 +25,7 @@ class CustomAllreduce:
         """``group``: a CPU-capable (gloo) group used only to exchange the IPC handles; ``max_size``: largest message in bytes
         (the reference's default is 8 MiB, custom_all_reduce.py:58)."""
         self.disabled = True
+        self.disabled_reason = ""
         self.group = group
         self.rank = dist.get_rank(group)
         self.world_size = dist.get_world_size(group)
@@ -33,26 +34,55 @@ class CustomAllreduce:
         self._own = ctypes.c_void_p()
         self._peers: List[Optional[int]] = []
         if self.world_size == 1 or self.world_size not in _SUPPORTED_WORLD_SIZES:
+            self.disabled_reason = f"world size {self.world_size} not in {_SUPPORTED_WORLD_SIZES}"
             return
         torch.cuda.set_device(self.device)
+        # Every step that can fail on ONE rank (allocation, IPC export, mapping a peer) is followed by an exchange of the outcome,
+        # so all ranks end up enabled or all disabled and nobody waits in a collective a failed peer never enters.
         handle = (ctypes.c_ubyte * 64)()
-        check(lib.sgl_mi355_car_alloc(self.max_size, ctypes.byref(self._own), handle))
-        handles = [None] * self.world_size
-        dist.all_gather_object(handles, bytes(handle), group=group)
+        err = self._try(lambda: check(lib.sgl_mi355_car_alloc(self.max_size, ctypes.byref(self._own), handle)))
+        metas = [None] * self.world_size
+        dist.all_gather_object(metas, (err, bytes(handle)), group=group)
+        if any(e for e, _ in metas):
+            self.disabled_reason = "; ".join(f"rank {r}: {e}" for r, (e, _) in enumerate(metas) if e)
+            if not err:
+                lib.sgl_mi355_car_free(self._own)
+            return
         ptrs = (ctypes.c_void_p * self.world_size)()
-        for r, h in enumerate(handles):
-            if r == self.rank:
-                ptrs[r] = self._own.value
-                self._peers.append(None)
-            else:
-                peer = ctypes.c_void_p()
-                buf = (ctypes.c_ubyte * 64).from_buffer_copy(h)
-                check(lib.sgl_mi355_car_open(buf, ctypes.byref(peer)))
-                ptrs[r] = peer.value
-                self._peers.append(peer.value)
+
+        def open_peers():
+            for r, (_, h) in enumerate(metas):
+                if r == self.rank:
+                    ptrs[r] = self._own.value
+                    self._peers.append(None)
+                else:
+                    peer = ctypes.c_void_p()
+                    buf = (ctypes.c_ubyte * 64).from_buffer_copy(h)
+                    check(lib.sgl_mi355_car_open(buf, ctypes.byref(peer)))
+                    ptrs[r] = peer.value
+                    self._peers.append(peer.value)
+
+        err = self._try(open_peers)
+        outcomes = [None] * self.world_size
+        dist.all_gather_object(outcomes, err, group=group)   # also the barrier: every rank has mapped every buffer before anyone launches
+        if any(outcomes):
+            self.disabled_reason = "; ".join(f"rank {r}: {e}" for r, e in enumerate(outcomes) if e)
+            for p in self._peers:
+                if p is not None:
+                    lib.sgl_mi355_car_close(ctypes.c_void_p(p))
+            self._peers = []
+            lib.sgl_mi355_car_free(self._own)
+            return
         self._ptrs = ptrs
-        dist.barrier(group=group)   # every rank has mapped every buffer before anyone launches
         self.disabled = False
+
+    @staticmethod
+    def _try(fn) -> str:
+        try:
+            fn()
+            return ""
+        except Exception as e:   # reported to every rank; the communicator stays disabled everywhere
+            return f"{type(e).__name__}: {e}"
 
     def should_use(self, inp: torch.Tensor) -> bool:
         """should_custom_ar (custom_all_reduce.py:345-360): small, 16-byte multiples, contiguous."""

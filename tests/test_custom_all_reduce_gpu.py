@@ -40,8 +40,13 @@ def _worker(rank, world, port, q):
 
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
+    # a failure on ONE rank (here: rank 1 passes a size the C-ABI rejects) must leave EVERY rank disabled, with the reason, and
+    # nobody stuck in the handle exchange
+    bad = CustomAllreduce(dist.group.WORLD, dev, max_size=-16 if rank == 1 else 8 * 1024 * 1024)
+    assert bad.disabled and "rank 1" in bad.disabled_reason, bad.disabled_reason
+    assert not bad.should_use(torch.zeros(64, device=dev))
     car = CustomAllreduce(dist.group.WORLD, dev)
-    assert not car.disabled
+    assert not car.disabled and car.disabled_reason == ""
     ok, worst = True, 0.0
     for it, (shape, dtype) in enumerate(SHAPES * 2):   # twice: both data halves of every size, epochs keep counting
         g = torch.Generator().manual_seed(1000 * it + rank)
@@ -145,7 +150,7 @@ def test_one_shot_all_reduce_bit_exact_over_ipc(world, pkg):
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    ok, worst = q.get(timeout=300)
+    ok, worst = q.get(timeout=150)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
