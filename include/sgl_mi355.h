@@ -326,16 +326,18 @@ int64_t sgl_mi355_radix_node_info(void* tree, int64_t node, int64_t* parent, int
 int sgl_mi355_awq_repack(const void* qweight, const void* scales, const void* qzeros, void* qpacked, void* sz, int K, int N,
                          int group_size, int scale_dtype, void* stream);
 /* number of f32 [M, N] slabs sgl_mi355_awq_gemm needs as workspace for this K (1: none) */
-/* Dense W [N, K] (row-major, scale dtype) from the repacked image: awq_dequantize + transpose in one pass for the M > 32
+/* Dense W [N, K] (row-major, scale dtype) from the repacked image: awq_dequantize + transpose in one pass for the M > 64
  * (prefill) matmul of AWQLinearMethod.apply (awq.py:401-418); values are exactly awq_dequantize's. */
 int sgl_mi355_awq_unpack_nk(const void* qpacked, const void* sz, void* out, int N, int K, int group_size, int dtype,
                             void* stream);
-int sgl_mi355_awq_gemm_num_kranges(int K);
+/* split-K ranges of sgl_mi355_awq_gemm (f32 [M, N] slabs of workspace it wants; 1: none): 4096 k per range for M <= 32, 2048 k
+ * for 33..64 rows */
+int sgl_mi355_awq_gemm_num_kranges(int M, int K);
 int sgl_mi355_awq_gemm(const void* x, int64_t x_stride_elems, const void* qpacked, const void* sz, void* y,
                        int64_t y_stride_elems, const void* bias, int M, int N, int K, int group_size, int dtype,
                        float* workspace, int64_t workspace_floats, void* stream);
 /* Producer half of the launch-boundary split-K reduce for an int4 weight: raw f32 partial sums [kranges, M, N]
- * (kranges = sgl_mi355_awq_gemm_num_kranges(K)); consumed by sgl_mi355_fused_add_rmsnorm_quant_fp8 (slabs, no scales). */
+ * (kranges = sgl_mi355_awq_gemm_num_kranges(M, K)); consumed by sgl_mi355_fused_add_rmsnorm_quant_fp8 (slabs, no scales). */
 int sgl_mi355_awq_gemm_slabs(const void* x, int64_t x_stride_elems, const void* qpacked, const void* sz, float* slabs, int M,
                              int N, int K, int group_size, int dtype, void* stream);
 /* AWQLinearMethod.apply (awq.py:401-418) fused with the op that consumes it, bit-identical to awq_gemm followed by that op; the

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void awq_dequant_kernel(const uint32_t* __rest
 
 
 // ---------------------------------------------------------------------------------------------------------
-// Fused int4 dequant + skinny GEMM for decode-sized M (<= 32):  y[m][n] = sum_k x[m][k] * W[k][n] (+ bias), with
+// Fused int4 dequant + skinny GEMM for decode-sized M (<= 64):  y[m][n] = sum_k x[m][k] * W[k][n] (+ bias), with
 // W[k][n] EXACTLY the value awq_dequantize produces (the dequantisation happens in registers, between the global
 // load and the MFMA; nothing but int4 weights is ever read from HBM).
 //
@@ -58,7 +58,8 @@ __global__ __launch_bounds__(256) void awq_dequant_kernel(const uint32_t* __rest
 // Structure = the X-stationary skinny GEMM of skinny_gemm.hip without the LDS re-layout: one 512-thread workgroup per
 // CU; wave w owns k-blocks w, w+8, w+16, w+24 of the k-range (blockIdx.y: 32 blocks = 4096 k) for the whole launch and
 // keeps their X fragments in registers; the workgroup walks 16-column tiles; the 8 waves' partial sums of TPP tiles
-// meet in LDS between two barriers.  k-ranges > 1 (K > 4096) go through f32 slabs and a reduce kernel.
+// meet in LDS between two barriers.  k-ranges > 1 (K > 4096) go through f32 slabs and a reduce kernel.  33..64 rows (MT = 4):
+// two k-blocks per wave (k-range 2048), so the X fragments stay at 128 VGPRs; two output rows per thread in the epilogue.
 // Dequantisation, bit-identical to awq_dequantize's T(float(q - z) * float(s)):
 //   f16:  pair | 0x64006400 = (1024 + q) as packed f16; v_pk_add_f16 with -(1024 + z) gives q - z exactly; v_pk_mul_f16 by
 //         the scale rounds once  ->  2 VALU lane-ops per weight;
@@ -147,7 +148,9 @@ struct AwqDequant<__bf16> {
 };
 
 constexpr int kAwqWaves = 8;
-constexpr int kAwqBpw = 4;  // k-blocks (128 k each) per wave and k-range
+// k-blocks (128 k each) per wave and k-range: 4 (a k-range = 4096 k) while the X fragments of 32 rows fit the register budget,
+// 2 (k-range 2048) for 33..64 rows (MT = 4): 128 VGPRs of X fragments either way
+constexpr int awq_bpw(int mt) { return mt >= 4 ? 2 : 4; }
 
 // SG = scale groups per 128-k block (1: G % 128 == 0, 2: G = 64, 4: G = 32); EPI: gemm_epilogue.h (single k-range, columns
 // interleaved at repack time so that the two values an output needs are 8 columns apart in one 16-column tile)
@@ -157,6 +160,9 @@ __global__ __launch_bounds__(kAwqWaves * 64, 1) void awq_gemm_kernel(const AwqGe
   typedef ElemTraits<T> Tr;
   typedef typename Tr::vec8 vec8;
   static_assert(TPP == 1 || TPP % PD == 0, "static slot indices");
+  constexpr int kAwqBpw = awq_bpw(MT);
+  constexpr int EPT = (MT * 16 + 31) / 32;  // output rows per thread and tile (512 threads cover 32 rows x 16 columns)
+  static_assert(EPI == EPI_NONE || MT <= 2, "the fused epilogues keep one output row per thread");
   __shared__ float red[TPP][kAwqWaves][MT * 16][16];
   __shared__ __attribute__((aligned(16))) char ximg[kAwqWaves * 4096];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -224,14 +230,14 @@ __global__ __launch_bounds__(kAwqWaves * 64, 1) void awq_gemm_kernel(const AwqGe
 #pragma unroll
   for (int j = 0; j < PD; ++j) issue(j, j);
 
-  const int em = tid >> 4, en = tid & 15;  // this thread's output element of every tile
+  const int em0 = tid >> 4, en = tid & 15;  // this thread's output elements of every tile: rows em0 + 32 e, column en
   const bool has_bias = p.bias != nullptr;
   const T* biasp = has_bias ? (const T*)p.bias : (const T*)p.sz;  // any readable address when absent
   int64_t ep_loc = 0;
   const float* ep_cs = nullptr;
   if constexpr (EPI == EPI_ROPE) {
-    ep_loc = ep.loc[min(em, p.M - 1)];
-    ep_cs = ep.cos_sin + ep.positions[min(em, p.M - 1)] * 128;
+    ep_loc = ep.loc[min(em0, p.M - 1)];
+    ep_cs = ep.cos_sin + ep.positions[min(em0, p.M - 1)] * 128;
   }
 
   for (int j0 = 0; j0 < cnt; j0 += TPP) {
@@ -272,7 +278,10 @@ __global__ __launch_bounds__(kAwqWaves * 64, 1) void awq_gemm_kernel(const AwqGe
     AWQ_STAMP(6 + 7 * (j0 / TPP));  // this phase's tiles dequantised and multiplied, partial sums in LDS
     __syncthreads();
     AWQ_STAMP(7 + 7 * (j0 / TPP));  // barrier passed
-    if (em < MT * 16) {
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int em = em0 + 32 * e;
+      if (em >= MT * 16) continue;
 #pragma unroll
       for (int jj = 0; jj < TPP; ++jj) {
         const int j = j0 + jj;
@@ -379,7 +388,7 @@ int awq_launch(const AwqGemmParams& p, int kranges, float* slabs, hipStream_t st
   if (ntiles <= gx)
     hipLaunchKernelGGL((awq_gemm_kernel<T, MT, 1, 1, SG, EPI>), grid, dim3(kAwqWaves * 64), 0, st, p, ntiles, slabs, ep);
   else
-    hipLaunchKernelGGL((awq_gemm_kernel<T, MT, 2, 4, SG, EPI>), grid, dim3(kAwqWaves * 64), 0, st, p, ntiles, slabs, ep);
+    hipLaunchKernelGGL((awq_gemm_kernel<T, MT, 2, (MT >= 4 ? 2 : 4), SG, EPI>), grid, dim3(kAwqWaves * 64), 0, st, p, ntiles, slabs, ep);
   SGL_HIP_LAUNCH_CHECK();
   return SGL_MI355_OK;
 }
@@ -420,7 +429,9 @@ int awq_dispatch(const AwqGemmParams& p, int kranges, float* slabs, hipStream_t 
   if (sg == 2) return awq_launch<T, MTv, 2, EPI>(p, kranges, slabs, st, ep);         \
   return awq_launch<T, MTv, 4, EPI>(p, kranges, slabs, st, ep)
   if (p.M <= 16) { SGL_AWQ_CASE(1); }
-  SGL_AWQ_CASE(2);
+  if (p.M <= 32 || EPI != EPI_NONE) { SGL_AWQ_CASE(2); }
+  if constexpr (EPI == EPI_NONE) { SGL_AWQ_CASE(4); }
+  return SGL_MI355_EINVAL;
 #undef SGL_AWQ_CASE
 }
 
@@ -503,14 +514,17 @@ extern "C" int sgl_mi355_awq_repack(const void* qweight, const void* scales, con
 }
 
 // f32 [M, N] slabs of workspace sgl_mi355_awq_gemm wants (1: none)
-extern "C" int sgl_mi355_awq_gemm_num_kranges(int K) { return (K / 128 + kAwqWaves * kAwqBpw - 1) / (kAwqWaves * kAwqBpw); }
+extern "C" int sgl_mi355_awq_gemm_num_kranges(int M, int K) {
+  const int blocks = kAwqWaves * awq_bpw(M > 32 ? 4 : 2);  // 128-k blocks per k-range: 4096 k for M <= 32, 2048 k for 33..64
+  return (K / 128 + blocks - 1) / blocks;
+}
 
 namespace {
 // argument checks and parameter block shared by the awq_gemm entry points
 int awq_params(AwqGemmParams& p, const char* who, const void* x, int64_t x_stride_elems, const void* qpacked, const void* sz, void* y,
                int64_t y_stride_elems, const void* bias, int M, int N, int K, int group_size, int dtype) {
   SGL_CHECK(M > 0 && N > 0 && K > 0 && group_size > 0, "%s: bad shape", who);
-  SGL_CHECK(M <= 32, "%s: M=%d exceeds 32 (use awq_dequantize + the tiled GEMM)", who, M);
+  SGL_CHECK(M <= 64, "%s: M=%d exceeds 64 (use awq_unpack_nk + the tiled GEMM)", who, M);
   SGL_CHECK(x && qpacked && sz && y, "%s: null pointer", who);
   SGL_CHECK(K % 128 == 0 && N % 16 == 0, "%s: needs K %% 128 == 0 and N %% 16 == 0 (K=%d N=%d)", who, K, N);
   SGL_CHECK(K % group_size == 0 && (group_size % 128 == 0 || group_size == 64 || group_size == 32),
@@ -527,7 +541,7 @@ int awq_params(AwqGemmParams& p, const char* who, const void* x, int64_t x_strid
 }
 }  // namespace
 
-// y [M, N] = x [M, K] . dequant(qpacked, sz) (+ bias); M <= 32; dtype of x / y / bias / scales: SGL_BF16 or SGL_F16.
+// y [M, N] = x [M, K] . dequant(qpacked, sz) (+ bias); M <= 64; dtype of x / y / bias / scales: SGL_BF16 or SGL_F16.
 extern "C" int sgl_mi355_awq_gemm(const void* x, int64_t x_stride_elems, const void* qpacked, const void* sz, void* y,
                                   int64_t y_stride_elems, const void* bias, int M, int N, int K, int group_size, int dtype,
                                   float* workspace, int64_t workspace_floats, void* stream) {
@@ -537,7 +551,7 @@ extern "C" int sgl_mi355_awq_gemm(const void* x, int64_t x_stride_elems, const v
   const int prc = awq_params(p, "awq_gemm", x, x_stride_elems, qpacked, sz, y, y_stride_elems, bias, M, N, K, group_size, dtype);
   if (prc != SGL_MI355_OK) return prc;
   hipStream_t st = (hipStream_t)stream;
-  const int kranges = sgl_mi355_awq_gemm_num_kranges(K);
+  const int kranges = sgl_mi355_awq_gemm_num_kranges(M, K);
   float* slabs = nullptr;
   if (kranges > 1) {
     SGL_CHECK(workspace != nullptr && workspace_floats >= (int64_t)kranges * M * N && N % 4 == 0,
@@ -559,14 +573,14 @@ extern "C" int sgl_mi355_awq_gemm(const void* x, int64_t x_stride_elems, const v
 }
 
 // Producer half of the launch-boundary split-K reduce for an int4 weight: raw f32 partial sums [kranges, M, N]
-// (kranges = sgl_mi355_awq_gemm_num_kranges(K), also 1); the consumer (sgl_mi355_fused_add_rmsnorm_quant_fp8 with slabs and no
+// (kranges = sgl_mi355_awq_gemm_num_kranges(M, K), also 1); the consumer (sgl_mi355_fused_add_rmsnorm_quant_fp8 with slabs and no
 // scales) sums them in the order awq_gemm's own reduce kernel does.
 extern "C" int sgl_mi355_awq_gemm_slabs(const void* x, int64_t x_stride_elems, const void* qpacked, const void* sz, float* slabs,
                                         int M, int N, int K, int group_size, int dtype, void* stream) {
   AwqGemmParams p;
   const int prc = awq_params(p, "awq_gemm_slabs", x, x_stride_elems, qpacked, sz, slabs, N, nullptr, M, N, K, group_size, dtype);
   if (prc != SGL_MI355_OK) return prc;
-  const int kranges = sgl_mi355_awq_gemm_num_kranges(K);
+  const int kranges = sgl_mi355_awq_gemm_num_kranges(M, K);
   return dtype == SGL_BF16 ? awq_dispatch<__bf16>(p, kranges, slabs, (hipStream_t)stream)
                            : awq_dispatch<_Float16>(p, kranges, slabs, (hipStream_t)stream);
 }
@@ -581,7 +595,7 @@ extern "C" int sgl_mi355_awq_gemm_silu_mul(const void* x, int64_t x_stride_elems
   const int prc = awq_params(p, "awq_gemm_silu_mul", x, x_stride_elems, qpacked_interleaved, sz_interleaved, act, act_stride_elems,
                              nullptr, M, N, K, group_size, dtype);
   if (prc != SGL_MI355_OK) return prc;
-  SGL_CHECK(sgl_mi355_awq_gemm_num_kranges(K) == 1, "awq_gemm_silu_mul: K=%d exceeds one k-range (4096)", K);
+  SGL_CHECK(M <= 32 && sgl_mi355_awq_gemm_num_kranges(M, K) == 1, "awq_gemm_silu_mul: needs M <= 32 and K <= 4096 (one k-range); M=%d K=%d", M, K);
   return dtype == SGL_BF16 ? awq_dispatch<__bf16, EPI_SILU>(p, 1, nullptr, (hipStream_t)stream)
                            : awq_dispatch<_Float16, EPI_SILU>(p, 1, nullptr, (hipStream_t)stream);
 }
@@ -601,7 +615,7 @@ extern "C" int sgl_mi355_awq_qkv_rope_set_kv(const void* x, int64_t x_stride_ele
   const int prc = awq_params(p, "awq_qkv_rope_set_kv", x, x_stride_elems, qpacked_interleaved, sz_interleaved, q_out, q_stride_elems,
                              bias_interleaved, M, (num_q_heads + 2 * num_kv_heads) * 128, K, group_size, dtype);
   if (prc != SGL_MI355_OK) return prc;
-  SGL_CHECK(sgl_mi355_awq_gemm_num_kranges(K) == 1, "awq_qkv_rope_set_kv: K=%d exceeds one k-range (4096)", K);
+  SGL_CHECK(M <= 32 && sgl_mi355_awq_gemm_num_kranges(M, K) == 1, "awq_qkv_rope_set_kv: needs M <= 32 and K <= 4096 (one k-range); M=%d K=%d", M, K);
   EpiParams ep;
   ep.positions = positions; ep.cos_sin = cos_sin_cache; ep.loc = loc; ep.k_buf = k_buffer; ep.v_buf = v_buffer;
   ep.k_slot_stride = k_slot_stride; ep.v_slot_stride = v_slot_stride; ep.hq = num_q_heads; ep.hkv = num_kv_heads;

@@ -185,7 +185,7 @@ def awq_gemm_slabs(x, qpacked, sz, group_size: int):
     """Raw f32 split-K partial sums [S, M, N] of awq_gemm (no bias): consumed by fused_add_rmsnorm_quant_fp8(slabs=...)."""
     m, k = x.shape
     n = sz.shape[1]
-    kr = lib.sgl_mi355_awq_gemm_num_kranges(k)
+    kr = lib.sgl_mi355_awq_gemm_num_kranges(m, k)
     out = torch.empty((kr, m, n), dtype=torch.float32, device=x.device)
     check(lib.sgl_mi355_awq_gemm_slabs(ptr(x), x.stride(0), ptr(qpacked), ptr(sz), ptr(out), m, n, k, int(group_size),
                                        dtype_code(x.dtype), current_stream()))

@@ -91,7 +91,7 @@ def awq_unpack_nk(qpacked: torch.Tensor, sz: torch.Tensor, group_size: int, dtyp
 
 def awq_gemm(x: torch.Tensor, qpacked: torch.Tensor, sz: torch.Tensor, group_size: int,
              bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """y [M, N] = x [M, K] @ dequant(W) (+ bias) for M <= 32 on a weight re-laid by :func:`awq_repack`; the weight values
+    """y [M, N] = x [M, K] @ dequant(W) (+ bias) for M <= 64 on a weight re-laid by :func:`awq_repack`; the weight values
     are exactly awq_dequantize's (awq.py:401-418 computes the same product as dequantize + matmul)."""
     _cuda(x, qpacked, sz, bias)
     assert x.dim() == 2 and x.stride(1) == 1 and qpacked.is_contiguous() and sz.is_contiguous()
@@ -100,7 +100,7 @@ def awq_gemm(x: torch.Tensor, qpacked: torch.Tensor, sz: torch.Tensor, group_siz
     if qpacked.shape[0] * 16 != n or qpacked.shape[1] * 128 != k:
         raise RuntimeError("awq_gemm: x / qpacked / sz shapes do not match")
     out = torch.empty((m, n), dtype=x.dtype, device=x.device)
-    kr = lib.sgl_mi355_awq_gemm_num_kranges(k)
+    kr = lib.sgl_mi355_awq_gemm_num_kranges(m, k)
     ws, ws_n = None, 0
     if kr > 1:
         ws, ws_n = _workspace(x.device, kr * m * n)
@@ -109,9 +109,9 @@ def awq_gemm(x: torch.Tensor, qpacked: torch.Tensor, sz: torch.Tensor, group_siz
     return out
 
 
-def awq_gemm_num_kranges(k: int) -> int:
-    """Split-K ranges of awq_gemm for this K (1: no slabs)."""
-    return int(lib.sgl_mi355_awq_gemm_num_kranges(int(k)))
+def awq_gemm_num_kranges(m: int, k: int) -> int:
+    """Split-K ranges of awq_gemm for this M and K (1: no slabs)."""
+    return int(lib.sgl_mi355_awq_gemm_num_kranges(int(m), int(k)))
 
 
 def fp8_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype, bias=None):

@@ -2,7 +2,7 @@
 Marlin / MoE variants are NVIDIA layouts and out of scope).
 
 apply() computes the reference's product (:401-418): ``out = awq_dequantize(qweight, scales, qzeros); y = x @ out (+ bias)``.
-* decode-sized batches (M <= 32): the FUSED int4 dequant-GEMM (``sgl_kernel.awq_gemm``) on a copy of the weight re-laid
+* decode-sized batches (M <= 64): the FUSED int4 dequant-GEMM (``sgl_kernel.awq_gemm``) on a copy of the weight re-laid
   once in process_weights_after_loading (``awq_repack``; what awq_marlin_repack is to the reference's Marlin path) — only
   the int4 bytes are read, the weight values are bit-identical to awq_dequantize's;
 * larger M: awq_dequantize (bit-exact HIP kernel) + the tiled MFMA GEMM, the reference's unfused structure."""
@@ -83,7 +83,7 @@ class AWQLinearMethod(LinearMethodBase):
         out_shape = x.shape[:-1] + (qweight.shape[-1] * self.quant_config.pack_factor,)
         x2d = x.reshape(-1, x.shape[-1])
         packed = getattr(layer, "_awq_packed", None)
-        if packed is not None and x2d.shape[0] <= 32 and x2d.dtype == scales.dtype:
+        if packed is not None and x2d.shape[0] <= 64 and x2d.dtype == scales.dtype:
             return awq_gemm(x2d.contiguous(), packed[0], packed[1], self.quant_config.group_size, bias).reshape(out_shape)
         if packed is not None and x2d.dtype == scales.dtype:
             # prefill: the dense [N, K] weight straight from the repacked image (dequantise + transpose in one pass)

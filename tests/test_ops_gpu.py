@@ -286,6 +286,10 @@ def test_awq_repack_bit_exact_vs_oracle(k, n, g, dtype, sk):
     (1, 512, 144, 64, torch.bfloat16, False),        # two scale groups per 128-k block
     (16, 384, 48, 32, torch.float16, True),          # four scale groups per block, ragged last k-range
     (3, 1024, 64, 256, torch.bfloat16, False),       # group spanning two blocks
+    (64, 3584, 4608, 128, torch.float16, True),      # 33..64 rows: four X tiles, two k-blocks per wave (two k-ranges here)
+    (48, 18944, 3584, 128, torch.bfloat16, False),   # ten k-ranges
+    (33, 2048, 256, 64, torch.bfloat16, True),       # one k-range, ragged last X tile
+    (40, 384, 48, 32, torch.float16, False),
 ])
 def test_awq_gemm_vs_oracle(m, k, n, g, dtype, bias, sk):
     """Fused int4 dequant-GEMM == x @ awq_dequantize(...) of the oracle (float64 product of the SAME dequantised weights,
@@ -305,10 +309,12 @@ def test_awq_gemm_vs_oracle(m, k, n, g, dtype, bias, sk):
     assert err <= tol, (err, tol)
 
 
-def test_awq_gemm_exact_small_integers(sk):
+@pytest.mark.parametrize("m,k", [(20, 768), (64, 768), (50, 4608)])
+def test_awq_gemm_exact_small_integers(m, k, sk):
     # power-of-two scales and small-integer activations: every product and partial sum is exact, so the fused kernel
-    # must equal dequantize -> matmul bit for bit (pins the nibble order, zero points and group indexing)
-    k, n, g, m = 768, 96, 128, 20
+    # must equal dequantize -> matmul bit for bit (pins the nibble order, zero points and group indexing; M > 32: the four-tile
+    # instantiation and its k-range split)
+    n, g = 96, 128
     gen = torch.Generator().manual_seed(11)
     qw = torch.randint(-2**31, 2**31 - 1, (k, n // 8), generator=gen, dtype=torch.int32)
     qz = torch.randint(-2**31, 2**31 - 1, (k // g, n // 8), generator=gen, dtype=torch.int32)
@@ -382,7 +388,7 @@ def test_awq_slabs_into_norm_bit_exact(m, n, k, dtype, sk):
     res = torch.randn(m, n, generator=gen).to(dtype).to(DEV)
     wn = (1 + 0.1 * torch.randn(n, generator=gen)).to(dtype).to(DEV)
     qp, sz = sk.awq_repack(qw, sc, qz)
-    assert sk.awq_gemm_num_kranges(k) > 1
+    assert sk.awq_gemm_num_kranges(m, k) > 1
     y = sk.awq_gemm(x, qp, sz, g)
     r1 = res.clone()
     sk.fused_add_rmsnorm(y, r1, wn, 1e-5)
