@@ -340,13 +340,13 @@ class LlamaForCausalLM(nn.Module):
         return tensor_model_parallel_all_gather(logits) if tp > 1 else logits
 
     def _fused_dense_ok(self, forward_batch) -> bool:
-        """Unquantised (bf16 / f16) weights, or int4 AWQ weights at M <= 32 (the fused dequant GEMM's range)."""
+        """Unquantised (bf16 / f16) weights, or int4 AWQ weights at M <= 64 (the fused dequant GEMM's range)."""
         if not (self.fused_decode and forward_batch.forward_mode.is_decode() and self.tp_size == 1
                 and self.cfg.hidden_size <= 8192 and forward_batch.token_to_kv_pool.dtype != torch.float8_e4m3fn):
             return False
         if self.quant_config is None:
             return True
-        if self.quant_config.get_name() != "awq" or forward_batch.batch_size > 32:
+        if self.quant_config.get_name() != "awq" or forward_batch.batch_size > 64:
             return False
         lin = self.layers[0]
         return all(getattr(mod, "_awq_packed", None) is not None and mod.scales.dtype == self.dtype
@@ -372,10 +372,10 @@ class LlamaForCausalLM(nn.Module):
                 gu_w=K.interleave_gate_up_rows(gw, tg), qkv_tile=tq, gu_tile=tg)
         return cached
 
-    def _fused_weights_awq(self, layer):
+    def _fused_weights_awq(self, layer, m: int):
         """Column-interleaved re-packs of the int4 qkv / gate_up weights for the fused dequant GEMM's epilogues (built once; one
-        extra int4 copy of those two); None when K exceeds one k-range (4096) or head_dim is not 128."""
-        if not self.fused_epilogues:
+        extra int4 copy of those two); None when M > 32, K exceeds one k-range (4096) or head_dim is not 128."""
+        if not self.fused_epilogues or m > 32:
             return None
         attn, mlp = layer.self_attn, layer.mlp
         if attn.head_dim != 128 or attn.qkv_proj.qweight.shape[0] > 4096:
@@ -396,7 +396,7 @@ class LlamaForCausalLM(nn.Module):
 
     def forward_decode_fused_dense(self, input_ids, positions, forward_batch: ForwardBatch):
         """The decode step of the 16-bit-activation linears -- unquantised bf16 / f16 weights (UnquantizedLinearMethod) or int4
-        AWQ weights (AWQLinearMethod at M <= 32) -- on fused kernels: 6 launches per layer instead of 10: add + RMSNorm (consuming
+        AWQ weights (AWQLinearMethod at M <= 64; the GEMM epilogue fusions at M <= 32) -- on fused kernels: 6 launches per layer instead of 10: add + RMSNorm (consuming
         the previous down_proj's split-K partial sums), qkv GEMM with the RoPE + KV-write epilogue, attention with the in-launch
         merge, o_proj, add + RMSNorm, gate_up GEMM with the SiluAndMul epilogue, down_proj (raw split-K slabs).  Every fused
         kernel is bit-identical to the op sequence it replaces, so this path and forward() give the same logits."""
@@ -422,7 +422,7 @@ class LlamaForCausalLM(nn.Module):
             else:
                 x = norm(hidden if slabs is None else None, residual, layer.input_layernorm, slabs)
             lid = attn.attn.layer_id
-            fw = self._fused_weights_awq(layer) if awq else self._fused_weights_dense(layer, m)
+            fw = self._fused_weights_awq(layer, m) if awq else self._fused_weights_dense(layer, m)
             rope_args = (positions, attn.rotary_emb.cos_sin_cache, forward_batch.out_cache_loc, pool.get_key_buffer(lid),
                          pool.get_value_buffer(lid), attn.num_heads, attn.num_kv_heads, attn.head_dim)
             if fw is not None and awq:
