@@ -268,7 +268,9 @@ int sgl_mi355_fp8_qkv_rope_set_kv(const void* x, int64_t x_stride_elems, const v
                                   void* stream);
 /* The same two fusions for either operand type: in_dtype SGL_FP8_E4M3 (both scale vectors, out bf16 / f16) or SGL_BF16 /
  * SGL_F16 (UnquantizedLinearMethod.apply, quantization/unquant.py: scales NULL, out_dtype == in_dtype).  K must fit one
- * k-range of the weight-streaming kernel: 4096 bytes per row, 8192 at M <= 32. */
+ * k-range of the weight-streaming kernel: 4096 bytes per row, 8192 at M <= 32.  kv_dtype of the RoPE form: the pool's dtype =
+ * out_dtype, or SGL_FP8_E4M3 (kv_cache_dtype fp8_e4m3: set_kv_buffer's div_(scale) + e4m3 conversion, memory_pool.py:385-395;
+ * k_scale / v_scale <= 0: no scale). */
 int sgl_mi355_gemm_silu_mul(const void* x, int64_t x_stride_elems, const void* w_interleaved, int64_t w_stride_elems, void* act,
                             int64_t act_stride_elems, const float* scales_x, const float* scales_w_interleaved, int M, int N,
                             int K, int in_dtype, int out_dtype, int tile_rows, void* stream);
@@ -277,7 +279,7 @@ int sgl_mi355_qkv_rope_set_kv(const void* x, int64_t x_stride_elems, const void*
                               const void* bias_interleaved, const int64_t* positions, const float* cos_sin_cache,
                               const int64_t* loc, void* k_buffer, void* v_buffer, int64_t k_slot_stride, int64_t v_slot_stride,
                               int M, int num_q_heads, int num_kv_heads, int head_dim, int K, int in_dtype, int out_dtype,
-                              int tile_rows, void* stream);
+                              int tile_rows, int kv_dtype, float k_scale, float v_scale, void* stream);
 /* silu_and_mul (activation.py:60-63) -> sgl_per_token_quant_fp8 */
 int sgl_mi355_silu_and_mul_quant_fp8(const void* x, void* out_q, float* out_s, int tokens, int d, int dtype, void* stream);
 /* rotary_embedding (rotary_embedding.py:138-165) on q, k in place -> set_kv_buffer (memory_pool.py:369-407) of (k, v) */
@@ -351,7 +353,8 @@ int sgl_mi355_awq_qkv_rope_set_kv(const void* x, int64_t x_stride_elems, const v
                                   const void* sz_interleaved, void* q_out, int64_t q_stride_elems, const void* bias_interleaved,
                                   const int64_t* positions, const float* cos_sin_cache, const int64_t* loc, void* k_buffer,
                                   void* v_buffer, int64_t k_slot_stride, int64_t v_slot_stride, int M, int num_q_heads,
-                                  int num_kv_heads, int head_dim, int K, int group_size, int dtype, void* stream);
+                                  int num_kv_heads, int head_dim, int K, int group_size, int dtype, int kv_dtype, float k_scale,
+                                  float v_scale, void* stream);
 
 /* out[cols, rows] = in[rows, cols]^T for 16-bit elements (weight re-layout between awq_dequantize's [K, N] and
  * the [N, K] the GEMMs stream; AWQLinearMethod.apply, layers/quantization/awq.py:401-418) */

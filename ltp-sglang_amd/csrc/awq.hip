@@ -608,8 +608,9 @@ extern "C" int sgl_mi355_awq_qkv_rope_set_kv(const void* x, int64_t x_stride_ele
                                              const void* bias_interleaved, const int64_t* positions, const float* cos_sin_cache,
                                              const int64_t* loc, void* k_buffer, void* v_buffer, int64_t k_slot_stride,
                                              int64_t v_slot_stride, int M, int num_q_heads, int num_kv_heads, int head_dim, int K,
-                                             int group_size, int dtype, void* stream) {
+                                             int group_size, int dtype, int kv_dtype, float k_scale, float v_scale, void* stream) {
   SGL_CHECK(positions && cos_sin_cache && loc && k_buffer && v_buffer, "awq_qkv_rope_set_kv: null pointer");
+  SGL_CHECK(kv_dtype == dtype || kv_dtype == SGL_FP8_E4M3, "awq_qkv_rope_set_kv: the pool holds the activation dtype or float8_e4m3fn (kv_dtype %d)", kv_dtype);
   SGL_CHECK(head_dim == 128, "awq_qkv_rope_set_kv: head_dim (= rotary_dim) must be 128, got %d", head_dim);
   AwqGemmParams p;
   const int prc = awq_params(p, "awq_qkv_rope_set_kv", x, x_stride_elems, qpacked_interleaved, sz_interleaved, q_out, q_stride_elems,
@@ -619,6 +620,7 @@ extern "C" int sgl_mi355_awq_qkv_rope_set_kv(const void* x, int64_t x_stride_ele
   EpiParams ep;
   ep.positions = positions; ep.cos_sin = cos_sin_cache; ep.loc = loc; ep.k_buf = k_buffer; ep.v_buf = v_buffer;
   ep.k_slot_stride = k_slot_stride; ep.v_slot_stride = v_slot_stride; ep.hq = num_q_heads; ep.hkv = num_kv_heads;
+  ep.kv_fp8 = kv_dtype == SGL_FP8_E4M3 ? 1 : 0; ep.k_scale = k_scale; ep.v_scale = v_scale;
   return dtype == SGL_BF16 ? awq_dispatch<__bf16, EPI_ROPE>(p, 1, nullptr, (hipStream_t)stream, ep)
                            : awq_dispatch<_Float16, EPI_ROPE>(p, 1, nullptr, (hipStream_t)stream, ep);
 }

@@ -110,4 +110,27 @@ struct LseMerge {
   __device__ __forceinline__ float finish(float a) const { return L > 0.f ? a / L : 0.f; }
 };
 
+// ---- fp8 (e4m3fn) KV cache conversion (memory_pool.py:385-395): cache.div_(scale) in the source dtype when a scale is given
+// (scale <= 0: none), then .to(float8_e4m3fn) = round to nearest even, and what torch turns into NaN (|x| > 464, inf, NaN ->
+// 0x7F | sign; c10/util/Float8_e4m3fn.h) instead of the hardware's saturation to 448.  Shared by set_kv_buffer_fp8 and the
+// GEMM epilogues that write the pool, so both produce the same bytes.
+template <typename T>
+__device__ __forceinline__ float kv_fp8_scaled(float v, float scale) {
+  if (scale > 0.0f) {  // div_ rounds to the tensor dtype before the cast (forced through the bit pattern: clang keeps 16-bit
+    uint32_t bits = __builtin_bit_cast(uint16_t, (T)(v / scale));  // float expressions in excess precision)
+    asm volatile("" : "+v"(bits));
+    v = (float)__builtin_bit_cast(T, (uint16_t)bits);
+  }
+  return v;
+}
+__device__ __forceinline__ bool kv_fp8_is_nan(float f) { return !(fabsf(f) <= 464.0f); }
+__device__ __forceinline__ uint32_t kv_fp8_nan_byte(float f) { return 0x7Fu | ((__builtin_bit_cast(uint32_t, f) >> 24) & 0x80u); }
+// one value (already a T) -> its pool byte
+template <typename T>
+__device__ __forceinline__ uint8_t kv_fp8_byte(float v, float scale) {
+  const float f = kv_fp8_scaled<T>(v, scale);
+  const uint32_t w = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(f, f, 0, false);
+  return (uint8_t)(kv_fp8_is_nan(f) ? kv_fp8_nan_byte(f) : (w & 0xFFu));
+}
+
 static inline int cdiv_i(int a, int b) { return (a + b - 1) / b; }

@@ -10,7 +10,8 @@ namespace {
 //   EPI_SILU: tile t = [gate rows 8t..8t+7 | up rows 8t..8t+7]  -> act[m][8t+j] = T(T(silu(gate)) * up)
 //             (gate_up_proj + SiluAndMul, models/llama.py:94-98, activation.py:60-63)
 //   EPI_ROPE: inside every q/k head, tile u = [rows 8u..8u+7 | rows 64+8u..64+8u+7] (the neox rotation pairs); q is
-//             written rotated to q_out, k rotated and v straight into the KV pool rows loc[m]
+//             written rotated to q_out, k rotated and v straight into the KV pool rows loc[m] (16-bit pool, or float8_e4m3fn
+//             with set_kv_buffer's conversion)
 //             (qkv_proj -> rotary_emb -> set_kv_buffer, models/llama.py:180-191, rotary_embedding.py:49-72,
 //             memory_pool.py:401-407).  head_dim = rot_dim = 128.
 // Every rounding point of the unfused op sequence is kept (GEMM output -> T, each product -> T), so results are
@@ -24,6 +25,8 @@ struct EpiParams {
   void* v_buf;
   int64_t k_slot_stride, v_slot_stride;  // elements
   int hq, hkv;
+  int kv_fp8 = 0;                        // the pool is float8_e4m3fn (kv_cache_dtype fp8_e4m3): convert as set_kv_buffer does
+  float k_scale = -1.f, v_scale = -1.f;  // RadixAttention.k_scale / v_scale; <= 0: none
 };
 
 template <typename T>
@@ -63,8 +66,12 @@ __device__ __forceinline__ void epi_store(float v, bool live, int em, int en, in
         const int col = i + (lo ? 0 : 64);
         if (head < ep.hq)
           ((OutT*)y)[(int64_t)em * y_stride + head * 128 + col] = (OutT)o;
+        else if (ep.kv_fp8)
+          ((uint8_t*)ep.k_buf)[loc * ep.k_slot_stride + (head - ep.hq) * 128 + col] = kv_fp8_byte<OutT>(rnd_to<OutT>(o), ep.k_scale);
         else
           ((OutT*)ep.k_buf)[loc * ep.k_slot_stride + (head - ep.hq) * 128 + col] = (OutT)o;
+      } else if (ep.kv_fp8) {
+        ((uint8_t*)ep.v_buf)[loc * ep.v_slot_stride + (head - ep.hq - ep.hkv) * 128 + (n0 & 127) + en] = kv_fp8_byte<OutT>(vr, ep.v_scale);
       } else {
         ((OutT*)ep.v_buf)[loc * ep.v_slot_stride + (head - ep.hq - ep.hkv) * 128 + (n0 & 127) + en] = (OutT)vr;
       }

@@ -310,23 +310,13 @@ extern "C" int sgl_mi355_get_last_loc(const int32_t* req_to_token, int64_t req_t
 }
 
 // ---- fp8 (e4m3fn) KV cache: set_kv_buffer with kv_cache_dtype = fp8_e4m3 (memory_pool.py:385-395) ----
-// cache_k.div_(k_scale) in the source dtype (when a scale is given), then .to(float8_e4m3fn): round-to-nearest-even, and
-// what torch turns into NaN (|x| > 464, inf, NaN -> 0x7F | sign; c10/util/Float8_e4m3fn.h) instead of the hardware's
-// saturation to 448.
+// (conversion rules: common.h "fp8 (e4m3fn) KV cache conversion")
 namespace {
 template <typename T>
 __device__ __forceinline__ uint32_t cvt4_to_fp8(const T* x, float inv_or_zero, float scale) {
   float f[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    float v = (float)x[i];
-    if (scale > 0.0f) {  // div_ rounds to the tensor dtype before the cast (forced through the bit pattern: clang keeps
-      uint32_t bits = __builtin_bit_cast(uint16_t, (T)(v / scale));  // 16-bit float expressions in excess precision)
-      asm volatile("" : "+v"(bits));
-      v = (float)__builtin_bit_cast(T, (uint16_t)bits);
-    }
-    f[i] = v;
-  }
+  for (int i = 0; i < 4; ++i) f[i] = kv_fp8_scaled<T>((float)x[i], scale);
   (void)inv_or_zero;
   int w = 0;
   w = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], w, false);
@@ -334,10 +324,7 @@ __device__ __forceinline__ uint32_t cvt4_to_fp8(const T* x, float inv_or_zero, f
   uint32_t u = (uint32_t)w;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    if (!(fabsf(f[i]) <= 464.0f)) {
-      const uint32_t nanb = 0x7Fu | ((__builtin_bit_cast(uint32_t, f[i]) >> 24) & 0x80u);
-      u = (u & ~(0xFFu << (8 * i))) | (nanb << (8 * i));
-    }
+    if (kv_fp8_is_nan(f[i])) u = (u & ~(0xFFu << (8 * i))) | (kv_fp8_nan_byte(f[i]) << (8 * i));
   }
   return u;
 }

@@ -696,15 +696,17 @@ extern "C" int sgl_mi355_fp8_gemm_silu_mul(const void* x, int64_t x_stride_elems
 // qkv_proj + neox rotary embedding + set_kv_buffer in one launch (in_dtype as for sgl_mi355_gemm_silu_mul).  w_interleaved /
 // scales / bias rows: inside every q and k head (128 rows) tile u of tile_rows = 2 H rows = rows H u .. H u + H - 1 then rows
 // 64 + H u ..; v heads in natural order.  q (rotated) -> q_out [M, Hq*128]; k (rotated) and v -> pool rows loc[m] of k_buffer /
-// v_buffer ([slots, Hkv, 128], strides in elements).
+// v_buffer ([slots, Hkv, 128], strides in elements).  kv_dtype: the pool's dtype -- out_dtype, or SGL_FP8_E4M3 with set_kv_buffer's
+// conversion (k_scale / v_scale: the layer's scales, <= 0: none; memory_pool.py:385-395).
 extern "C" int sgl_mi355_qkv_rope_set_kv(const void* x, int64_t x_stride_elems, const void* w_interleaved, int64_t w_stride_elems,
                                          void* q_out, int64_t q_stride_elems, const float* scales_x,
                                          const float* scales_w_interleaved, const void* bias_interleaved,
                                          const int64_t* positions, const float* cos_sin_cache, const int64_t* loc,
                                          void* k_buffer, void* v_buffer, int64_t k_slot_stride, int64_t v_slot_stride, int M,
                                          int num_q_heads, int num_kv_heads, int head_dim, int K, int in_dtype, int out_dtype,
-                                         int tile_rows, void* stream) {
+                                         int tile_rows, int kv_dtype, float k_scale, float v_scale, void* stream) {
   SGL_CHECK(x && w_interleaved && q_out && positions && cos_sin_cache && loc && k_buffer && v_buffer, "qkv_rope_set_kv: null pointer");
+  SGL_CHECK(kv_dtype == out_dtype || kv_dtype == SGL_FP8_E4M3, "qkv_rope_set_kv: the pool holds the output dtype or float8_e4m3fn (kv_dtype %d)", kv_dtype);
   SGL_CHECK(head_dim == 128, "qkv_rope_set_kv: head_dim (= rotary_dim) must be 128, got %d", head_dim);
   SkinnyParams p;
   p.x = (const char*)x; p.x_stride = x_stride_elems; p.w = (const char*)w_interleaved; p.w_stride = w_stride_elems;
@@ -713,6 +715,7 @@ extern "C" int sgl_mi355_qkv_rope_set_kv(const void* x, int64_t x_stride_elems, 
   EpiParams ep;
   ep.positions = positions; ep.cos_sin = cos_sin_cache; ep.loc = loc; ep.k_buf = k_buffer; ep.v_buf = v_buffer;
   ep.k_slot_stride = k_slot_stride; ep.v_slot_stride = v_slot_stride; ep.hq = num_q_heads; ep.hkv = num_kv_heads;
+  ep.kv_fp8 = (kv_dtype == SGL_FP8_E4M3 && out_dtype != SGL_FP8_E4M3) ? 1 : 0; ep.k_scale = k_scale; ep.v_scale = v_scale;
   return run_epi<EPI_ROPE>(p, ep, in_dtype, out_dtype, tile_rows, (hipStream_t)stream, "qkv_rope_set_kv");
 }
 
@@ -728,5 +731,5 @@ extern "C" int sgl_mi355_fp8_qkv_rope_set_kv(const void* x, int64_t x_stride_ele
   return sgl_mi355_qkv_rope_set_kv(x, x_stride_elems, w_interleaved, w_stride_elems, q_out, q_stride_elems, scales_x,
                                    scales_w_interleaved, bias_interleaved, positions, cos_sin_cache, loc, k_buffer, v_buffer,
                                    k_slot_stride, v_slot_stride, M, num_q_heads, num_kv_heads, head_dim, K, SGL_FP8_E4M3, out_dtype,
-                                   tile_rows, stream);
+                                   tile_rows, out_dtype, -1.f, -1.f, stream);
 }

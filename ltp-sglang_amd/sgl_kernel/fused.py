@@ -93,17 +93,25 @@ def fp8_gemm_silu_mul(x_q, x_s, w_interleaved_nk, w_s_interleaved, out_dtype, ti
     return act
 
 
+def _kv_args(k_buffer, v_buffer, k_scale, v_scale):
+    """(kv_dtype code, k_scale, v_scale) of a pool write: the pool's dtype; scales only apply to float8_e4m3fn pools."""
+    assert k_buffer.dtype == v_buffer.dtype and k_buffer[0].is_contiguous() and v_buffer[0].is_contiguous()
+    return dtype_code(k_buffer.dtype), (-1.0 if k_scale is None else float(k_scale)), (-1.0 if v_scale is None else float(v_scale))
+
+
 def fp8_qkv_rope_set_kv(x_q, x_s, w_interleaved_nk, w_s_interleaved, bias_interleaved, positions, cos_sin_cache, loc, k_buffer,
-                        v_buffer, num_q_heads, num_kv_heads, head_dim, out_dtype, tile_rows: int = 16):
-    """q [M, Hq*D] (rotated); rotated k and v are written to pool rows ``loc`` of k_buffer / v_buffer."""
+                        v_buffer, num_q_heads, num_kv_heads, head_dim, out_dtype, tile_rows: int = 16, k_scale=None, v_scale=None):
+    """q [M, Hq*D] (rotated); rotated k and v are written to pool rows ``loc`` of k_buffer / v_buffer (16-bit pools, or
+    float8_e4m3fn pools with set_kv_buffer's conversion and the layer's k_scale / v_scale)."""
     m, k = x_q.shape
     q = torch.empty((m, num_q_heads * head_dim), dtype=out_dtype, device=x_q.device)
-    assert k_buffer[0].is_contiguous() and v_buffer[0].is_contiguous() and cos_sin_cache.shape[1] == head_dim
-    check(lib.sgl_mi355_fp8_qkv_rope_set_kv(ptr(x_q), x_q.stride(0), ptr(w_interleaved_nk), w_interleaved_nk.stride(0), ptr(q),
-                                            q.stride(0), ptr(x_s), ptr(w_s_interleaved), ptr(bias_interleaved), ptr(positions),
-                                            ptr(cos_sin_cache), ptr(loc), ptr(k_buffer), ptr(v_buffer), k_buffer.stride(0),
-                                            v_buffer.stride(0), m, num_q_heads, num_kv_heads, head_dim, k,
-                                            dtype_code(out_dtype), int(tile_rows), current_stream()))
+    assert cos_sin_cache.shape[1] == head_dim
+    check(lib.sgl_mi355_qkv_rope_set_kv(ptr(x_q), x_q.stride(0), ptr(w_interleaved_nk), w_interleaved_nk.stride(0), ptr(q),
+                                        q.stride(0), ptr(x_s), ptr(w_s_interleaved), ptr(bias_interleaved), ptr(positions),
+                                        ptr(cos_sin_cache), ptr(loc), ptr(k_buffer), ptr(v_buffer), k_buffer.stride(0),
+                                        v_buffer.stride(0), m, num_q_heads, num_kv_heads, head_dim, k, dtype_code(x_q.dtype),
+                                        dtype_code(out_dtype), int(tile_rows), *_kv_args(k_buffer, v_buffer, k_scale, v_scale),
+                                        current_stream()))
     return q
 
 
@@ -120,17 +128,17 @@ def gemm_silu_mul(x, w_interleaved_nk, tile_rows: int = 16):
 
 
 def qkv_rope_set_kv(x, w_interleaved_nk, bias_interleaved, positions, cos_sin_cache, loc, k_buffer, v_buffer, num_q_heads,
-                    num_kv_heads, head_dim, tile_rows: int = 16):
+                    num_kv_heads, head_dim, tile_rows: int = 16, k_scale=None, v_scale=None):
     """The bf16 / f16 form of fp8_qkv_rope_set_kv (unquantised qkv_proj): q [M, Hq*D] rotated; k, v -> pool rows ``loc``."""
     m, k = x.shape
     assert x.dtype == w_interleaved_nk.dtype and x.stride(1) == 1 and w_interleaved_nk.stride(1) == 1
     q = torch.empty((m, num_q_heads * head_dim), dtype=x.dtype, device=x.device)
-    assert k_buffer[0].is_contiguous() and v_buffer[0].is_contiguous() and cos_sin_cache.shape[1] == head_dim
+    assert cos_sin_cache.shape[1] == head_dim
     check(lib.sgl_mi355_qkv_rope_set_kv(ptr(x), x.stride(0), ptr(w_interleaved_nk), w_interleaved_nk.stride(0), ptr(q), q.stride(0),
                                         None, None, ptr(bias_interleaved), ptr(positions), ptr(cos_sin_cache), ptr(loc),
                                         ptr(k_buffer), ptr(v_buffer), k_buffer.stride(0), v_buffer.stride(0), m, num_q_heads,
                                         num_kv_heads, head_dim, k, dtype_code(x.dtype), dtype_code(x.dtype), int(tile_rows),
-                                        current_stream()))
+                                        *_kv_args(k_buffer, v_buffer, k_scale, v_scale), current_stream()))
     return q
 
 
@@ -169,15 +177,16 @@ def awq_gemm_silu_mul(x, qpacked_interleaved, sz_interleaved, group_size: int):
 
 
 def awq_qkv_rope_set_kv(x, qpacked_interleaved, sz_interleaved, bias_interleaved, group_size, positions, cos_sin_cache, loc,
-                        k_buffer, v_buffer, num_q_heads, num_kv_heads, head_dim):
+                        k_buffer, v_buffer, num_q_heads, num_kv_heads, head_dim, k_scale=None, v_scale=None):
     """The int4 form of qkv_rope_set_kv: q [M, Hq*D] rotated; rotated k and v -> pool rows ``loc``."""
     m, k = x.shape
-    assert x.stride(1) == 1 and k_buffer[0].is_contiguous() and v_buffer[0].is_contiguous() and cos_sin_cache.shape[1] == head_dim
+    assert x.stride(1) == 1 and cos_sin_cache.shape[1] == head_dim
     q = torch.empty((m, num_q_heads * head_dim), dtype=x.dtype, device=x.device)
     check(lib.sgl_mi355_awq_qkv_rope_set_kv(ptr(x), x.stride(0), ptr(qpacked_interleaved), ptr(sz_interleaved), ptr(q), q.stride(0),
                                             ptr(bias_interleaved), ptr(positions), ptr(cos_sin_cache), ptr(loc), ptr(k_buffer),
                                             ptr(v_buffer), k_buffer.stride(0), v_buffer.stride(0), m, num_q_heads, num_kv_heads,
-                                            head_dim, k, int(group_size), dtype_code(x.dtype), current_stream()))
+                                            head_dim, k, int(group_size), dtype_code(x.dtype),
+                                            *_kv_args(k_buffer, v_buffer, k_scale, v_scale), current_stream()))
     return q
 
 

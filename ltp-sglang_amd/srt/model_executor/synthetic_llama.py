@@ -97,14 +97,28 @@ class LlamaAttention(nn.Module):
         self.attn = RadixAttention(self.num_heads, self.head_dim, self.head_dim ** -0.5, self.num_kv_heads, layer_id)
         self.fused_rope_kv = True   # decode: rotary_emb + set_kv_buffer in one launch (bit-identical; 16-bit KV pools)
 
+    def kv_scales(self):
+        """(k_scale, v_scale) as set_kv_buffer takes them: the layer's scales or None."""
+        a = self.attn
+        return (None if a.k_scale is None else float(a.k_scale)), (None if a.v_scale is None else float(a.v_scale))
+
+    def rope_and_write_kv(self, positions, q, k, v, forward_batch):
+        """rotary_emb on q, k in place, then (k, v) into the pool rows out_cache_loc: one launch for 16-bit pools, the
+        rotary kernel + the converting scatter for float8_e4m3fn pools."""
+        pool, lid = forward_batch.token_to_kv_pool, self.attn.layer_id
+        if pool.dtype == torch.float8_e4m3fn:
+            self.rotary_emb(positions, q, k)
+            pool.set_kv_buffer(self.attn, forward_batch.out_cache_loc, k, v, self.attn.k_scale, self.attn.v_scale)
+        else:
+            K.rope_set_kv(positions, q, k, v, self.head_dim, self.rotary_emb.cos_sin_cache, True, pool.get_key_buffer(lid),
+                          pool.get_value_buffer(lid), forward_batch.out_cache_loc)
+
     def forward(self, positions, hidden_states, forward_batch):
         qkv, _ = self.qkv_proj(hidden_states)
         q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
         pool = forward_batch.token_to_kv_pool
         if self.fused_rope_kv and forward_batch.forward_mode.is_decode() and pool.dtype != torch.float8_e4m3fn:
-            lid = self.attn.layer_id
-            K.rope_set_kv(positions, q, k, v, self.head_dim, self.rotary_emb.cos_sin_cache, True, pool.get_key_buffer(lid),
-                          pool.get_value_buffer(lid), forward_batch.out_cache_loc)
+            self.rope_and_write_kv(positions, q, k, v, forward_batch)
             attn_output = self.attn(q, k, v, forward_batch, save_kv_cache=False)
             output, _ = self.o_proj(attn_output)
             return output
@@ -286,22 +300,17 @@ class LlamaForCausalLM(nn.Module):
                                                           slab_sx=slab_sx, slab_sw=slab_sw, dtype=self.dtype)
             lid = attn.attn.layer_id
             fw = self._fused_weights(layer) if m <= 64 else None   # the GEMM epilogue fusions are weight-streaming (M <= 64) kernels
-            kv8 = pool.dtype == torch.float8_e4m3fn   # fp8 KV cache: the pool write converts, so it is its own kernel
-            if fw is not None and not kv8:   # qkv GEMM with the RoPE + KV-write epilogue
+            ks, vs = attn.kv_scales()
+            if fw is not None:   # qkv GEMM with the RoPE + KV-write epilogue (16-bit or fp8 pool)
                 q = K.fp8_qkv_rope_set_kv(xq, xs.view(-1), fw["qkv_w"], fw["qkv_s"], fw["qkv_b"], positions,
                                           attn.rotary_emb.cos_sin_cache, forward_batch.out_cache_loc, pool.get_key_buffer(lid),
                                           pool.get_value_buffer(lid), attn.num_heads, attn.num_kv_heads, attn.head_dim, self.dtype,
-                                          fw["qkv_tile"])
+                                          fw["qkv_tile"], ks, vs)
             else:
                 qkv = K.fp8_scaled_mm(xq, attn.qkv_proj.weight, xs.view(-1), attn.qkv_proj.weight_scale.view(-1), self.dtype,
                                       attn.qkv_proj.bias)
                 q, k, v = qkv.split([attn.q_size, attn.kv_size, attn.kv_size], dim=-1)
-                if kv8:
-                    attn.rotary_emb(positions, q, k)
-                    pool.set_kv_buffer(attn.attn, forward_batch.out_cache_loc, k, v, attn.attn.k_scale, attn.attn.v_scale)
-                else:
-                    K.rope_set_kv(positions, q, k, v, attn.head_dim, attn.rotary_emb.cos_sin_cache, True,
-                                  pool.get_key_buffer(lid), pool.get_value_buffer(lid), forward_batch.out_cache_loc)
+                attn.rope_and_write_kv(positions, q, k, v, forward_batch)
             if self.fused_attn_merge and attn.head_dim in (64, 128):
                 _, oq, osc = backend.forward_decode_merged_quant(q, attn.attn, forward_batch)   # stage 2 inside the launch
             else:
@@ -342,7 +351,7 @@ class LlamaForCausalLM(nn.Module):
     def _fused_dense_ok(self, forward_batch) -> bool:
         """Unquantised (bf16 / f16) weights, or int4 AWQ weights at M <= 64 (the fused dequant GEMM's range)."""
         if not (self.fused_decode and forward_batch.forward_mode.is_decode() and self.tp_size == 1
-                and self.cfg.hidden_size <= 8192 and forward_batch.token_to_kv_pool.dtype != torch.float8_e4m3fn):
+                and self.cfg.hidden_size <= 8192):
             return False
         if self.quant_config is None:
             return True
@@ -425,15 +434,15 @@ class LlamaForCausalLM(nn.Module):
             fw = self._fused_weights_awq(layer, m) if awq else self._fused_weights_dense(layer, m)
             rope_args = (positions, attn.rotary_emb.cos_sin_cache, forward_batch.out_cache_loc, pool.get_key_buffer(lid),
                          pool.get_value_buffer(lid), attn.num_heads, attn.num_kv_heads, attn.head_dim)
+            ks, vs = attn.kv_scales()
             if fw is not None and awq:
-                q = K.awq_qkv_rope_set_kv(x, fw["qkv_qp"], fw["qkv_sz"], fw["qkv_b"], gsz, *rope_args)
+                q = K.awq_qkv_rope_set_kv(x, fw["qkv_qp"], fw["qkv_sz"], fw["qkv_b"], gsz, *rope_args, ks, vs)
             elif fw is not None:
-                q = K.qkv_rope_set_kv(x, fw["qkv_w"], fw["qkv_b"], *rope_args, fw["qkv_tile"])
+                q = K.qkv_rope_set_kv(x, fw["qkv_w"], fw["qkv_b"], *rope_args, fw["qkv_tile"], ks, vs)
             else:
                 qkv = linear(attn.qkv_proj, x)
                 q, k, v = qkv.split([attn.q_size, attn.kv_size, attn.kv_size], dim=-1)
-                K.rope_set_kv(positions, q, k, v, attn.head_dim, attn.rotary_emb.cos_sin_cache, True, pool.get_key_buffer(lid),
-                              pool.get_value_buffer(lid), forward_batch.out_cache_loc)
+                attn.rope_and_write_kv(positions, q, k, v, forward_batch)
             o = attn.attn(q, None, None, forward_batch, save_kv_cache=False)
             h2 = norm(linear(attn.o_proj, o), residual, layer.post_attention_layernorm)
             if fw is not None and awq:
@@ -479,12 +488,7 @@ class LlamaForCausalLM(nn.Module):
             qkv = K.fp8_scaled_mm(xq, attn.qkv_proj.weight, xs.view(-1), attn.qkv_proj.weight_scale.view(-1), self.dtype,
                                   attn.qkv_proj.bias)
             q, k, v = qkv.split([attn.q_size, attn.kv_size, attn.kv_size], dim=-1)
-            if pool.dtype == torch.float8_e4m3fn:
-                attn.rotary_emb(positions, q, k)
-                pool.set_kv_buffer(attn.attn, forward_batch.out_cache_loc, k, v, attn.attn.k_scale, attn.attn.v_scale)
-            else:
-                K.rope_set_kv(positions, q, k, v, attn.head_dim, attn.rotary_emb.cos_sin_cache, True, pool.get_key_buffer(lid),
-                              pool.get_value_buffer(lid), forward_batch.out_cache_loc)
+            attn.rope_and_write_kv(positions, q, k, v, forward_batch)
             o = backend.forward_extend(q, k.view(-1, attn.num_kv_heads, attn.head_dim), v.view(-1, attn.num_kv_heads, attn.head_dim),
                                        attn.attn, forward_batch, save_kv_cache=False)
             oq, osc = K.sglang_per_token_quant_fp8(o)

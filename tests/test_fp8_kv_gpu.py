@@ -111,7 +111,62 @@ def test_extend_attention_fp8_prefix_vs_oracle(dtype, d, scales, pkg):
     assert (o.cpu().double() - ref).abs().max().item() <= TOL[c["dtype"]] * max(1.0, vs)
 
 
-def test_model_fp8_kv_fused_equals_plain_and_tracks_bf16_kv(pkg):
+@pytest.mark.parametrize("operands", ["fp8", "bf16", "f16", "awq"])
+@pytest.mark.parametrize("scales", [None, (0.5, 2.0)])
+def test_qkv_gemm_epilogue_writes_fp8_pool_bit_exact(operands, scales, pkg):
+    """qkv GEMM with the RoPE + KV-write epilogue into a float8_e4m3fn pool == GEMM -> rope -> set_kv_buffer (the converting
+    scatter), byte for byte, for every operand type; a large bias drives some values past the e4m3 NaN boundary (464)."""
+    from ltp_sglang_amd import sgl_kernel as sk
+    from oracle import elementwise as oe
+
+    m, hq, hkv, d, k, g = 23, 8, 2, 128, 1024, 128
+    n = (hq + 2 * hkv) * d
+    dtype = torch.float16 if operands in ("f16", "awq") else torch.bfloat16
+    gen = torch.Generator().manual_seed(5)
+    x = (torch.randn(m, k, generator=gen) * 2).to(dtype).to(DEV)
+    bvec = (torch.randn(n, generator=gen) * 40).to(dtype).to(DEV)
+    bvec[hq * d + 7] = 700.0          # a k column beyond the NaN boundary, a v column at the saturation edge
+    bvec[(hq + hkv) * d + 9] = -470.0
+    positions = torch.randint(0, 4096, (m,), generator=gen).to(DEV)
+    cache = oe.rope_cache(d, d, 4096, 10000.0).to(DEV)
+    loc = (torch.randperm(99, generator=gen)[:m] + 1).to(DEV)
+    ks, vs = scales if scales else (None, None)
+    pool = lambda: torch.zeros(100, hkv, d, dtype=torch.uint8, device=DEV).view(torch.float8_e4m3fn)
+    kb1, vb1, kb2, vb2 = pool(), pool(), pool(), pool()
+    if operands == "fp8":
+        w = (torch.randn(n, k, generator=gen) * 0.05).to(DEV)
+        wq, ws = sk.sglang_per_token_quant_fp8(w.to(dtype))
+        xq, xs = sk.sglang_per_token_quant_fp8(x)
+        qkv = sk.fp8_scaled_mm(xq, wq.t(), xs.view(-1), ws.view(-1), dtype, bvec)
+        il = lambda t: sk.interleave_rope_rows(t, hq, hkv, d, 16)
+        fused = lambda: sk.fp8_qkv_rope_set_kv(xq, xs.view(-1), il(wq.view(torch.uint8)).view(torch.float8_e4m3fn), il(ws.view(-1)),
+                                               il(bvec), positions, cache, loc, kb2, vb2, hq, hkv, d, dtype, 16, ks, vs)
+    elif operands == "awq":
+        qw = torch.randint(-2**31, 2**31 - 1, (k, n // 8), generator=gen, dtype=torch.int32).to(DEV)
+        qz = torch.randint(-2**31, 2**31 - 1, (k // g, n // 8), generator=gen, dtype=torch.int32).to(DEV)
+        sc = (torch.rand(k // g, n, generator=gen) * 0.02 + 1e-3).to(dtype).to(DEV)
+        qp, sz = sk.awq_repack(qw, sc, qz)
+        qkv = sk.awq_gemm(x, qp, sz, g, bvec)
+        pq, pz, ps, pb = sk.awq_permute_cols(sk.awq_rope_col_order(hq, hkv, DEV), qw, qz, sc, bvec)
+        qpi, szi = sk.awq_repack(pq, ps, pz)
+        fused = lambda: sk.awq_qkv_rope_set_kv(x, qpi, szi, pb, g, positions, cache, loc, kb2, vb2, hq, hkv, d, ks, vs)
+    else:
+        w = (torch.randn(n, k, generator=gen) * 0.05).to(dtype).to(DEV)
+        qkv = sk.dense_linear(x, w, bvec)
+        il = lambda t: sk.interleave_rope_rows(t, hq, hkv, d, 16)
+        fused = lambda: sk.qkv_rope_set_kv(x, il(w), il(bvec), positions, cache, loc, kb2, vb2, hq, hkv, d, 16, ks, vs)
+    q, kk, vv = qkv.split([hq * d, hkv * d, hkv * d], dim=-1)
+    q, kk = q.contiguous(), kk.contiguous()
+    sk.apply_rope_with_cos_sin_cache_inplace(positions, q, kk, d, cache, True)
+    sk.set_kv_buffer(kb1, vb1, loc, kk, vv, ks, vs)
+    q2 = fused()
+    assert torch.equal(q2, q)
+    assert torch.equal(kb1.view(torch.uint8), kb2.view(torch.uint8)) and torch.equal(vb1.view(torch.uint8), vb2.view(torch.uint8))
+    assert (kb1.view(torch.uint8)[loc] == 0x7F).any()   # the NaN rule was exercised
+
+
+@pytest.mark.parametrize("quant,scales", [("w8a8_fp8", None), ("w8a8_fp8", (0.5, 2.0)), (None, (0.5, 2.0)), ("awq", None)])
+def test_model_fp8_kv_fused_equals_plain_and_tracks_bf16_kv(quant, scales, pkg):
     from ltp_sglang_amd.srt.model_executor.synthetic_llama import LlamaShape, SyntheticModelRunner
 
     cfg = LlamaShape(hidden_size=1024, num_attention_heads=8, num_key_value_heads=2, head_dim=128, num_hidden_layers=3,
@@ -119,9 +174,14 @@ def test_model_fp8_kv_fused_equals_plain_and_tracks_bf16_kv(pkg):
     outs = {}
     feed = None
     for mode in ("bf16kv", "plain", "fused", "graph"):
-        runner = SyntheticModelRunner(cfg, "w8a8_fp8", max_running_requests=8, context_len=256, max_total_tokens=2048, device="cuda:0",
+        runner = SyntheticModelRunner(cfg, quant, max_running_requests=8, context_len=256, max_total_tokens=2048, device="cuda:0",
                                       seed=5, kv_cache_dtype=None if mode == "bf16kv" else torch.float8_e4m3fn)
         runner.model.fused_decode = runner.model.fused_extend = mode != "plain"
+        if scales and mode != "bf16kv":   # per-layer KV scales (RadixAttention.k_scale / v_scale, radix_attention.py:73-76)
+            for layer in runner.model.layers:
+                a = layer.self_attn.attn
+                a.k_scale, a.v_scale = torch.tensor(scales[0]), torch.tensor(scales[1])
+                a.k_scale_float, a.v_scale_float = scales
         g = torch.Generator().manual_seed(1)
         ids = [torch.randint(0, cfg.vocab_size, (n,), generator=g).to("cuda:0") for n in (50, 7, 33, 1)]
         logits, state = runner.extend(ids)
