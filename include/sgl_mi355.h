@@ -216,6 +216,12 @@ int sgl_mi355_fp8_gemm_force_tile(int mode);
 int sgl_mi355_fp8_gemm(const void* x, int64_t x_stride_elems, const void* w, int64_t w_stride_elems, void* y,
                        int64_t y_stride_elems, const float* scales_x, const float* scales_w, const void* bias, int M,
                        int N, int K, int out_dtype, float* workspace, int64_t workspace_floats, void* stream);
+/* Split-K of sgl_mi355_fp8_gemm at 64 < M <= 256 (the streaming tile) left to the consumer: num_slabs = how many f32 [M, N]
+ * partial sums it forms for this shape and scratch size (1: none); fp8_gemm_slabs writes them raw (no scales) for
+ * sgl_mi355_fused_add_rmsnorm_quant_fp8 (slabs + sx + sw), with fp8_gemm's own k-range partition. */
+int sgl_mi355_fp8_gemm_num_slabs(int M, int N, int K, int64_t workspace_floats);
+int sgl_mi355_fp8_gemm_slabs(const void* x, int64_t x_stride_elems, const void* w, int64_t w_stride_elems, float* slabs, int M,
+                             int N, int K, int64_t workspace_floats, void* stream);
 /* (workspace: optional f32 scratch for split-K when a launch has fewer 128x128 output tiles than half the CUs -- decode at
  * 64 < M <= 256, the continuous-batching regime, where the weights are streamed once; NULL disables it) */
 /* Unquantised bf16/f16 linear for M > 64 (UnquantizedLinearMethod.apply, layers/quantization/unquant.py);

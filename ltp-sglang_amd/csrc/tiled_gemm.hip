@@ -736,8 +736,28 @@ int launch(GemmParams& p, hipStream_t st, float* workspace = nullptr, int64_t wo
   return SGL_MI355_OK;
 }
 
+// split-K ranges of the streaming 128x128 tile for this shape (1: none) and the slices per range
+inline int splits128s(int M, int N, int kbytes, bool have_workspace, int64_t workspace_floats, int* kt_per) {
+  const int tiles = ((M + S_BM - 1) / S_BM) * ((N + S_BN - 1) / S_BN), nk = kbytes / BKB, cus = tg_cus();
+  int splits = 1;
+  if (have_workspace && tiles < cus && N % 4 == 0) {
+    splits = cus / tiles;                  // one 128 KiB workgroup per CU
+    if (splits > nk / 8) splits = nk / 8;  // at least 8 slices (1 KiB of K) per workgroup: more splits only move the cost into slabs
+    if (splits < 1) splits = 1;
+    while (splits > 1 && (int64_t)splits * M * N > workspace_floats) --splits;
+  }
+  if (splits > 1) {
+    *kt_per = (nk + splits - 1) / splits;
+    return (nk + *kt_per - 1) / *kt_per;
+  }
+  *kt_per = nk;
+  return 1;
+}
+
+// slabs_only: leave the raw f32 partial sums [splits][M][N] in `workspace` for a consumer kernel that combines them
+// (sgl_mi355_fused_add_rmsnorm_quant_fp8), instead of running the reduce kernel into p.y; requires splits > 1.
 template <typename OutT>
-int launch128s(GemmParams& p, hipStream_t st, float* workspace, int64_t workspace_floats) {
+int launch128s(GemmParams& p, hipStream_t st, float* workspace, int64_t workspace_floats, bool slabs_only = false) {
   constexpr int smem = S_STAGES * 2 * S_OPB;  // 128 KiB
   static bool attr_set = false;
   if (!attr_set) {
@@ -746,26 +766,13 @@ int launch128s(GemmParams& p, hipStream_t st, float* workspace, int64_t workspac
   }
   p.tiles_m = (p.M + S_BM - 1) / S_BM;
   p.tiles_n = (p.N + S_BN - 1) / S_BN;
-  const int tiles = p.tiles_m * p.tiles_n, nk = p.kbytes / BKB, cus = tg_cus();
-  int splits = 1;
-  if (workspace != nullptr && tiles < cus && p.N % 4 == 0) {
-    splits = cus / tiles;                  // one 128 KiB workgroup per CU
-    if (splits > nk / 8) splits = nk / 8;  // at least 8 slices (1 KiB of K) per workgroup: more splits only move the cost into slabs
-    if (splits < 1) splits = 1;
-    while (splits > 1 && (int64_t)splits * p.M * p.N > workspace_floats) --splits;
-  }
-  if (splits > 1) {
-    p.kt_per = (nk + splits - 1) / splits;
-    splits = (nk + p.kt_per - 1) / p.kt_per;
-    p.slabs = workspace;
-  } else {
-    splits = 1;
-    p.kt_per = nk;
-    p.slabs = nullptr;
-  }
+  const int tiles = p.tiles_m * p.tiles_n;
+  const int splits = splits128s(p.M, p.N, p.kbytes, workspace != nullptr, workspace_floats, &p.kt_per);
+  p.slabs = splits > 1 ? workspace : nullptr;
+  SGL_CHECK(!slabs_only || splits > 1, "fp8_gemm_slabs: this shape runs as one k-range (no slabs): M=%d N=%d", p.M, p.N);
   hipLaunchKernelGGL((fp8_gemm128s_kernel<OutT>), dim3(tiles, splits), dim3(512), smem, st, p);
   SGL_HIP_LAUNCH_CHECK();
-  if (splits > 1) {
+  if (splits > 1 && !slabs_only) {
     const int64_t items = (int64_t)p.M * (p.N / 4);
     const unsigned blocks = (unsigned)((items + 255) / 256 > 4096 ? 4096 : (items + 255) / 256);
     hipLaunchKernelGGL((tiled_splitk_reduce_kernel<OutT>), dim3(blocks), dim3(256), 0, st, workspace, splits, p.sx, p.sw,
@@ -773,6 +780,12 @@ int launch128s(GemmParams& p, hipStream_t st, float* workspace, int64_t workspac
     SGL_HIP_LAUNCH_CHECK();
   }
   return SGL_MI355_OK;
+}
+
+// does sgl_mi355_fp8_gemm send this fp8 problem to the streaming 128x128 tile?
+inline bool takes128s(int M, int N, int kbytes, int64_t x_stride_b, int64_t w_stride_b) {
+  const bool can256 = kbytes % BKB == 0 && kbytes >= BKB && (int64_t)N * w_stride_b < 0xFFFFFFF0ll && (int64_t)M * x_stride_b < 0xFFFFFFF0ll;
+  return can256 && (g_tiled_force == 5 || (g_tiled_force == 0 && M <= 256));
 }
 
 int run(const void* x, int64_t xs, const void* w, int64_t ws, void* y, int64_t ys, const float* sx, const float* sw,
@@ -800,7 +813,7 @@ int run(const void* x, int64_t xs, const void* w, int64_t ws, void* y, int64_t y
     const bool can256 = p.kbytes % BKB == 0 && p.kbytes >= BKB && (int64_t)N * p.w_stride < 0xFFFFFFF0ll &&
                         (int64_t)M * p.x_stride < 0xFFFFFFF0ll;  // 32-bit buffer offsets
     // decode-sized M: the streaming tile (weights read once; bytes in flight decide)
-    if (can256 && (g_tiled_force == 5 || (g_tiled_force == 0 && M <= 256)))
+    if (takes128s(M, N, p.kbytes, p.x_stride, p.w_stride))
       return out_dtype == SGL_BF16 ? launch128s<__bf16>(p, st, workspace, workspace_floats)
                                    : launch128s<_Float16>(p, st, workspace, workspace_floats);
     if (can256 && g_tiled_force == 4) return out_dtype == SGL_BF16 ? launch256<__bf16, 8, false>(p, st) : launch256<_Float16, 8, false>(p, st);
@@ -848,6 +861,32 @@ extern "C" int sgl_mi355_fp8_gemm(const void* x, int64_t x_stride_elems, const v
                                   void* stream) {
   return run(x, x_stride_elems, w, w_stride_elems, y, y_stride_elems, scales_x, scales_w, bias, M, N, K, SGL_FP8_E4M3,
              out_dtype, stream, "fp8_gemm", workspace, workspace_floats);
+}
+
+// How many f32 [M, N] slabs sgl_mi355_fp8_gemm sums for this shape when given `workspace_floats` of scratch (1: it runs as one
+// k-range; > 1 only for the streaming tile, 64 < M <= 256 with fewer tiles than CUs).  Contiguous rows assumed.
+extern "C" int sgl_mi355_fp8_gemm_num_slabs(int M, int N, int K, int64_t workspace_floats) {
+  if (M <= 0 || N <= 0 || K <= 0 || !takes128s(M, N, K, K, K)) return 1;
+  int kt_per = 0;
+  return splits128s(M, N, K, true, workspace_floats, &kt_per);
+}
+
+// Producer half of the launch-boundary split-K reduce for 64 < M <= 256: the raw f32 partial sums [num_slabs][M][N] of
+// fp8_scaled_mm, no scales (the consumer, sgl_mi355_fused_add_rmsnorm_quant_fp8 with slabs, applies sx[m] * sw[n]).  The k-range
+// partition is sgl_mi355_fp8_gemm's for the same `workspace_floats`, so both sum identically; fails unless num_slabs > 1.
+extern "C" int sgl_mi355_fp8_gemm_slabs(const void* x, int64_t x_stride_elems, const void* w, int64_t w_stride_elems, float* slabs,
+                                        int M, int N, int K, int64_t workspace_floats, void* stream) {
+  SGL_CHECK(x && w && slabs && M > 0 && N > 0 && K > 0, "fp8_gemm_slabs: bad arguments");
+  SGL_CHECK(K % 16 == 0 && x_stride_elems % 16 == 0 && w_stride_elems % 16 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0,
+            "fp8_gemm_slabs: rows must be 16-byte aligned (K=%d)", K);
+  SGL_CHECK(takes128s(M, N, K, x_stride_elems, w_stride_elems), "fp8_gemm_slabs: M=%d N=%d K=%d is not a streaming-tile shape", M, N, K);
+  GemmParams p;
+  p.x = (const char*)x; p.x_stride = x_stride_elems;
+  p.w = (const char*)w; p.w_stride = w_stride_elems;
+  p.y = nullptr; p.y_stride = 0;
+  p.sx = nullptr; p.sw = nullptr; p.bias = nullptr;
+  p.M = M; p.N = N; p.kbytes = K;
+  return launch128s<__bf16>(p, (hipStream_t)stream, slabs, workspace_floats, true);
 }
 
 extern "C" int sgl_mi355_dense_gemm(const void* x, int64_t x_stride_elems, const void* w, int64_t w_stride_elems, void* y,

@@ -41,6 +41,8 @@ from .gemm import (
     awq_unpack_nk,
     dense_linear,
     dense_linear_kranges,
+    fp8_gemm_num_slabs,
+    fp8_gemm_slabs,
     fp8_linear_slabs,
     fp8_scaled_mm,
     sgl_per_tensor_quant_fp8,

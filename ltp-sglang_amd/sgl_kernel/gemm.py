@@ -196,6 +196,31 @@ def fp8_linear_slabs(x_q: torch.Tensor, weight_nk: torch.Tensor, m: int, n: int,
     return out
 
 
+def fp8_gemm_num_slabs(m: int, n: int, k: int, device) -> int:
+    """How many f32 [M, N] split-K slabs fp8_scaled_mm forms for this shape at 64 < M <= 256 (the streaming tile; 1: none)."""
+    if not 64 < m <= 256:
+        return 1
+    _, ws_n = _tiled_workspace(device)
+    return int(lib.sgl_mi355_fp8_gemm_num_slabs(int(m), int(n), int(k), ws_n))
+
+
+def fp8_gemm_slabs(x_q: torch.Tensor, weight_nk: torch.Tensor) -> torch.Tensor:
+    """The 64 < M <= 256 form of fp8_linear_slabs: raw f32 partial sums [S, M, N] of fp8_scaled_mm's streaming tile, with its
+    own k-range partition (so the consumer's sum equals fp8_scaled_mm's); requires fp8_gemm_num_slabs(...) > 1."""
+    _cuda(x_q, weight_nk)
+    assert x_q.dtype == torch.float8_e4m3fn and weight_nk.dtype == torch.float8_e4m3fn
+    m, k = x_q.shape
+    n = weight_nk.shape[0]
+    _, ws_n = _tiled_workspace(x_q.device)
+    kr = int(lib.sgl_mi355_fp8_gemm_num_slabs(m, n, k, ws_n))
+    if kr <= 1:
+        raise RuntimeError(f"fp8_gemm_slabs: M={m} N={n} K={k} runs as one k-range (no slabs)")
+    out = torch.empty((kr, m, n), dtype=torch.float32, device=x_q.device)
+    check(lib.sgl_mi355_fp8_gemm_slabs(ptr(x_q), x_q.stride(0), ptr(weight_nk), weight_nk.stride(0), ptr(out), m, n, k, ws_n,
+                                       current_stream()))
+    return out
+
+
 def dense_linear_kranges(m: int, n: int, k: int, dtype) -> int:
     """How many split-K ranges dense_linear / fp8_scaled_mm use for this shape at M <= 64 (1: no slabs; 0: generic kernel)."""
     return int(lib.sgl_mi355_skinny_gemm_num_kranges(m, n, k, dtype_code(dtype))) if m <= 64 else 0

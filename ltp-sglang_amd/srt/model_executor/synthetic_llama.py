@@ -317,12 +317,20 @@ class LlamaForCausalLM(nn.Module):
                 md = backend.forward_decode_partial(q, attn.attn, forward_batch)
                 _, oq, osc = K.decode_merge_quant_fp8(md.attn_logits, md.attn_lse, md.kv_indptr, md.num_kv_splits,
                                                       backend.max_kv_splits, self.dtype)
-            attn_out = K.fp8_scaled_mm(oq, attn.o_proj.weight, osc.view(-1), attn.o_proj.weight_scale.view(-1), self.dtype)
             ln2 = layer.post_attention_layernorm
-            if tp > 1:   # partial sums: all-reduce + add + RMSNorm + quant in one launch
-                _, hq2, hs2 = ar_norm_quant(attn_out, residual, ln2.weight.data, ln2.variance_epsilon)
+            wo = attn.o_proj.weight   # [K, N] column-major view of the [N, K] parameter
+            if tp == 1 and K.fp8_gemm_num_slabs(m, wo.shape[1], wo.shape[0], wo.device) > 1:
+                # 64 < M <= 256: o_proj's split-K partial sums go straight into the add + RMSNorm + quant (no reduce launch)
+                o_slabs = K.fp8_gemm_slabs(oq, wo.t())
+                _, hq2, hs2 = K.fused_add_rmsnorm_quant_fp8(None, residual, ln2.weight.data, ln2.variance_epsilon, slabs=o_slabs,
+                                                            slab_sx=osc.view(-1), slab_sw=attn.o_proj.weight_scale.view(-1),
+                                                            dtype=self.dtype)
             else:
-                _, hq2, hs2 = K.fused_add_rmsnorm_quant_fp8(attn_out, residual, ln2.weight.data, ln2.variance_epsilon)
+                attn_out = K.fp8_scaled_mm(oq, wo, osc.view(-1), attn.o_proj.weight_scale.view(-1), self.dtype)
+                if tp > 1:   # partial sums: all-reduce + add + RMSNorm + quant in one launch
+                    _, hq2, hs2 = ar_norm_quant(attn_out, residual, ln2.weight.data, ln2.variance_epsilon)
+                else:
+                    _, hq2, hs2 = K.fused_add_rmsnorm_quant_fp8(attn_out, residual, ln2.weight.data, ln2.variance_epsilon)
             if fw is not None:   # gate_up GEMM with the SiluAndMul epilogue, then the per-token quantisation
                 act = K.fp8_gemm_silu_mul(hq2, hs2.view(-1), fw["gu_w"], fw["gu_s"], self.dtype, fw["gu_tile"])
                 aq, asc = K.sglang_per_token_quant_fp8(act)
@@ -333,7 +341,11 @@ class LlamaForCausalLM(nn.Module):
             if tp == 1 and m <= 64:
                 slabs = K.fp8_linear_slabs(aq, wd.t(), m, wd.shape[1], wd.shape[0])
                 slab_sx, slab_sw = asc.view(-1), mlp.down_proj.weight_scale.view(-1)
+            elif tp == 1 and K.fp8_gemm_num_slabs(m, wd.shape[1], wd.shape[0], wd.device) > 1:
+                slabs = K.fp8_gemm_slabs(aq, wd.t())   # 64 < M <= 256: the streaming tile's partial sums, same hand-off
+                slab_sx, slab_sw = asc.view(-1), mlp.down_proj.weight_scale.view(-1)
             else:
+                slabs = None
                 hidden = K.fp8_scaled_mm(aq, wd, asc.view(-1), mlp.down_proj.weight_scale.view(-1), self.dtype)   # (tp > 1: partial)
         if slabs is not None:
             hidden, _, _ = K.fused_add_rmsnorm_quant_fp8(None, residual, self.norm.weight.data, self.norm.variance_epsilon,

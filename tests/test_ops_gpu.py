@@ -695,6 +695,35 @@ def test_dense_slabs_into_norm_bit_exact(m, n, k, dtype, sk):
     assert torch.equal(r1, r2) and torch.equal(out, y)
 
 
+@pytest.mark.parametrize("m,n,k", [(128, 4096, 4096), (128, 8192, 3584), (96, 1280, 8192), (200, 2048, 2048)])
+def test_streaming_tile_slabs_into_norm_bit_exact(m, n, k, sk):
+    """64 < M <= 256: fp8_scaled_mm's split-K partial sums handed raw to add + RMSNorm + quant == fp8_scaled_mm -> the same op."""
+    c = _cases.build_gemm_case(dict(m=m, n=n, k=k, bias=False, out="bf16"), seed=m + n)
+    a, wt, sa, sb = c["a"].to(DEV), c["w"].to(DEV), c["sa"].to(DEV) * 3, c["sb"].to(DEV) * 3
+    g = torch.Generator().manual_seed(k)
+    res = torch.randn(m, n, generator=g).to(torch.bfloat16).to(DEV)
+    wn = (1 + 0.1 * torch.randn(n, generator=g)).to(torch.bfloat16).to(DEV)
+    kr = sk.fp8_gemm_num_slabs(m, n, k, DEV)
+    assert kr > 1
+    y = sk.fp8_scaled_mm(a, wt.t(), sa, sb, torch.bfloat16)
+    r1 = res.clone()
+    n1, q1, s1 = sk.fused_add_rmsnorm_quant_fp8(y, r1, wn, 1e-5, want_norm=True)
+    slabs = sk.fp8_gemm_slabs(a, wt)
+    assert slabs.shape == (kr, m, n)
+    r2 = res.clone()
+    n2, q2, s2 = sk.fused_add_rmsnorm_quant_fp8(None, r2, wn, 1e-5, slabs=slabs, slab_sx=sa, slab_sw=sb, want_norm=True, dtype=torch.bfloat16)
+    assert torch.equal(r1, r2) and torch.equal(n1, n2) and torch.equal(s1, s2)
+    assert torch.equal(q1.view(torch.uint8), q2.view(torch.uint8))
+
+
+def test_streaming_tile_slabs_reject_single_range(sk):
+    a = torch.zeros(128, 1024, dtype=torch.float8_e4m3fn, device=DEV)
+    w = torch.zeros(28672, 1024, dtype=torch.float8_e4m3fn, device=DEV)
+    assert sk.fp8_gemm_num_slabs(128, 28672, 1024, DEV) == 1
+    with pytest.raises(RuntimeError, match="one k-range"):
+        sk.fp8_gemm_slabs(a, w)
+
+
 def test_decode_prepare_matches_index_ops(sk):
     """prepare_for_decode + the graph runner's buffer copies in one launch == the separate index ops (bit-exact)."""
     g = torch.Generator().manual_seed(11)
