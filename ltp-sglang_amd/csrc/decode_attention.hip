@@ -57,19 +57,18 @@ struct DecodeParams {
   void* mq_o;          // optional T [bs, Hq * Dv]
   void* mq_q;          // optional e4m3 [bs, Hq * Dv] with mq_s f32 [bs]
   float* mq_s;
-  // Cascade shared-prefix decode (the LSE merge is merge_attn_states.cu's): all `bs` requests share the first
-  // prefix_len slots of their sequences.
-  //   (a wide prefix kernel -- 64 columns per wave on every staged tile, 512-register budget -- was built and measured SLOWER:
-//   28 us against 19 us for the prefix pass at 64 requests x 1536 shared keys; a quarter of the workgroups, each latency-bound)
-//   prefix pass  (shared_reqs = bs > 0): ONE virtual request whose GQA group of kv head kh is the bs * group query heads
-  //                {(request r, head kh * group + j)}: every K/V row of the prefix is read once per (kv head, 16-column chunk,
-  //                split) for ALL requests -- the extra requests are extra MFMA columns.  Keys = kv_indices[0, prefix_len),
-  //                prefix_splits splits, partials go to split slots [0, prefix_splits) of each request.
-  //   suffix pass  (split_base = prefix_splits): the ordinary kernel over every request's private slots; its partials go to
-  //                slots [split_base, split_base + num_kv_splits[b]) and the in-launch merge combines prefix + suffix slots.
-  int shared_reqs;
+  // Cascade shared-prefix decode: all `bs` requests share the first prefix_len slots of their sequences.
+  //   prefix pass  a launch of the EXTEND kernel (extend_attention.hip, ExtendParams::casc_*): the bs decode queries are the
+  //                query block, the shared rows the keys, staged once per (kv head, 32 requests, split) in LDS for all 4 x 32
+  //                (head, request) pairs of a workgroup; prefix_splits split partials (O = acc / l, LSE) per (request, head)
+  //                go to the TOP split slots [max_kv_splits - prefix_splits, max_kv_splits).  (Round 2 first ran the prefix as
+  //                16-column chunks of this kernel -- every chunk re-read the rows, 19.6 us at 64 x 1536 -- and then had the
+  //                merging workgroup of every request read prefix + suffix partials, +2 us per prefix split.)
+  //   suffix pass  (CASC = 2, prefix_splits > 0): the ordinary kernel over every request's private slots, except that split 0
+  //                of every (request, kv head) CONTINUES the online softmax from the prefix state (the LSE-weighted sum of the
+  //                prefix partials is its initial (m, l, acc) -- the math of merge_state, merge_attn_states.cu, applied before
+  //                instead of after), so the in-launch merge sees suffix slots only.
   int prefix_len, prefix_splits;
-  int split_base;
 };
 
 constexpr int kTile = 32;  // tokens per wave tile == reference _MIN_BLOCK_KV (decode_attention.py:35)
@@ -131,11 +130,9 @@ __device__ __forceinline__ void arrive_and_merge(const DecodeParams& p, int b, i
   __syncthreads();
   float* red = (float*)smem + 4;
   if (p.hq * p.dv <= 256 * 8 * 4)
-    merge_quant_row<T, 4>(b, p.attn_logits, p.attn_lse, seq_len, nsplit, p.max_kv_splits, p.hq, p.dv, (T*)p.mq_o, (uint8_t*)p.mq_q, p.mq_s, red,
-                          CASC ? p.prefix_len : 0, CASC ? p.split_base : 0);
+    merge_quant_row<T, 4>(b, p.attn_logits, p.attn_lse, seq_len, nsplit, p.max_kv_splits, p.hq, p.dv, (T*)p.mq_o, (uint8_t*)p.mq_q, p.mq_s, red, CASC);
   else
-    merge_quant_row<T, 8>(b, p.attn_logits, p.attn_lse, seq_len, nsplit, p.max_kv_splits, p.hq, p.dv, (T*)p.mq_o, (uint8_t*)p.mq_q, p.mq_s, red,
-                          CASC ? p.prefix_len : 0, CASC ? p.split_base : 0);
+    merge_quant_row<T, 8>(b, p.attn_logits, p.attn_lse, seq_len, nsplit, p.max_kv_splits, p.hq, p.dv, (T*)p.mq_o, (uint8_t*)p.mq_q, p.mq_s, red, CASC);
   if (threadIdx.x == 0) __hip_atomic_store(p.merge_cnt + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -161,9 +158,9 @@ __device__ __forceinline__ void cvt16_fp8(const u32x4_t& in, u32x4_t& lo, u32x4_
 //         units of one request with the kv head fastest, so they read ADJACENT 256-byte pieces of the same token rows
 //         at about the same time (whole 2-KiB token rows per workgroup instead of scattered 256-byte pieces) and no
 //         barrier or cross-wave merge exists at all.
-// KVB: bytes per pool element (1 = e4m3 KV cache, converted on the way into LDS).  CASC: 1 = the cascade (shared-prefix) PREFIX
-// pass (its rows are re-read by every 16-column chunk of a kv head: default cache policy), 2 = the SUFFIX pass; the forms of
-// MODE 0 -- their extra index arithmetic stays out of the ordinary instantiation (it cost 28 spilled SGPRs there).
+// KVB: bytes per pool element (1 = e4m3 KV cache, converted on the way into LDS).  CASC = 2: the SUFFIX pass of the cascade
+// (shared-prefix) decode, a form of MODE 0 whose split 0 starts from the prefix state (DecodeParams::prefix_*) -- its own
+// instantiation, so the extra code stays out of the ordinary one.
 template <typename T, int D, int NW, int MODE, int KVB = 2, int CASC = 0>
 __global__ __launch_bounds__(NW * 64, 2) void decode_attn_stage1(const DecodeParams p) {
   using Tr = ElemTraits<T>;
@@ -188,10 +185,8 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attn_stage1(const DecodePar
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  constexpr bool shared = CASC == 1;                              // cascade prefix pass
-  const int split_base = CASC == 2 ? p.split_base : 0;
-  const int vgroup = shared ? p.shared_reqs * p.group : p.group;  // query columns that share one kv head's K/V rows
-  const int hchunks = (vgroup + 15) >> 4;
+  static_assert(CASC == 0 || (CASC == 2 && MODE == 0), "the cascade suffix pass is a MODE 0 form");
+  const int hchunks = (p.group + 15) >> 4;
   int khc, split;
   if constexpr (MODE == 0) {
     khc = blockIdx.x;
@@ -204,30 +199,20 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attn_stage1(const DecodePar
   const int kh = khc / hchunks;
   const int hc = khc - kh * hchunks;
   const int b = blockIdx.y;
-  const int nh = min(16, vgroup - hc * 16);
-  // column v = hc * 16 + a of this kv head -> (request row, q head); identity for an ordinary launch
-  auto col_req = [&](int v) -> int { return shared ? v / p.group : b; };
-  auto col_head = [&](int v) -> int { return kh * p.group + (shared ? v % p.group : v); };
+  const int nh = min(16, p.group - hc * 16);
 
   const int32_t* idx_row;
   int seq_len;
-  int nsplit;
-  if (shared) {
-    idx_row = p.kv_indices;
-    seq_len = p.prefix_len;
-    nsplit = p.prefix_splits;
-  } else {
-    request_range(p, b, idx_row, seq_len);
-    nsplit = p.num_kv_splits[b];
-  }
-  nsplit = max(1, min(nsplit, p.max_kv_splits - split_base));
+  request_range(p, b, idx_row, seq_len);
+  const int nsplit = max(1, min(p.num_kv_splits[b], p.max_kv_splits - (CASC == 2 ? p.prefix_splits : 0)));
   if (split >= nsplit) return;  // MODE 1: a whole-wave exit; the kernel has no barrier in that mode
   const int per = split_len(seq_len, nsplit);
   const int start = split * per;
   const int end = min(start + per, seq_len);
-  if (start >= end) {
+  const bool continues_prefix = CASC == 2 && split == 0;   // carries the prefix state even if the private part is empty
+  if (start >= end && !continues_prefix) {
     if constexpr (MODE == 0) {  // an empty split still counts as arrived for the in-launch merge (uniform per workgroup)
-      if (p.merge_cnt) arrive_and_merge<T, CASC != 0>(p, b, seq_len, nsplit, hchunks, smem);
+      if (p.merge_cnt) arrive_and_merge<T, CASC == 2>(p, b, seq_len, nsplit, hchunks, smem);
     }
     return;
   }
@@ -244,7 +229,7 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attn_stage1(const DecodePar
   vec8 qf[KS];
   {
     const int va = hc * 16 + min(a, nh - 1);
-    const T* qrow = (const T*)p.q + (int64_t)col_req(va) * p.q_stride_t + (int64_t)col_head(va) * D;
+    const T* qrow = (const T*)p.q + (int64_t)b * p.q_stride_t + (int64_t)(kh * p.group + va) * D;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       if (a < nh) {
@@ -260,7 +245,7 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attn_stage1(const DecodePar
   const char* vbase = (const char*)p.v_buf + ((int64_t)kh * p.v_stride_h) * KVB + c16 * 16;
   const int64_t kst = p.k_stride_t * KVB, vst = p.v_stride_t * KVB;
 
-  const int ntiles = (end - start + kTile - 1) / kTile;
+  const int ntiles = max(0, end - start + kTile - 1) / kTile;
   const float sm_scale = p.sm_scale * p.k_scale;
   const float scale_log2 = sm_scale * kLog2e;
   const bool use_cap = p.logit_cap > 0.0f;
@@ -269,6 +254,34 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attn_stage1(const DecodePar
   f32x4_t acc[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) acc[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  if constexpr (CASC == 2) {
+    // Split 0 of the private part continues from the shared prefix: wave 0 starts with the LSE-weighted sum of the prefix
+    // split partials (top slots of this (request, head)) as its (m, l, acc) -- m in log2 units, l on the g = 0 lane (the four
+    // g-lanes of a head are summed at the end), acc before the v_scale the partials already carry.
+    if (continues_prefix && w == 0 && a < nh) {
+      const int64_t slot0 = ((int64_t)b * p.hq + (kh * p.group + hc * 16 + a)) * p.max_kv_splits + (p.max_kv_splits - p.prefix_splits);
+      float M = -INFINITY;
+      for (int sI = 0; sI < p.prefix_splits; ++sI) M = fmaxf(M, p.attn_lse[slot0 + sI]);
+      float L = 0.0f;
+      for (int sI = 0; sI < p.prefix_splits; ++sI) {
+        const float wgt = __expf(p.attn_lse[slot0 + sI] - M);
+        L += wgt;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const f32x4_t o = *(const f32x4_t*)(p.attn_logits + (slot0 + sI) * D + 16 * n + 4 * g);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[n][r] = fmaf(o[r], wgt, acc[n][r]);
+        }
+      }
+      const float inv_vs = 1.0f / p.v_scale;
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[n][r] *= inv_vs;
+      m_i = M * kLog2e;
+      l_i = g == 0 ? L : 0.0f;
+    }
+  }
 
   u32x4_t kreg[GNI], vreg[GNI];
 
@@ -283,13 +296,8 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attn_stage1(const DecodePar
       // NON-TEMPORAL loads: every K/V row is read once per decode step, so keeping it in L2 / the Infinity Cache only
       // evicts what the step re-reads (activations, split partials) and lengthens the miss path.  Same-box A/B at the
       // BASELINE shape (round 2): stage 1 55.0 -> 50.3 us per launch (4.9 -> 5.4 TB/s), decode step 4.55 -> 4.39 ms.
-      if constexpr (CASC == 1) {   // shared prefix rows: 16 workgroup chunks per kv head re-read them -- keep them cached
-        kreg[i] = *(const u32x4_t*)(kbase + (int64_t)id * kst);
-        vreg[i] = *(const u32x4_t*)(vbase + (int64_t)id * vst);
-      } else {
-        kreg[i] = __builtin_nontemporal_load((const u32x4_t*)(kbase + (int64_t)id * kst));
-        vreg[i] = __builtin_nontemporal_load((const u32x4_t*)(vbase + (int64_t)id * vst));
-      }
+      kreg[i] = __builtin_nontemporal_load((const u32x4_t*)(kbase + (int64_t)id * kst));
+      vreg[i] = __builtin_nontemporal_load((const u32x4_t*)(vbase + (int64_t)id * vst));
     }
   };
 
@@ -453,7 +461,7 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attn_stage1(const DecodePar
       val += red_acc[(ww * 16 + h) * D + d] * sc;
     }
     const int vh = hc * 16 + h;
-    const int64_t slot = ((int64_t)col_req(vh) * p.hq + col_head(vh)) * p.max_kv_splits + split_base + split;
+    const int64_t slot = ((int64_t)b * p.hq + (kh * p.group + vh)) * p.max_kv_splits + split;
     const float ov = val / L * p.v_scale, lv = M * kLn2 + __logf(L);
     if (p.merge_cnt) {  // in-launch merge: the partial is PUBLISHED -- write-through (sc1) stores, no release fence needed
       __hip_atomic_store(p.attn_logits + slot * D + d, ov, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -463,7 +471,7 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attn_stage1(const DecodePar
       if (d == 0) p.attn_lse[slot] = lv;
     }
   }
-  if (p.merge_cnt) arrive_and_merge<T, CASC != 0>(p, b, seq_len, nsplit, hchunks, smem);
+  if (p.merge_cnt) arrive_and_merge<T, CASC == 2>(p, b, seq_len, nsplit, hchunks, smem);
 }
 
 // Any-head-dim fallback (D, Dv <= 256, not multiples of 32 allowed): one wave per
@@ -561,18 +569,8 @@ int g_decode_mode = 0;  // 0 = workgroup-shared split (default: faster at batch 
 
 template <typename T, int D, int KVB>
 int launch_mfma(const DecodeParams& p, hipStream_t st) {
-  const int hchunks = ((p.shared_reqs > 0 ? p.shared_reqs * p.group : p.group) + 15) / 16;
-  if (p.shared_reqs > 0) {   // cascade prefix pass: MODE 0 only (checked by the entry point)
-    constexpr int NW = 4;
-    constexpr int smem = NW * 2 * kTile * D * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)decode_attn_stage1<T, D, NW, 0, KVB, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-      attr_set = true;
-    }
-    dim3 grid(p.hkv * hchunks, 1, p.prefix_splits);
-    hipLaunchKernelGGL((decode_attn_stage1<T, D, NW, 0, KVB, 1>), grid, dim3(NW * 64), smem, st, p);
-  } else if (p.split_base > 0) {   // cascade suffix pass
+  const int hchunks = (p.group + 15) / 16;
+  if (p.prefix_splits > 0) {   // cascade suffix pass: MODE 0 only (checked by the entry point)
     constexpr int NW = 4;
     constexpr int smem = NW * 2 * kTile * D * 2;
     static bool attr_set = false;
@@ -580,7 +578,7 @@ int launch_mfma(const DecodeParams& p, hipStream_t st) {
       (void)hipFuncSetAttribute((const void*)decode_attn_stage1<T, D, NW, 0, KVB, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
       attr_set = true;
     }
-    dim3 grid(p.hkv * hchunks, p.bs, p.max_kv_splits - p.split_base);
+    dim3 grid(p.hkv * hchunks, p.bs, p.max_kv_splits - p.prefix_splits);
     hipLaunchKernelGGL((decode_attn_stage1<T, D, NW, 0, KVB, 2>), grid, dim3(NW * 64), smem, st, p);
   } else if (g_decode_mode == 0) {
     constexpr int NW = 4;
@@ -644,7 +642,7 @@ static int decode_entry(
     const int64_t* seq_lens, float* attn_logits, float* attn_lse, const int32_t* num_kv_splits, int max_kv_splits,
     int batch, int num_q_heads, int num_kv_heads, int head_dim, int v_head_dim, float sm_scale, float logit_cap,
     int dtype, int kv_dtype, float k_scale, float v_scale, int32_t* merge_cnt, void* mq_o, void* mq_q, float* mq_s,
-    void* stream, int shared_reqs = 0, int prefix_len = 0, int prefix_splits = 0, int split_base = 0) {
+    void* stream, int prefix_len = 0, int prefix_splits = 0) {
   SGL_CHECK(batch >= 0, "decode_attention: negative batch %d", batch);
   if (batch == 0) return SGL_MI355_OK;
   SGL_CHECK(q && k_buffer && v_buffer, "decode_attention: null tensor pointer");  // o == NULL: split partials only
@@ -685,17 +683,13 @@ static int decode_entry(
   p.kv_fp8 = kv8 ? 1 : 0;
   p.k_scale = kv8 ? k_scale : 1.0f; p.v_scale = kv8 ? v_scale : 1.0f;
   p.merge_cnt = merge_cnt; p.mq_o = mq_o; p.mq_q = mq_q; p.mq_s = mq_s;
-  p.shared_reqs = shared_reqs; p.prefix_len = prefix_len; p.prefix_splits = prefix_splits; p.split_base = split_base;
-  if (shared_reqs > 0 || split_base > 0) {
+  p.prefix_len = prefix_len; p.prefix_splits = prefix_splits;
+  if (prefix_splits > 0) {
     SGL_CHECK(head_dim == v_head_dim && (head_dim == 128 || head_dim == 64) && g_decode_mode == 0,
               "decode_attention_cascade: needs the MFMA kernel (head_dim 64 / 128) in its workgroup-per-split mode");
-    SGL_CHECK(prefix_len > 0 && prefix_splits >= 1 && prefix_splits < max_kv_splits,
+    SGL_CHECK(prefix_len > 0 && prefix_splits < max_kv_splits,
               "decode_attention_cascade: prefix_len=%d, prefix_splits=%d must be positive and leave split slots for the suffix (max_kv_splits=%d)",
               prefix_len, prefix_splits, max_kv_splits);
-  }
-  if (shared_reqs > 0) {   // prefix pass: one virtual request, grid.y = 1
-    p.bs = 1;
-    p.kv_indptr = nullptr;   // (the range is [0, prefix_len) of kv_indices)
   }
   if (merge_cnt != nullptr) {
     SGL_CHECK(head_dim == v_head_dim && (head_dim == 128 || head_dim == 64) && g_decode_mode == 0,
@@ -737,13 +731,20 @@ extern "C" int sgl_mi355_decode_attention_merge_quant(
 }
 
 // Cascade shared-prefix decode: every request of the batch shares its first prefix_len slots (one radix-tree
-// node, radix_cache.py:370-412).  Two launches: (1) the prefix is attended ONCE per (kv head, 16-column chunk, split) for the
-// query heads of ALL requests (prefix_indices int32 [prefix_len], prefix_splits splits); (2) every request's private suffix
-// (kv_indptr / kv_indices over the slots after the prefix, num_kv_splits[b] splits) with the in-launch stage 2 merging prefix
-// + suffix partials by their log-sum-exp -- the math of merge_state (sgl-kernel/csrc/attention/merge_attn_states.cu) -- into
+// node, radix_cache.py:370-412).  Two launches: (1) the prefix is attended ONCE for all requests -- a launch of the extend kernel
+// with the batch's decode queries as its query block and at most prefix_splits splits of the shared rows (prefix_indices int32
+// [prefix_len]), partials into the top split slots; (2) every request's private part (kv_indptr / kv_indices over the slots after
+// the prefix, num_kv_splits[b] splits, at least the new token) whose first split continues the online softmax from the prefix
+// state -- the math of merge_state (sgl-kernel/csrc/attention/merge_attn_states.cu) -- with the in-launch stage 2 producing
 // out_o (T, optional) and / or the per-token fp8 row out_q / out_s (optional).  attn_logits / attn_lse hold max_kv_splits
 // split slots per (request, head): prefix_splits + max(num_kv_splits) <= max_kv_splits.  merge_counters: int32 [batch], zero
 // on entry, left zero.
+int sgl_mi355_internal_cascade_prefix(const void* q, int64_t q_stride_t, const void* k_buffer, const void* v_buffer, int64_t k_stride_t,
+                                      int64_t k_stride_h, int64_t v_stride_t, int64_t v_stride_h, const int32_t* prefix_indices,
+                                      int prefix_len, int chunk, int splits, int slot0, float* attn_logits, float* attn_lse,
+                                      int max_kv_splits, int batch, int num_q_heads, int num_kv_heads, int head_dim, float sm_scale,
+                                      float logit_cap, int dtype, int kv_dtype, float k_scale, float v_scale, hipStream_t st);  // extend_attention.hip
+
 extern "C" int sgl_mi355_decode_attention_cascade(
     const void* q, int64_t q_stride_t, const void* k_buffer, const void* v_buffer, int64_t k_stride_t,
     int64_t k_stride_h, int64_t v_stride_t, int64_t v_stride_h, const int32_t* prefix_indices, int prefix_len,
@@ -753,13 +754,24 @@ extern "C" int sgl_mi355_decode_attention_cascade(
     int32_t* merge_counters, void* out_o, void* out_q, float* out_s, void* stream) {
   SGL_CHECK(merge_counters != nullptr && kv_indptr != nullptr && prefix_indices != nullptr, "decode_attention_cascade: null pointer");
   if (batch == 0) return SGL_MI355_OK;
-  int rc = decode_entry(q, q_stride_t, k_buffer, v_buffer, k_stride_t, k_stride_h, v_stride_t, v_stride_h, nullptr, 0, kv_indptr,
-                        prefix_indices, nullptr, 0, nullptr, nullptr, attn_logits, attn_lse, num_kv_splits, max_kv_splits, batch,
-                        num_q_heads, num_kv_heads, head_dim, v_head_dim, sm_scale, logit_cap, dtype, kv_dtype, k_scale, v_scale,
-                        nullptr, nullptr, nullptr, nullptr, stream, batch, prefix_len, prefix_splits, 0);
+  SGL_CHECK(q && k_buffer && v_buffer && attn_logits && attn_lse, "decode_attention_cascade: null tensor pointer");
+  SGL_CHECK(head_dim == v_head_dim && (head_dim == 128 || head_dim == 64), "decode_attention_cascade: head_dim 64 / 128 only (got %d, %d)",
+            head_dim, v_head_dim);
+  SGL_CHECK(prefix_len > 0 && prefix_splits >= 1 && prefix_splits < max_kv_splits && num_kv_heads > 0 && num_q_heads % num_kv_heads == 0,
+            "decode_attention_cascade: prefix_len=%d prefix_splits=%d max_kv_splits=%d", prefix_len, prefix_splits, max_kv_splits);
+  SGL_CHECK(dtype == SGL_BF16 || dtype == SGL_F16, "decode_attention_cascade: dtype code %d unsupported", dtype);
+  SGL_CHECK(q_stride_t % 8 == 0 && ((uintptr_t)q % 16) == 0 && ((uintptr_t)k_buffer % 16) == 0 && ((uintptr_t)v_buffer % 16) == 0,
+            "decode_attention_cascade: q/k/v rows must be 16-byte aligned");
+  // whole 64-row tiles per split; fewer splits than asked for when the prefix is short (every split holds at least one row)
+  const int chunk = ((prefix_len + prefix_splits - 1) / prefix_splits + 63) / 64 * 64;
+  const int splits = (prefix_len + chunk - 1) / chunk;
+  int rc = sgl_mi355_internal_cascade_prefix(q, q_stride_t, k_buffer, v_buffer, k_stride_t, k_stride_h, v_stride_t, v_stride_h,
+                                             prefix_indices, prefix_len, chunk, splits, max_kv_splits - splits, attn_logits, attn_lse,
+                                             max_kv_splits, batch, num_q_heads, num_kv_heads, head_dim, sm_scale, logit_cap, dtype,
+                                             kv_dtype, k_scale, v_scale, (hipStream_t)stream);
   if (rc != SGL_MI355_OK) return rc;
   return decode_entry(q, q_stride_t, k_buffer, v_buffer, k_stride_t, k_stride_h, v_stride_t, v_stride_h, nullptr, 0, kv_indptr,
                       kv_indices, nullptr, 0, nullptr, nullptr, attn_logits, attn_lse, num_kv_splits, max_kv_splits, batch,
                       num_q_heads, num_kv_heads, head_dim, v_head_dim, sm_scale, logit_cap, dtype, kv_dtype, k_scale, v_scale,
-                      merge_counters, out_o, out_q, out_s, stream, 0, prefix_len, prefix_splits, prefix_splits);
+                      merge_counters, out_o, out_q, out_s, stream, prefix_len, splits);
 }

@@ -53,6 +53,14 @@ struct ExtendParams {
   const int64_t* mask_indptr;
   int skip_prefix_mask;
   int sliding_window;
+  // Cascade (shared-prefix) decode, PREFIX pass (casc_bs > 0; sgl_mi355_decode_attention_cascade): the casc_bs decode queries
+  // q [casc_bs, Hq, D] are the "extend tokens" of bs = prefix splits virtual sequences that all start at query row 0; sequence
+  // b attends ONLY to the shared prefix rows kv_indices[b * casc_chunk, min((b + 1) * casc_chunk, casc_prefix_len)) (no extend
+  // keys), and instead of o the kernel writes the split partial O = acc / l (f32) and its natural-log LSE to the decode
+  // kernel's split slots: part_o [casc_bs][hq][max_kv_splits][D], part_lse [casc_bs][hq][max_kv_splits], slot casc_slot0 + b.
+  int casc_bs = 0, casc_prefix_len = 0, casc_chunk = 0, casc_slot0 = 0, max_kv_splits = 0;
+  float* part_o = nullptr;
+  float* part_lse = nullptr;
 };
 
 constexpr int kKT = 64;  // kv tokens per tile
@@ -83,7 +91,9 @@ __device__ __forceinline__ u32x4_t cvt8_fp8(const u32x2_t& in) {
 // CAP: logit soft-capping (its own instantiation).  MASKED: custom mask and / or sliding window (speculative decoding, window
 // models): every tile takes the masking pass, the per-score mask bytes are plain global loads -- a correctness path whose
 // extra work stays out of the unmasked instantiations; the logit cap is a run-time branch there.
-template <typename T, int D, bool KV8 = false, bool CAP = false, bool MASKED = false>
+// QT: 16-row query tiles per wave (2: 128 (head, position) pairs per workgroup, the prefill form; 1: 64 pairs, half the per-tile
+// latency of a wave -- the cascade prefix pass, whose few workgroups are latency-bound).
+template <typename T, int D, bool KV8 = false, bool CAP = false, bool MASKED = false, int QT = 2>
 __global__ __launch_bounds__(256, 2) void extend_attn_kernel(const ExtendParams p) {
   using Tr = ElemTraits<T>;
   using vec8 = typename Tr::vec8;
@@ -113,14 +123,18 @@ __global__ __launch_bounds__(256, 2) void extend_attn_kernel(const ExtendParams 
   const int kh = khc / p.hchunks, hc = khc - kh * p.hchunks;
 
   const int bq = 1 << p.bq_log2;          // query positions per workgroup
-  const int gslots = 128 >> p.bq_log2;    // head slots per workgroup (<= 8)
-  const int q0 = p.qo_indptr ? p.qo_indptr[b] : p.extend_start_loc[b];
-  const int ext_len = p.qo_indptr ? p.qo_indptr[b + 1] - q0 : p.extend_seq_lens[b];
+  const int gslots = (64 * QT) >> p.bq_log2;    // head slots per workgroup (<= 4 QT)
+  const bool cascade = p.casc_bs > 0;
+  const int q0 = cascade ? 0 : (p.qo_indptr ? p.qo_indptr[b] : p.extend_start_loc[b]);
+  const int ext_len = cascade ? p.casc_bs : (p.qo_indptr ? p.qo_indptr[b + 1] - q0 : p.extend_seq_lens[b]);
   const int qpos0 = qb * bq;
   if (qpos0 >= ext_len) return;
   int pre_len;
   const int32_t* idx_row;
-  if (p.kv_indptr) {  // mode by indptr: kv_indices may legitimately be NULL when no request has a prefix
+  if (cascade) {
+    pre_len = min(p.casc_chunk, p.casc_prefix_len - b * p.casc_chunk);   // > 0: the launcher sizes bs = ceil(len / chunk)
+    idx_row = p.kv_indices + b * p.casc_chunk;
+  } else if (p.kv_indptr) {  // mode by indptr: kv_indices may legitimately be NULL when no request has a prefix
     const int s0 = p.kv_indptr[b];
     pre_len = p.kv_indptr[b + 1] - s0;
     idx_row = p.kv_indices + s0;
@@ -140,14 +154,14 @@ __global__ __launch_bounds__(256, 2) void extend_attn_kernel(const ExtendParams 
   const bool capped = CAP || (MASKED && p.logit_cap > 0.0f);
 
   // ---- this wave's two 16-row query tiles: tile t covers head slot (16 t) / bq, positions (16 t) % bq ... ----
-  int hq_idx[2], qpos[2];
-  bool head_ok[2];
-  vec8 qf[2][KS];
+  int hq_idx[QT], qpos[QT];
+  bool head_ok[QT];
+  vec8 qf[QT][KS];
 #pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
-    const int t16 = (2 * w + qt) * 16;
+  for (int qt = 0; qt < QT; ++qt) {
+    const int t16 = (QT * w + qt) * 16;
     const int hslot = t16 >> p.bq_log2;
-    const int hl = hc * 8 + hslot;  // head within the GQA group
+    const int hl = hc * (4 * QT) + hslot;  // head within the GQA group (at most 4 QT head slots per workgroup: >= 16 positions each)
     head_ok[qt] = hl < p.group && hslot < gslots;
     hq_idx[qt] = kh * p.group + min(hl, p.group - 1);
     qpos[qt] = qpos0 + (t16 & (bq - 1)) + a;  // position of this lane's query row inside the extend part
@@ -175,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void extend_attn_kernel(const ExtendParams 
 
   const int npre_tiles = (pre_len + kKT - 1) / kKT;
   const int ext_end = p.is_causal ? min(ext_len, qpos0 + bq) : ext_len;  // keys any row of this block may see
-  const int next_tiles = (ext_end + kKT - 1) / kKT;
+  const int next_tiles = cascade ? 0 : (ext_end + kKT - 1) / kKT;
   const int ntiles = npre_tiles + next_tiles;
 
   // Staging registers hold RAW loaded data: nothing consumes a load at issue time (zeroing the V rows past the end and the
@@ -190,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void extend_attn_kernel(const ExtendParams 
   const u32x4_t zero4 = {0u, 0u, 0u, 0u};
   // (16-bit pools: ONE unconditional load site per operand with selected addresses -- loads under a branch make the
   // wait-count insertion put vmcnt(0) in front of the next tile's first MFMA)
-  const int32_t* idx_dummy = p.qo_indptr ? p.qo_indptr : p.extend_start_loc;  // any readable int32 when there is no prefix row
+  const int32_t* idx_dummy = cascade ? p.kv_indices : (p.qo_indptr ? p.qo_indptr : p.extend_start_loc);  // any readable int32 when there is no prefix row
   auto load_idx = [&](int t) {
     const bool pre = t < npre_tiles;
 #pragma unroll
@@ -253,12 +267,15 @@ __global__ __launch_bounds__(256, 2) void extend_attn_kernel(const ExtendParams 
     }
   };
 
-  float m_i[2] = {-INFINITY, -INFINITY}, l_i[2] = {0.f, 0.f};
-  f32x4_t acc[2][NT];
+  float m_i[QT], l_i[QT];
+  f32x4_t acc[QT][NT];
 #pragma unroll
-  for (int qt = 0; qt < 2; ++qt)
+  for (int qt = 0; qt < QT; ++qt) {
+    m_i[qt] = -INFINITY;
+    l_i[qt] = 0.f;
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[qt][n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
 
   const float scale_log2 = p.sm_scale * kLog2e;
 
@@ -288,15 +305,15 @@ __global__ __launch_bounds__(256, 2) void extend_attn_kernel(const ExtendParams 
     }
 
     // a wave whose rows all lie in the causal past of this tile skips it (wave-uniform)
-    const int wave_qmax = qpos0 + (((2 * w + 1) * 16) & (bq - 1)) + 15;
-    const int wave_qmax0 = qpos0 + (((2 * w) * 16) & (bq - 1)) + 15;
+    const int wave_qmax = qpos0 + (((QT * w + QT - 1) * 16) & (bq - 1)) + 15;
+    const int wave_qmax0 = qpos0 + (((QT * w) * 16) & (bq - 1)) + 15;
     // (a custom mask replaces the causal rule in the extend phase: no causal skip then)
     const bool skip = !in_prefix && p.is_causal && !(MASKED && mrow) && kbase > max(wave_qmax, wave_qmax0);
-    const int wave_qmin = qpos0 + (bq >= 32 ? ((32 * w) & (bq - 1)) : 0);
+    const int wave_qmin = qpos0 + (bq >= 16 * QT ? ((16 * QT * w) & (bq - 1)) : 0);
     const bool need_mask = MASKED || (kbase + kKT > klimit) || (!in_prefix && p.is_causal && kbase + kKT - 1 > wave_qmin);
     if (!skip) {
       // ---- S^T tiles: s[qt][tt][r] = score(query row a of tile qt, key 16 tt + 4 g + r) ----
-      f32x4_t s[2][4];
+      f32x4_t s[QT][4];
       // K fragments two key groups ahead of their MFMAs (double-buffered registers): a fragment set requested right before its
       // MFMAs made every 8 of them wait for an LDS round trip
       vec8 kfb[2][KS];
@@ -312,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void extend_attn_kernel(const ExtendParams 
       for (int tt = 0; tt < 4; ++tt) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
+        for (int qt = 0; qt < QT; ++qt) {
           f32x4_t c = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks) c = Tr::mfma16(kfb[tt & 1][ks], qf[qt][ks], c);
@@ -326,7 +343,7 @@ __global__ __launch_bounds__(256, 2) void extend_attn_kernel(const ExtendParams 
       // basic blocks and nothing was scheduled across them) ----
       if (capped) {   // compile-time true / false in the unmasked instantiations
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
+        for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
           for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
@@ -334,7 +351,7 @@ __global__ __launch_bounds__(256, 2) void extend_attn_kernel(const ExtendParams 
       }
       if constexpr (MASKED) {
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
+        for (int qt = 0; qt < QT; ++qt) {
           const int qp = qpos[qt];
           const bool qrow_ok = qp < ext_len;   // padding rows are never stored: keep their mask reads in bounds
           const uint8_t* mq = mrow ? mrow + (int64_t)min(qp, ext_len - 1) * seq_total + (in_prefix ? 0 : pre_len) : nullptr;
@@ -357,7 +374,7 @@ __global__ __launch_bounds__(256, 2) void extend_attn_kernel(const ExtendParams 
         }
       } else if (need_mask) {
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
+        for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
           for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
@@ -371,9 +388,9 @@ __global__ __launch_bounds__(256, 2) void extend_attn_kernel(const ExtendParams 
       // ---- online softmax per query tile, branch-free (m_i in log2 units; the score scale is folded into the exponent's fma;
       // a row that has seen no key yet keeps m = -inf, l = 0, acc = 0 through the clamped maximum) ----
       const float cs = capped ? 1.0f : tlog2;  // x = s * cs (sm_scale * log2 e > 0; soft-capped scores are already in log2 units)
-      vec8 pf[2][2];
+      vec8 pf[QT][2];
 #pragma unroll
-      for (int qt = 0; qt < 2; ++qt) {
+      for (int qt = 0; qt < QT; ++qt) {
         float m = -INFINITY;
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt)
@@ -439,7 +456,7 @@ __global__ __launch_bounds__(256, 2) void extend_attn_kernel(const ExtendParams 
 #pragma unroll
           for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt)
+            for (int qt = 0; qt < QT; ++qt)
               acc[qt][nb * NB + nn] = Tr::mfma16(vfb[nb & 1][nn][u], pf[qt][u], acc[qt][nb * NB + nn]);
       }
     }
@@ -449,10 +466,25 @@ __global__ __launch_bounds__(256, 2) void extend_attn_kernel(const ExtendParams 
 
   // ---- o = acc / l ; lane (a, g) owns query row a, columns 16 n + 4 g + [0, 4) ----
 #pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
+  for (int qt = 0; qt < QT; ++qt) {
     float l = l_i[qt];
     l += __shfl_xor(l, 16, WAVE);
     l += __shfl_xor(l, 32, WAVE);
+    if (cascade) {   // split partial of (request qpos, head hq_idx): O = acc / l in f32 and LSE = m ln 2 + ln l, the decode kernel's slot layout
+      if (head_ok[qt] && qpos[qt] < ext_len) {
+        const int64_t slot = ((int64_t)qpos[qt] * p.hq + hq_idx[qt]) * p.max_kv_splits + p.casc_slot0 + b;
+        const float inv = 1.0f / l;   // l > 0: every split holds at least one key
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          f32x4_t o = acc[qt][n];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] *= inv;
+          *(f32x4_t*)(p.part_o + slot * D + 16 * n + 4 * g) = o;
+        }
+        if (g == 0) p.part_lse[slot] = m_i[qt] * 0.6931471805599453f + __logf(l);
+      }
+      continue;
+    }
     if (head_ok[qt] && qpos[qt] < ext_len) {
       const float inv = l > 0.f ? 1.0f / l : 0.f;
       T* orow = (T*)p.o + (int64_t)(q0 + qpos[qt]) * p.o_stride_t + (int64_t)hq_idx[qt] * D;
@@ -555,25 +587,27 @@ __global__ __launch_bounds__(64) void extend_attn_generic(const ExtendParams p, 
   }
 }
 
-template <typename T, int D, bool KV8, bool CAP = false, bool MASKED = false>
+template <typename T, int D, bool KV8, bool CAP = false, bool MASKED = false, int QT = 2>
 int launch_mfma(ExtendParams& p, int max_len_extend, hipStream_t st) {
-  if constexpr (!CAP && !MASKED) {
+  if constexpr (!CAP && !MASKED && QT == 2) {
     if (p.custom_mask != nullptr || p.sliding_window > 0) return launch_mfma<T, D, KV8, false, true>(p, max_len_extend, st);
+    if (p.casc_bs > 0) return p.logit_cap > 0.0f ? launch_mfma<T, D, KV8, true, false, 1>(p, max_len_extend, st)
+                                                 : launch_mfma<T, D, KV8, false, false, 1>(p, max_len_extend, st);
     if (p.logit_cap > 0.0f) return launch_mfma<T, D, KV8, true>(p, max_len_extend, st);
   }
   constexpr int smem = 2 * 2 * kKT * D * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)extend_attn_kernel<T, D, KV8, CAP, MASKED>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)extend_attn_kernel<T, D, KV8, CAP, MASKED, QT>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
-  // head slots per workgroup: smallest power of two >= min(group, 8); positions per workgroup = 128 / slots
+  // head slots per workgroup: smallest power of two >= min(group, 4 QT); positions per workgroup = 64 QT / slots (>= 16)
   int slots = 1;
-  while (slots < p.group && slots < 8) slots <<= 1;
-  int bq = 128 / slots, lg = 0;
+  while (slots < p.group && slots < 4 * QT) slots <<= 1;
+  int bq = 64 * QT / slots, lg = 0;
   while ((1 << lg) < bq) ++lg;
   p.bq_log2 = lg;
-  p.hchunks = (p.group + 7) / 8;
+  p.hchunks = (p.group + 4 * QT - 1) / (4 * QT);
   p.nqb = (max_len_extend + bq - 1) / bq;
   const int npairs = p.bs * p.hkv * p.hchunks;
   const int64_t nblocks = (int64_t)((npairs + 7) / 8) * p.nqb * 8;
@@ -582,7 +616,7 @@ int launch_mfma(ExtendParams& p, int max_len_extend, hipStream_t st) {
     snprintf(g_sgl_mi355_err, sizeof(g_sgl_mi355_err), "extend_attention: grid too large");
     return SGL_MI355_EINVAL;
   }
-  hipLaunchKernelGGL((extend_attn_kernel<T, D, KV8, CAP, MASKED>), dim3((unsigned)nblocks), dim3(256), smem, st, p);
+  hipLaunchKernelGGL((extend_attn_kernel<T, D, KV8, CAP, MASKED, QT>), dim3((unsigned)nblocks), dim3(256), smem, st, p);
   SGL_HIP_LAUNCH_CHECK();
   return SGL_MI355_OK;
 }
@@ -597,6 +631,29 @@ int launch_all(ExtendParams& p, int d_qk, int dv, int total_q, int max_len_exten
 }
 
 }  // namespace
+
+// Cascade prefix pass (called by sgl_mi355_decode_attention_cascade, decode_attention.hip): see ExtendParams::casc_*.
+// Returns the number of prefix split slots written through *splits_out (slots [slot0, slot0 + splits)).
+int sgl_mi355_internal_cascade_prefix(const void* q, int64_t q_stride_t, const void* k_buffer, const void* v_buffer, int64_t k_stride_t,
+                                      int64_t k_stride_h, int64_t v_stride_t, int64_t v_stride_h, const int32_t* prefix_indices,
+                                      int prefix_len, int chunk, int splits, int slot0, float* attn_logits, float* attn_lse,
+                                      int max_kv_splits, int batch, int num_q_heads, int num_kv_heads, int head_dim, float sm_scale,
+                                      float logit_cap, int dtype, int kv_dtype, float k_scale, float v_scale, hipStream_t st) {
+  ExtendParams p{};
+  p.q = q; p.ke = nullptr; p.ve = nullptr; p.o = nullptr;
+  p.q_stride_t = q_stride_t; p.ke_stride_t = 0; p.ve_stride_t = 0; p.o_stride_t = 0;
+  p.k_buf = k_buffer; p.v_buf = v_buffer;
+  p.k_stride_t = k_stride_t; p.k_stride_h = k_stride_h; p.v_stride_t = v_stride_t; p.v_stride_h = v_stride_h;
+  p.kv_indices = prefix_indices;
+  p.bs = splits; p.hq = num_q_heads; p.hkv = num_kv_heads; p.group = num_q_heads / num_kv_heads;
+  p.sm_scale = sm_scale; p.logit_cap = logit_cap; p.is_causal = 0;
+  const bool kv8 = kv_dtype == SGL_FP8_E4M3;
+  p.kv_fp8 = kv8 ? 1 : 0; p.k_scale = kv8 ? k_scale : 1.0f; p.v_scale = kv8 ? v_scale : 1.0f;
+  p.nqb = 0; p.bq_log2 = 0; p.hchunks = 1;
+  p.casc_bs = batch; p.casc_prefix_len = prefix_len; p.casc_chunk = chunk; p.casc_slot0 = slot0; p.max_kv_splits = max_kv_splits;
+  p.part_o = attn_logits; p.part_lse = attn_lse;
+  return dtype == SGL_BF16 ? launch_all<__bf16>(p, head_dim, head_dim, batch, batch, st) : launch_all<_Float16>(p, head_dim, head_dim, batch, batch, st);
+}
 
 extern "C" int sgl_mi355_extend_attention(
     const void* q_extend, const void* k_extend, const void* v_extend, void* o_extend, int64_t q_stride_t,

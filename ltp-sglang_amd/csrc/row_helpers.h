@@ -89,16 +89,12 @@ __device__ __forceinline__ void quant_row(const float (&vals)[MAXV][8], int nvec
 template <typename T, int MAXV>
 __device__ __forceinline__ void merge_quant_row(int b, const float* attn_logits, const float* attn_lse, int seq_len, int nsplit,
                                                 int max_kv_splits, int hq, int dv, T* out_o, uint8_t* out_q, float* out_s,
-                                                float* red, int pre_len = 0, int pre_splits = 0) {
-  // cascade (shared-prefix) decode: split slots [0, pre_splits) hold the partials of the shared prefix (pre_len keys, its own
-  // split length), slots [pre_splits, pre_splits + nsplit) those of the request's private suffix (seq_len keys)
+                                                float* red, bool split0_always = false) {
   const int per0 = (seq_len + nsplit - 1) / nsplit;
   const int per = (per0 + 31) / 32 * 32;
-  const int pper = pre_splits > 0 ? ((pre_len + pre_splits - 1) / pre_splits + 31) / 32 * 32 : 0;
-  const int total = pre_splits + nsplit;
-  auto live = [&](int sI) -> bool {
-    return sI < pre_splits ? sI * pper < pre_len : (sI < total && (sI - pre_splits) * per < seq_len);
-  };
+  const int total = nsplit;
+  // split0_always: the cascade decode's split 0 carries the shared-prefix state even when the request's private part is empty
+  auto live = [&](int sI) -> bool { return sI < total && (sI * per < seq_len || (sI == 0 && split0_always)); };
   const int row_elems = hq * dv, nvec = row_elems / 8;
   float vals[MAXV][8];
 #pragma unroll

@@ -129,11 +129,15 @@ class HipAttnBackend(AttentionBackend):
         return md
 
     def _cascade_prefix_splits(self, bs: int, shared_prefix_len: int) -> int:
+        """Splits of the shared prefix: the prefix pass (the extend kernel over the batch's decode queries) runs one workgroup
+        per (kv head, 64 (head, request) pairs, split); enough splits for about one workgroup per CU, at least 128 rows each,
+        at most half of the split slots (the private parts need the rest)."""
         group = self.num_head // self.num_kv_head
-        chunks = self.num_kv_head * ((bs * group + 15) // 16)
-        # one round of resident workgroups (2 per CU); every extra split is one more partial per (request, head) for the
-        # merging workgroup to read (measured: 4 splits 57 us, 8: 66 us, 12: 75 us per layer at 64 x (1536 + 512))
-        return max(1, min(2 * self.device_core_count // max(chunks, 1), shared_prefix_len // 128, 4))
+        slots = 1
+        while slots < group and slots < 4:
+            slots *= 2
+        per_split = self.num_kv_head * ((group + 3) // 4) * ((bs + 64 // slots - 1) // (64 // slots))
+        return max(1, min(self.device_core_count // max(per_split, 1), shared_prefix_len // 128, self.max_kv_splits // 2))
 
     def _cascade_ok(self, bs: int, shared_prefix_len: int) -> bool:
         return shared_prefix_len >= 64 and bs >= 2 and self.v_head_dim in (64, 128)

@@ -96,5 +96,9 @@ def run_cascade(bs=64, hq=32, hkv=8, d=128, pre=1536, uniq=512, max_splits=16, l
     print("max |cascade - plain| =", float((o1.float() - o2.float()).abs().max()))
 
 
-for ps, ss in (((4, 1),) if "--cascade-only" in sys.argv else ((2, 1), (4, 1), (4, 2), (8, 1))):
+for ps, ss in (((8, 1),) if "--cascade-only" in sys.argv else ((2, 1), (4, 1), (6, 1), (8, 1), (12, 1), (8, 2))):
     run_cascade(prefix_splits=ps, suffix_splits=ss)
+if "--long-prefix" in sys.argv:   # a longer system prompt, shorter private parts: where the shared rows dominate
+    for pre, uniq in ((4096, 256), (8192, 128)):
+        print(f"--- prefix {pre} + private {uniq}")
+        run_cascade(pre=pre, uniq=uniq, prefix_splits=8, suffix_splits=1)
