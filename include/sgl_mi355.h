@@ -78,12 +78,13 @@ int sgl_mi355_merge_state(const void* v_a, const float* s_a, const void* v_b, co
 
 /* Cascade shared-prefix decode ("shared-prefix once, unique-suffix per request"): every request of the batch
  * shares its first prefix_len KV slots -- one RadixCache node (python/sglang/srt/mem_cache/radix_cache.py:370-412).  The
- * prefix rows are attended once for the query heads of ALL requests (they become extra MFMA columns), each request's private
- * suffix (kv_indptr / kv_indices over the slots AFTER the prefix) separately, and the two partial states are combined by
- * their log-sum-exp inside the second launch -- the math of merge_state / merge_state_v2
- * (sgl-kernel/csrc/attention/merge_attn_states.cu, python/sgl_kernel/attention.py:12-52).  Outputs as
- * sgl_mi355_decode_attention_merge_quant.  attn_logits / attn_lse: max_kv_splits slots per (request, head), of which the
- * first prefix_splits belong to the prefix.  merge_counters: int32 [batch], zero on entry, left zero. */
+ * prefix rows are attended once for the query heads of ALL requests (a launch of the extend kernel with the batch's decode
+ * queries as its query block, at most prefix_splits splits), each request's private part (kv_indptr / kv_indices over the slots
+ * AFTER the prefix; at least the new token) separately, its first split continuing the online softmax from the prefix state
+ * -- the log-sum-exp combination of merge_state / merge_state_v2 (sgl-kernel/csrc/attention/merge_attn_states.cu,
+ * python/sgl_kernel/attention.py:12-52).  Outputs as sgl_mi355_decode_attention_merge_quant.  attn_logits / attn_lse:
+ * max_kv_splits slots per (request, head), of which the LAST prefix_splits hold the prefix partials: prefix_splits +
+ * max(num_kv_splits) <= max_kv_splits.  head_dim 64 / 128.  merge_counters: int32 [batch], zero on entry, left zero. */
 int sgl_mi355_decode_attention_cascade(const void* q, int64_t q_stride_t, const void* k_buffer, const void* v_buffer,
                                        int64_t k_stride_t, int64_t k_stride_h, int64_t v_stride_t, int64_t v_stride_h,
                                        const int32_t* prefix_indices, int prefix_len, int prefix_splits,

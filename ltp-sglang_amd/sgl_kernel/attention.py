@@ -213,9 +213,10 @@ def decode_attention_cascade(q, k_buffer, v_buffer, prefix_indices, prefix_split
                              num_kv_splits, max_kv_splits, sm_scale, merge_counters, logit_cap=0.0, k_scale=1.0, v_scale=1.0,
                              want_o=True, want_quant=False):
     """Shared-prefix ("cascade") decode: all requests of the batch share the KV slots ``prefix_indices`` (int32 [P], one radix
-    node); ``kv_indptr`` / ``kv_indices`` cover each request's private slots after the prefix.  The prefix is read once for all
-    requests' heads, the suffixes per request, and the two partial states are merged by LSE (``merge_state`` math) inside the
-    second launch.  Same result as decode_attention_fwd over the full sequences, up to the order of the softmax sums.
+    node); ``kv_indptr`` / ``kv_indices`` cover each request's private slots after the prefix (at least the new token).  The
+    prefix is attended once for all requests' heads (extend kernel, up to ``prefix_splits`` splits whose partials use the LAST
+    split slots), the private parts per request, their first split continuing the online softmax from the prefix state
+    (``merge_state`` math).  Same result as decode_attention_fwd over the full sequences, up to the order of the softmax sums.
     Returns (o or None, o_q or None, o_scale or None) like decode_attention_merge_quant."""
     _require_cuda(q, k_buffer, v_buffer, prefix_indices, kv_indptr, kv_indices, attn_logits, attn_lse, num_kv_splits, merge_counters)
     bs, hq, d = q.shape
