@@ -44,6 +44,10 @@ def run(m, n, k, dtype=torch.float8_e4m3fn, copies=12, iters=10, launches=None):
     print(f"M={m} N={n} K={k} {str(dtype)[6:]}: {ms*1e3:7.1f} us  {n*k*es/ms/1e6:6.0f} GB/s")
 
 if __name__ == "__main__":
+    if "--bf16" in sys.argv:   # config 2: the unquantised linears
+        for n, k in [(6144, 4096), (4096, 4096), (28672, 4096), (4096, 14336)]:
+            run(32, n, k, torch.bfloat16, copies=6)
+        sys.exit(0)
     for n, k in [(6144, 4096), (4096, 4096), (28672, 4096), (4096, 14336)]:
         run(32, n, k)
     run(32, 128256, 4096, torch.bfloat16, copies=2)
