@@ -387,6 +387,38 @@ def test_cascade_decode_matches_plain_and_oracle(hq, hkv, d, dtype, prefix_split
     assert torch.equal(oq_.cpu().view(torch.uint8), rq.view(torch.uint8)) and torch.equal(os_.cpu(), rs)
 
 
+@pytest.mark.parametrize("bs,prefix,prefix_splits,hq,hkv", [(33, 64, 8, 32, 8), (70, 65, 3, 16, 16), (17, 1000, 8, 8, 2), (64, 1536, 8, 32, 8),
+                                                            (5, 129, 12, 4, 4), (2, 640, 5, 64, 8)])
+def test_cascade_decode_batch_and_prefix_shapes(bs, prefix, prefix_splits, hq, hkv, pkg):
+    """Ragged batch sizes (not multiples of the 16-request query tiles), prefix lengths around the 64-row tile and split
+    boundaries, GQA groups 1 / 4 / 8, more splits asked for than the prefix has tiles: cascade == float64 oracle."""
+    from ltp_sglang_amd import sgl_kernel
+
+    dev = torch.device("cuda:0")
+    d, dtype, S = 128, torch.bfloat16, 16
+    g = torch.Generator().manual_seed(bs + prefix)
+    suffix = [int(x) for x in torch.randint(1, 90, (bs,), generator=g)]
+    P = _shared_prefix_problem(bs, hq, hkv, d, prefix=prefix, suffix=suffix, dtype=dtype, seed=bs)
+    suf = torch.tensor(suffix, dtype=torch.int32)
+    kv_indptr = torch.zeros(bs + 1, dtype=torch.int32)
+    kv_indptr[1:] = torch.cumsum(suf, 0)
+    kv_indices = torch.cat([P["r2t"][P["rpi"][i], prefix:int(P["seq"][i])] for i in range(bs)]).int()
+    logits = torch.full((bs, hq, S, d), float("nan"), dtype=torch.float32, device=dev)
+    lse = torch.full((bs, hq, S), float("nan"), dtype=torch.float32, device=dev)
+    nsplit = torch.randint(1, S - prefix_splits + 1, (bs,), generator=g).int().to(dev)
+    cnt = torch.zeros(bs, dtype=torch.int32, device=dev)
+    o, _, _ = sgl_kernel.decode_attention_cascade(P["q"].to(dev), P["k"].to(dev), P["v"].to(dev), P["pre_slots"].to(dev), prefix_splits,
+                                                  kv_indptr.to(dev), kv_indices.to(dev), logits, lse, nsplit, S, d ** -0.5, cnt,
+                                                  want_o=True, want_quant=False)
+    torch.cuda.synchronize()
+    assert int(cnt.abs().sum()) == 0
+    rows = sorted({0, bs - 1, bs // 2, min(bs - 1, 16), min(bs - 1, 31)})   # the float64 oracle on a sample of requests
+    ref = oa.decode_attention_f64(P["q"][rows], P["k"], P["v"], P["r2t"], P["rpi"][rows], P["seq"][rows], d ** -0.5)
+    got = o.view(bs, hq, d).cpu()[rows]
+    assert torch.isfinite(o.float()).all()
+    assert (got.double() - ref).abs().max().item() <= TOL_F64[dtype]
+
+
 def test_cascade_decode_fp8_kv_and_logit_cap(pkg):
     from ltp_sglang_amd import sgl_kernel
 
