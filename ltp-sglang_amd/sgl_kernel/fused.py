@@ -201,9 +201,12 @@ def awq_gemm_slabs(x, qpacked, sz, group_size: int):
     return out
 
 
-def balanced_tile_rows(n_rows: int) -> int:
-    """16-row tiles, or 8-row tiles when 16-row tiles would leave the last round of the persistent workgroups mostly idle (the
-    rule of the plain skinny GEMM's launcher): e.g. qkv_proj of Llama-3-8B, 384 tiles on 256 CUs."""
+def balanced_tile_rows(n_rows: int, elem_bytes: int = 1) -> int:
+    """16-row tiles, or -- fp8 operands only -- 8-row tiles when 16-row tiles would leave the last round of the persistent
+    workgroups mostly idle (the rule of the plain skinny GEMM's launcher): e.g. qkv_proj of Llama-3-8B, 384 tiles on 256 CUs.
+    (16-bit operands: an 8-row tile costs a wave the same 16 load instructions as a 16-row tile; measured slower.)"""
+    if elem_bytes != 1:
+        return 16
     cus = lib.sgl_mi355_device_cu_count(torch.cuda.current_device())
     t16 = n_rows // 16
     rounds = -(-t16 // cus)

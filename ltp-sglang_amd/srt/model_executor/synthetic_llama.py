@@ -386,7 +386,7 @@ class LlamaForCausalLM(nn.Module):
         if cached is None:
             hq, hkv = attn.num_heads, attn.num_kv_heads
             qw, gw = attn.qkv_proj.weight.data, mlp.gate_up_proj.weight.data   # [N, K]
-            tq, tg = K.balanced_tile_rows(qw.shape[0]), K.balanced_tile_rows(gw.shape[0])
+            tq, tg = K.balanced_tile_rows(qw.shape[0], qw.element_size()), K.balanced_tile_rows(gw.shape[0], gw.element_size())
             cached = layer._fused_w = dict(
                 qkv_w=K.interleave_rope_rows(qw, hq, hkv, 128, tq),
                 qkv_b=None if attn.qkv_proj.bias is None else K.interleave_rope_rows(attn.qkv_proj.bias.data, hq, hkv, 128, tq),
