@@ -46,7 +46,9 @@ def parse_args():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fused-decode", action="store_true", help="measurement hook: the per-op decode path (same logits, more launches)")
-    ap.add_argument("--prefill-chunk", type=int, default=8, help="requests per prefill call")
+    ap.add_argument("--prefill-chunk", type=int, default=32,
+                    help="requests per prefill call (32 = the whole BASELINE batch in one extend, as bench_one_batch.py does; "
+                         "sweep on one box: 4 / 8 / 16 / 32 requests -> 1 915 / 1 950 / 1 958 / 1 978 TFLOP/s)")
     ap.add_argument("--gemm-hook", type=int, default=0, help="measurement hook: value passed to sgl_mi355_fp8_gemm_force_tile")
     ap.add_argument("--kv-split-rule", type=int, default=2, help="0 = the reference's heuristic, 1 = max splits everywhere, 2 = the MI355X balance rule")
     ap.add_argument("--max-kv-splits", type=int, default=16, help="triton_attention_num_kv_splits (16 = the reference's HIP default)")
@@ -374,7 +376,8 @@ def main():
                    "all_reduce": ar_kind, "hip_graph": bool(use_graph), "layers": L, "kv_cache_dtype": args.kv_cache_dtype,
                    "act_dtype": args.dtype},
         "prefill": {"tflops": prefill_flops / prefill_s / 1e12, "seconds": prefill_s, "tokens": bs * seq,
-                    "tokens_per_s": bs * seq / prefill_s, "flops": prefill_flops},
+                    "tokens_per_s": bs * seq / prefill_s, "flops": prefill_flops,
+                    "requests_per_extend_call": min(bs, args.prefill_chunk)},
         "step_roofline": {"algorithmic_bytes_per_step": step_bytes, "hbm_peak_GBps": 8000.0,
                           "frac_of_hbm_roofline": step_bytes / (elapsed / args.steps) / (8e12 * world)},
         "roofline": {"kernel": "decode_attn_stage1", "bound": "hbm", "achieved": achieved, "peak": 8000.0,
