@@ -156,6 +156,12 @@ int sgl_mi355_set_kv_buffer_fp8(void* k_buffer, void* v_buffer, int64_t k_slot_b
                                 const void* cache_k, const void* cache_v, int64_t cache_k_stride, int64_t cache_v_stride,
                                 int k_row, int v_row, int64_t tokens, int src_dtype, float k_scale, float v_scale,
                                 void* stream);
+/* MHATokenToKVPool.move_kv_cache -> copy_all_layer_kv_cache (memory_pool.py:409-417, 1046-1081): buf[tgt_loc[i]] = buf[src_loc[i]]
+ * for every buffer in data_ptrs (uint64 [num_buffers], device) with rows of data_strides[b] bytes (int64 [num_buffers], device;
+ * multiples of 16), in place: every source row of a column block is read before any target row of it is written, as in the
+ * reference kernel.  Byte-exact.  num_locs <= 4096 per call. */
+int sgl_mi355_move_kv_cache(const void* data_ptrs, const int64_t* data_strides, int num_buffers, int64_t max_stride_bytes,
+                            const void* tgt_loc, int tgt_is64, const void* src_loc, int src_is64, int num_locs, void* stream);
 /* kv_indptr[1:bs+1] = cumsum(seq_lens) (triton_backend.py:172) and get_num_kv_splits_triton
  * (triton_backend.py:876-924); either output may be NULL.  static_splits: 0 = reference heuristic, 1 = max everywhere,
  * 2 = MI355X balance rule (about two rounds of resident workgroups). */
@@ -287,6 +293,25 @@ int sgl_mi355_qkv_rope_set_kv(const void* x, int64_t x_stride_elems, const void*
                               const int64_t* loc, void* k_buffer, void* v_buffer, int64_t k_slot_stride, int64_t v_slot_stride,
                               int M, int num_q_heads, int num_kv_heads, int head_dim, int K, int in_dtype, int out_dtype,
                               int tile_rows, int kv_dtype, float k_scale, float v_scale, void* stream);
+/* ---- persistent MLP half of a w8a8-fp8 decode layer (round 3; csrc/mlp_block.hip) --------------------------------------
+ * ONE launch for LlamaDecoderLayer's post_attention_layernorm (fused add + RMSNorm, models/llama.py:265, layernorm.py:135-171)
+ * -> per-token fp8 quant (fp8_utils.py:706-713) -> gate_up_proj + SiluAndMul (models/llama.py:94-96) -> per-token fp8 quant ->
+ * down_proj (models/llama.py:97, linear.py:1285-1309) at M <= 32: one resident workgroup per CU whose weight loads run ahead of
+ * the three chip-wide hand-offs between the steps.  x [M, hidden] = o_proj's output, residual [M, hidden] in/out; weights as for
+ * sgl_mi355_fp8_gemm_silu_mul (16-row interleaving) and fp8_scaled_mm ([hidden, inter] row-major); out_slabs f32
+ * [ceil(inter / 4096), M, hidden] raw down_proj partial sums, act_scales [M] their per-token scale (the consumer, e.g.
+ * sgl_mi355_fused_add_rmsnorm_quant_fp8 with slabs, applies act_scales[m] * down_scale[n]).  Scratch: xq [M, hidden] bytes,
+ * xs [M] f32, actq [M, inter] bytes, pmax (..._pmax_words uint32, 128-byte aligned), sync (..._sync_words uint32, 128-byte
+ * aligned, ZEROED by the caller before every launch; word 16 != 0 afterwards: a hand-off timed out).  timeline: NULL, or
+ * [CUs][8][16] int64 s_memrealtime stamps.  Arithmetic = the stand-alone kernels' (same rounding points; the RMSNorm variance is
+ * summed in another order).  ..._supported: 1 if the shape is taken (else keep the four-launch path). */
+int sgl_mi355_fp8_mlp_block_sync_words(void);
+int sgl_mi355_fp8_mlp_block_pmax_words(void);
+int sgl_mi355_fp8_mlp_block_supported(int M, int hidden, int inter);
+int sgl_mi355_fp8_mlp_block(const void* x, void* residual, const void* ln_weight, float eps, const void* w_gate_up_interleaved,
+                            const float* scales_gate_up_interleaved, const void* w_down, float* out_slabs, float* act_scales,
+                            void* xq_scratch, float* xs_scratch, void* actq_scratch, void* pmax_scratch, void* sync, int M,
+                            int hidden, int inter, int dtype, long long* timeline, void* stream);
 /* silu_and_mul (activation.py:60-63) -> sgl_per_token_quant_fp8 */
 int sgl_mi355_silu_and_mul_quant_fp8(const void* x, void* out_q, float* out_s, int tokens, int d, int dtype, void* stream);
 /* rotary_embedding (rotary_embedding.py:138-165) on q, k in place -> set_kv_buffer (memory_pool.py:369-407) of (k, v) */

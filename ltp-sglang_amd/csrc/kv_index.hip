@@ -523,3 +523,61 @@ extern "C" int sgl_mi355_alloc_decode(const void* seq_lens, int seq_is64, const 
   SGL_HIP_LAUNCH_CHECK();
   return SGL_MI355_OK;
 }
+
+// ---- move_kv_cache: MHATokenToKVPool.move_kv_cache -> copy_all_layer_kv_cache (memory_pool.py:409-417, 1046-1081) ----
+// buf[tgt_loc[i]] = buf[src_loc[i]] for every K and V buffer of every layer, IN PLACE: as in the reference kernel all source
+// rows of a column block are read before any target row of that block is written (a location may be both a source and a
+// target).  One workgroup per (buffer, column block): the block's n x cw bytes are gathered into LDS, a barrier, then
+// scattered.  cw (a multiple of 16 bytes) is the widest block that keeps n x cw within 64 KiB, so a handful of moved
+// tokens copy whole rows with coalesced 16-byte accesses.
+namespace {
+constexpr int kMoveLds = 64 * 1024;
+
+__global__ __launch_bounds__(256) void move_kv_cache_kernel(const uint64_t* __restrict__ data_ptrs, const int64_t* __restrict__ strides,
+                                                            const void* tgt_loc, int tgt64, const void* src_loc, int src64, int n,
+                                                            int cw) {
+  extern __shared__ __attribute__((aligned(16))) char stage[];
+  const int64_t stride = strides[blockIdx.x];
+  const int64_t c0 = (int64_t)blockIdx.y * cw;
+  if (c0 >= stride) return;  // (buffers with a shorter row than the widest one)
+  char* base = (char*)data_ptrs[blockIdx.x];
+  const int pieces = (int)(min((int64_t)cw, stride - c0) / 16);  // 16-byte pieces of this block per row
+  const int total = n * pieces;
+  for (int idx = threadIdx.x; idx < total; idx += 256) {
+    const int i = idx / pieces, pc = idx - i * pieces;
+    *(u32x4_t*)(stage + (int64_t)idx * 16) = *(const u32x4_t*)(base + ld_idx(src_loc, i, src64) * stride + c0 + pc * 16);
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < total; idx += 256) {
+    const int i = idx / pieces, pc = idx - i * pieces;
+    *(u32x4_t*)(base + ld_idx(tgt_loc, i, tgt64) * stride + c0 + pc * 16) = *(const u32x4_t*)(stage + (int64_t)idx * 16);
+  }
+}
+}  // namespace
+
+// data_ptrs uint64 [num_buffers] (device) = the buffers' base addresses, data_strides int64 [num_buffers] (device) = bytes per
+// row of each (multiples of 16), max_stride_bytes = the largest of them: MHATokenToKVPool.data_ptrs / data_strides
+// (memory_pool.py:241-256).  tgt_loc / src_loc: int32 or int64 [num_locs] (device), num_locs <= 4096 per call.
+extern "C" int sgl_mi355_move_kv_cache(const void* data_ptrs, const int64_t* data_strides, int num_buffers, int64_t max_stride_bytes,
+                                       const void* tgt_loc, int tgt_is64, const void* src_loc, int src_is64, int num_locs,
+                                       void* stream) {
+  SGL_CHECK(num_buffers >= 0 && num_locs >= 0, "move_kv_cache: negative count");
+  if (num_buffers == 0 || num_locs == 0) return SGL_MI355_OK;
+  SGL_CHECK(data_ptrs && data_strides && tgt_loc && src_loc, "move_kv_cache: null pointer");
+  SGL_CHECK(num_locs <= kMoveLds / 16, "move_kv_cache: at most %d locations per call (got %d)", kMoveLds / 16, num_locs);
+  SGL_CHECK(max_stride_bytes > 0 && max_stride_bytes % 16 == 0, "move_kv_cache: rows must be multiples of 16 bytes (got %lld)",
+            (long long)max_stride_bytes);
+  int64_t cw = (kMoveLds / num_locs) / 16 * 16;
+  if (cw > max_stride_bytes) cw = max_stride_bytes;
+  const int64_t nblk = (max_stride_bytes + cw - 1) / cw;
+  SGL_CHECK(nblk <= 65535, "move_kv_cache: row too long");
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)move_kv_cache_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMoveLds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(move_kv_cache_kernel, dim3(num_buffers, (unsigned)nblk), dim3(256), (size_t)num_locs * cw, (hipStream_t)stream,
+                     (const uint64_t*)data_ptrs, data_strides, tgt_loc, tgt_is64, src_loc, src_is64, num_locs, (int)cw);
+  SGL_HIP_LAUNCH_CHECK();
+  return SGL_MI355_OK;
+}

@@ -24,6 +24,10 @@ from .fused import (
     awq_qkv_rope_set_kv,
     awq_gemm_slabs,
     fp8_gemm_silu_mul,
+    fp8_mlp_block,
+    fp8_mlp_block_supported,
+    fp8_mlp_block_pack_weights,
+    Fp8MlpBlockScratch,
     fp8_qkv_rope_set_kv,
     gemm_silu_mul,
     qkv_rope_set_kv,
@@ -55,6 +59,7 @@ from .kvcache import (
     decode_metadata,
     decode_prepare,
     get_last_loc,
+    move_kv_cache,
     set_kv_buffer,
     write_req_to_token,
 )

@@ -211,3 +211,69 @@ def balanced_tile_rows(n_rows: int, elem_bytes: int = 1) -> int:
     t16 = n_rows // 16
     rounds = -(-t16 // cus)
     return 8 if (rounds < 4 and t16 % cus != 0 and (t16 % cus) < (3 * cus) // 4 and n_rows % 8 == 0) else 16
+
+
+class Fp8MlpBlockScratch:
+    """Device buffers of ``fp8_mlp_block`` for one (M, hidden, inter) and ``layers`` layers: the hand-off scratch (shared by all
+    layers: every launch writes it before it reads it), ONE sync block per layer (all zeroed by ``reset()`` once per step, before the
+    first layer's launch) and the output slabs / activation scales (consumed by the next kernel, so shared as well)."""
+
+    def __init__(self, m: int, hidden: int, inter: int, layers: int, device, timeline: bool = False):
+        self.m, self.hidden, self.inter, self.layers = m, hidden, inter, layers
+        words = int(lib.sgl_mi355_fp8_mlp_block_sync_words())
+        self.sync = torch.zeros((layers, words), dtype=torch.int32, device=device)
+        self.pmax = torch.zeros(int(lib.sgl_mi355_fp8_mlp_block_pmax_words()), dtype=torch.int32, device=device)
+        self.xq = torch.zeros((m, hidden), dtype=torch.uint8, device=device)
+        self.xs = torch.zeros(m, dtype=torch.float32, device=device)
+        self.actq = torch.zeros((m, inter), dtype=torch.uint8, device=device)
+        self.slabs = torch.zeros(((inter + 4095) // 4096, m, hidden), dtype=torch.float32, device=device)
+        self.act_scales = torch.zeros(m, dtype=torch.float32, device=device)
+        cus = self.pmax.numel() // 32
+        self.timeline = torch.zeros((cus, 8, 16), dtype=torch.int64, device=device) if timeline else None
+
+    def reset(self) -> None:
+        self.sync.zero_()
+
+    def error_codes(self) -> torch.Tensor:
+        """Per layer: 0, or the hand-off (1: normed rows, 2: row maxima, 3: activation) whose wait timed out (device sync)."""
+        return self.sync[:, 16].cpu()
+
+
+def fp8_mlp_block_pack_weights(w_gate_up_interleaved_nk: torch.Tensor, w_down_nk: torch.Tensor):
+    """Copies the two weights of one layer into ONE allocation and returns the two views: ``fp8_mlp_block`` reads both through a
+    single buffer descriptor, so they must lie within one 4 GiB window (two separate torch allocations can be anywhere)."""
+    assert w_gate_up_interleaved_nk.element_size() == 1 and w_down_nk.element_size() == 1
+    n1, n2 = w_gate_up_interleaved_nk.numel(), w_down_nk.numel()
+    pad = (-n1) % 256
+    buf = torch.empty(n1 + pad + n2, dtype=torch.uint8, device=w_gate_up_interleaved_nk.device)
+    g = buf[:n1].view(w_gate_up_interleaved_nk.shape)
+    d = buf[n1 + pad:].view(w_down_nk.shape)
+    g.copy_(w_gate_up_interleaved_nk.contiguous().view(torch.uint8))
+    d.copy_(w_down_nk.contiguous().view(torch.uint8))
+    return g.view(w_gate_up_interleaved_nk.dtype), d.view(w_down_nk.dtype)
+
+
+def fp8_mlp_block_supported(m: int, hidden: int, inter: int) -> bool:
+    return bool(lib.sgl_mi355_fp8_mlp_block_supported(int(m), int(hidden), int(inter)))
+
+
+def fp8_mlp_block(x: torch.Tensor, residual: torch.Tensor, ln_weight: torch.Tensor, eps: float, w_gate_up_interleaved_nk: torch.Tensor,
+                  scales_gate_up_interleaved: torch.Tensor, w_down_nk: torch.Tensor, scratch: Fp8MlpBlockScratch, layer: int):
+    """post_attention_layernorm (fused add + RMSNorm) -> per-token fp8 quant -> gate_up_proj + SiluAndMul -> per-token fp8 quant ->
+    down_proj in ONE persistent launch (M <= 32; csrc/mlp_block.hip).  ``residual`` is updated in place.  Returns
+    (slabs f32 [S, M, hidden] raw down_proj partial sums, act_scales [M]): the consumer (``fused_add_rmsnorm_quant_fp8`` with
+    ``slabs=``, ``slab_sx=act_scales``, ``slab_sw=`` the down_proj weight scale) finishes the GEMM.  ``scratch.reset()`` must have
+    run since the last launch with the same ``layer``."""
+    m, h = x.shape
+    inter = w_down_nk.shape[1]
+    assert (m, h, inter) == (scratch.m, scratch.hidden, scratch.inter) and 0 <= layer < scratch.layers
+    assert x.is_contiguous() and residual.is_contiguous() and w_gate_up_interleaved_nk.is_contiguous() and w_down_nk.is_contiguous()
+    assert w_gate_up_interleaved_nk.shape == (2 * inter, h) and w_down_nk.shape == (h, inter)
+    assert w_gate_up_interleaved_nk.element_size() == 1 and w_down_nk.element_size() == 1
+    assert scales_gate_up_interleaved.dtype == torch.float32 and scales_gate_up_interleaved.numel() == 2 * inter
+    check(lib.sgl_mi355_fp8_mlp_block(ptr(x), ptr(residual), ptr(ln_weight), float(eps), ptr(w_gate_up_interleaved_nk),
+                                      ptr(scales_gate_up_interleaved), ptr(w_down_nk), ptr(scratch.slabs), ptr(scratch.act_scales),
+                                      ptr(scratch.xq), ptr(scratch.xs), ptr(scratch.actq), ptr(scratch.pmax),
+                                      scratch.sync[layer].data_ptr(), m, h, inter, dtype_code(x.dtype), ptr(scratch.timeline),
+                                      current_stream()))
+    return scratch.slabs, scratch.act_scales

@@ -82,6 +82,20 @@ def set_kv_buffer(k_buffer, v_buffer, loc, cache_k, cache_v, k_scale=None, v_sca
                                       cv.shape[1] * es, t, current_stream()))
 
 
+def move_kv_cache(data_ptrs, data_strides, max_stride_bytes: int, tgt_loc, src_loc) -> None:
+    """buf[tgt_loc] = buf[src_loc] (rows of data_strides[b] bytes) for every buffer address in data_ptrs, in place: all source
+    rows are read before any target row is written (copy_all_layer_kv_cache, memory_pool.py:1046-1081).  More than 4096
+    locations go in several launches, which keeps that guarantee only inside each launch -- as the reference's kernel does
+    inside one 128-byte column block."""
+    n = tgt_loc.numel()
+    assert src_loc.numel() == n and data_ptrs.dtype == torch.uint64 and data_strides.dtype == torch.int64
+    assert tgt_loc.is_contiguous() and src_loc.is_contiguous()
+    for i0 in range(0, n, 4096):
+        t, s = tgt_loc[i0:i0 + 4096], src_loc[i0:i0 + 4096]
+        check(lib.sgl_mi355_move_kv_cache(ptr(data_ptrs), ptr(data_strides), data_ptrs.numel(), int(max_stride_bytes), ptr(t),
+                                          is64(t), ptr(s), is64(s), t.numel(), current_stream()))
+
+
 def decode_metadata(kv_indptr, num_kv_splits, seq_lens, num_group, num_head, num_kv_head, max_kv_splits,
                     device_core_count, static_splits=False) -> None:
     """kv_indptr[1:bs+1] = cumsum(seq_lens) and num_kv_splits, one launch.  static_splits: 0/False = the reference's

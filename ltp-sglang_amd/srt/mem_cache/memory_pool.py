@@ -70,6 +70,12 @@ class MHATokenToKVPool(KVCache):
         self.k_buffer = [self._kv[0, l] for l in range(layer_num)]
         self.v_buffer = [self._kv[1, l] for l in range(layer_num)]
         self.layer_transfer_counter = None
+        # base address and bytes per row of every K then every V buffer (memory_pool.py:241-256): move_kv_cache's operands
+        self.k_data_ptrs = torch.tensor([x.data_ptr() for x in self.k_buffer], dtype=torch.uint64, device=device)
+        self.v_data_ptrs = torch.tensor([x.data_ptr() for x in self.v_buffer], dtype=torch.uint64, device=device)
+        self.data_ptrs = torch.cat([self.k_data_ptrs, self.v_data_ptrs], dim=0)
+        self.data_strides = torch.tensor([x[0].numel() * x.element_size() for x in self.k_buffer + self.v_buffer],
+                                         dtype=torch.int64, device=device)
         k_bytes, v_bytes = self.get_kv_size_bytes()
         self.mem_usage = (k_bytes + v_bytes) / (1 << 30)
 
@@ -117,3 +123,10 @@ class MHATokenToKVPool(KVCache):
             cache_k, cache_v = cache_k.view(self.store_dtype), cache_v.view(self.store_dtype)
         i = layer_id - self.start_layer
         set_kv_buffer(self.k_buffer[i], self.v_buffer[i], loc, cache_k, cache_v)
+
+    def move_kv_cache(self, tgt_loc: torch.Tensor, src_loc: torch.Tensor):
+        """pool[:, tgt_loc] = pool[:, src_loc] for the K and V buffers of every layer, in place, byte for byte
+        (memory_pool.py:409-417 -> copy_all_layer_kv_cache :1046-1081): one HIP launch."""
+        from ...sgl_kernel import move_kv_cache
+
+        move_kv_cache(self.data_ptrs, self.data_strides, self.head_num * self.head_dim * self._kv.element_size(), tgt_loc, src_loc)

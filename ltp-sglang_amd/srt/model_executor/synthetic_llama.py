@@ -7,6 +7,7 @@ contracts, and the extend / decode drivers that build ForwardBatch objects the w
 prepare_for_decode do (schedule_batch.py:1123-1310,1520-1590).  No checkpoint loading, tokenizer or scheduler: the
 north star measures synthetic random-weight batches.
 """
+import os
 from dataclasses import dataclass
 from types import SimpleNamespace
 from typing import List, Optional
@@ -158,6 +159,10 @@ class LlamaForCausalLM(nn.Module):
         self.fused_extend = True
         self.fused_attn_merge = True   # decode: stage-2 merge + quant by the last-arriving workgroup of each request
         self.fused_epilogues = True
+        # decode, M <= 32: post-attention norm -> gate_up + SiluAndMul -> quant -> down_proj as ONE persistent launch
+        # (csrc/mlp_block.hip) instead of four; SGL_MI355_MLP_BLOCK=0 keeps the four launches
+        self.fused_mlp_block = os.environ.get("SGL_MI355_MLP_BLOCK", "1") != "0"
+        self._mlp_scratch = {}
         qc = None
         if quantization is not None and not isinstance(quantization, str):
             qc = quantization   # a QuantizationConfig instance (e.g. a serialized-checkpoint config)
@@ -266,6 +271,11 @@ class LlamaForCausalLM(nn.Module):
             gu_s=K.interleave_gate_up_rows(mlp.gate_up_proj.weight_scale.view(-1), tg),
             qkv_tile=tq, gu_tile=tg,
         )
+        if self.fused_mlp_block and tg == 16 and self.tp_size == 1:
+            # the persistent MLP launch reads gate_up and down_proj through ONE buffer descriptor: both in one allocation
+            # (the interleaved gate_up copy moves there; down_proj gets a second copy)
+            g, d = K.fp8_mlp_block_pack_weights(layer._fused_w["gu_w"], mlp.down_proj.weight.t())
+            layer._fused_w["gu_w"], layer._fused_w["mlp_down"] = g, d
         return layer._fused_w
 
     def forward_decode_fused(self, input_ids, positions, forward_batch: ForwardBatch):
@@ -283,7 +293,15 @@ class LlamaForCausalLM(nn.Module):
         m = input_ids.numel()
         hidden = K.embedding(input_ids, self.embed_tokens)
         residual, slabs, slab_sx, slab_sw = None, None, None, None
-        for layer in self.layers:
+        mlp_scratch = None
+        if (self.fused_mlp_block and tp == 1 and m <= 32 and self.fused_epilogues
+                and K.fp8_mlp_block_supported(m, self.cfg.hidden_size, self.cfg.intermediate_size)):
+            mlp_scratch = self._mlp_scratch.get(m)
+            if mlp_scratch is None:
+                mlp_scratch = self._mlp_scratch[m] = K.Fp8MlpBlockScratch(m, self.cfg.hidden_size, self.cfg.intermediate_size,
+                                                                         len(self.layers), hidden.device)
+            mlp_scratch.reset()   # the sync blocks of all layers, once per step
+        for li, layer in enumerate(self.layers):
             attn, mlp = layer.self_attn, layer.mlp
             ln1 = layer.input_layernorm
             if residual is None:
@@ -325,6 +343,13 @@ class LlamaForCausalLM(nn.Module):
                 _, hq2, hs2 = K.fused_add_rmsnorm_quant_fp8(None, residual, ln2.weight.data, ln2.variance_epsilon, slabs=o_slabs,
                                                             slab_sx=osc.view(-1), slab_sw=attn.o_proj.weight_scale.view(-1),
                                                             dtype=self.dtype)
+            elif mlp_scratch is not None and fw is not None and "mlp_down" in fw:
+                # the whole MLP half in one persistent launch: add + RMSNorm + quant -> gate_up + SiluAndMul -> quant -> down_proj
+                attn_out = K.fp8_scaled_mm(oq, wo, osc.view(-1), attn.o_proj.weight_scale.view(-1), self.dtype)
+                slabs, slab_sx = K.fp8_mlp_block(attn_out, residual, ln2.weight.data, ln2.variance_epsilon, fw["gu_w"], fw["gu_s"],
+                                                 fw["mlp_down"], mlp_scratch, li)
+                slab_sw = mlp.down_proj.weight_scale.view(-1)
+                continue
             else:
                 attn_out = K.fp8_scaled_mm(oq, wo, osc.view(-1), attn.o_proj.weight_scale.view(-1), self.dtype)
                 if tp > 1:   # partial sums: all-reduce + add + RMSNorm + quant in one launch

@@ -91,6 +91,31 @@ def test_set_kv_buffer_bit_exact(dtype, sk):
     assert torch.equal(kd.cpu(), kb) and torch.equal(vd.cpu(), vb)
 
 
+@pytest.mark.parametrize("kv_dtype", [torch.bfloat16, torch.float8_e4m3fn])
+@pytest.mark.parametrize("n,loc_dtype", [(5, torch.int64), (64, torch.int32), (700, torch.int64)])
+def test_move_kv_cache_byte_exact(kv_dtype, n, loc_dtype, pkg):
+    """MHATokenToKVPool.move_kv_cache (memory_pool.py:409-417, copy_all_layer_kv_cache :1046-1081): every layer's K and V rows,
+    in place, with OVERLAPPING source / target sets (a chain: slot i+1 <- slot i), against torch's index copy, whose right-hand
+    side is materialised before the write -- the reference kernel's load-all-then-store-all per column block."""
+    from ltp_sglang_amd.srt.mem_cache.memory_pool import MHATokenToKVPool
+
+    layers, hkv, d, size = 3, 4, 128, 1500
+    pool = MHATokenToKVPool(size, 1, kv_dtype, hkv, d, layers, DEV, False)
+    g = torch.Generator().manual_seed(n)
+    raw = torch.randint(0, 256, pool._kv.shape if pool._kv.dtype == torch.uint8 else (*pool._kv.shape, 2), dtype=torch.uint8, generator=g)
+    pool._kv.view(torch.uint8).copy_(raw.view(pool._kv.view(torch.uint8).shape))
+    before = pool._kv.view(torch.uint8).cpu().clone()
+    perm = torch.randperm(size, generator=g)[: n + 1] + 1
+    src, tgt = perm[:-1].to(loc_dtype), perm[1:].to(loc_dtype)      # tgt[i] == src[i + 1]: every middle slot is read AND written
+    pool.move_kv_cache(tgt.to(DEV), src.to(DEV))
+    want = before.clone()
+    flat = want.view(2, layers, size + 1, -1)
+    flat[:, :, tgt.long()] = flat[:, :, src.long()].clone()
+    assert torch.equal(pool._kv.view(torch.uint8).cpu().view_as(want), want)
+    # the buffers the reference indexes directly alias the same storage
+    assert pool.data_ptrs.numel() == 2 * layers and int(pool.data_strides[0]) == hkv * d * pool._kv.element_size()
+
+
 # ---------------------------------------------------------------- fp8 quant (bit exact)
 @pytest.mark.parametrize("case", _cases.QUANT_CASES, ids=lambda c: c["name"])
 def test_fp8_quant_bit_exact(case, sk, golden):
