@@ -284,8 +284,13 @@ def main():
                             seq_lens_cpu=sum([s.seq_lens_cpu for s in states], []))
     L, hid, inter, V = cfg.num_hidden_layers, cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size
     hq, hkv, d = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
-    lin_params = L * ((hq * d + 2 * hkv * d) * hid + hq * d * hid + 3 * inter * hid)
-    prefill_flops = 2.0 * lin_params * bs * seq + L * bs * (4.0 * seq * seq * hq * d) / 2 + 2.0 * V * hid * bs
+    # Bytes and FLOPs of what the timed processes execute: per-rank shard figures (heads / columns / rows / vocab divided by tp, kv
+    # heads replicated when there are fewer than tp: llama.py:118-133) times the number of ranks that really ran -- `world` real
+    # ranks, or ONE under --emulate-tp (round 2 divided the unsharded figures by a shard's time there: a "fraction" of 1.96).
+    hq_s, hkv_s = hq // tp, max(1, hkv // tp)
+    ranks_run = 1 if args.emulate_tp > 1 else world
+    lin_params = ranks_run * L * ((hq_s * d + 2 * hkv_s * d) * hid + hq_s * d * hid + 3 * (inter // tp) * hid)
+    prefill_flops = (2.0 * lin_params * bs * seq + ranks_run * (L * bs * (4.0 * seq * seq * hq_s * d) / 2 + 2.0 * (V // tp) * hid * bs))
     next_ids = K_argmax(torch.cat(last_logits))
 
     # ---- decode: W warm-up + K timed steps ----
@@ -360,8 +365,8 @@ def main():
             traffic_src = f"{pmc_rel} (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; FETCH_SIZE x2 on gfx950)"
             traffic_sha = pmc.get("git_sha")
     tok_s = bs * args.steps / elapsed
-    weights_bytes = lin_params * (1 if quant in ("w8a8_fp8", "fp8") else (0.5 if quant == "awq" else 2)) + V * hid * 2
-    step_bytes = weights_bytes + bs * (seq + args.warmup + args.steps / 2) * L * 2 * hkv * d * kv_es
+    weights_bytes = lin_params * (1 if quant in ("w8a8_fp8", "fp8") else (0.5 if quant == "awq" else 2)) + ranks_run * (V // tp) * hid * 2
+    step_bytes = weights_bytes + ranks_run * bs * (seq + args.warmup + args.steps / 2) * L * 2 * hkv_s * d * kv_es
     out = {
         "metric": ("decode tokens/sec (whole job) + prefill TFLOPS, Llama-3-8B fp8 batch=32 seq=2048"
                    if (args.model, args.quant, bs, seq, args.kv_cache_dtype) == ("llama3-8b", "w8a8_fp8", 32, 2048, "auto") else
@@ -379,7 +384,8 @@ def main():
                     "tokens_per_s": bs * seq / prefill_s, "flops": prefill_flops,
                     "requests_per_extend_call": min(bs, args.prefill_chunk)},
         "step_roofline": {"algorithmic_bytes_per_step": step_bytes, "hbm_peak_GBps": 8000.0,
-                          "frac_of_hbm_roofline": step_bytes / (elapsed / args.steps) / (8e12 * world)},
+                          "ranks_counted": ranks_run,
+                          "frac_of_hbm_roofline": step_bytes / (elapsed / args.steps) / (8e12 * ranks_run)},
         "roofline": {"kernel": "decode_attn_stage1", "bound": "hbm", "achieved": achieved, "peak": 8000.0,
                      "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                      "traffic_source": traffic_src, "traffic_profile_git_sha": traffic_sha, "launch_us": attn_ms * 1e3, "algorithmic_bytes_per_launch": kv_bytes},

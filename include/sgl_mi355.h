@@ -211,6 +211,11 @@ int sgl_mi355_skinny_gemm_num_kranges(int M, int N, int K, int in_dtype);
 int sgl_mi355_skinny_gemm_slabs_count(int M, int K);
 int sgl_mi355_skinny_gemm_slabs(const void* x, int64_t x_stride_elems, const void* w, int64_t w_stride_elems, float* slabs,
                                 int M, int N, int K, int in_dtype, void* stream);
+/* The same with at least `min_kranges` k-ranges (shorter K slices per workgroup; for a consumer that sums the slabs anyway:
+ * o_proj's partial sums into the post-attention add + RMSNorm + quant); ..._count_min = the number of slabs written. */
+int sgl_mi355_skinny_gemm_slabs_count_min(int M, int K, int min_kranges);
+int sgl_mi355_skinny_gemm_slabs_min(const void* x, int64_t x_stride_elems, const void* w, int64_t w_stride_elems, float* slabs,
+                                    int M, int N, int K, int in_dtype, int min_kranges, void* stream);
 
 /* Test hook: route every skinny GEMM through the generic (any-K) kernel instead of the X-stationary one. */
 int sgl_mi355_skinny_gemm_force_generic(int on);
@@ -392,13 +397,14 @@ int sgl_mi355_awq_qkv_rope_set_kv(const void* x, int64_t x_stride_elems, const v
  * the [N, K] the GEMMs stream; AWQLinearMethod.apply, layers/quantization/awq.py:401-418) */
 int sgl_mi355_transpose_2d(void* out, const void* in, int rows, int cols, void* stream);
 
-/* ---- one-shot P2P all-reduce over IPC-mapped peer buffers ------------------------------------
+/* ---- P2P all-reduce over IPC-mapped peer buffers (one-shot and two-stage) ----------------------
  * The tensor-parallel all-reduce of the decode path (RowParallelLinear, python/sglang/srt/layers/linear.py:1302-1303 ->
  * GroupCoordinator.all_reduce, distributed/parallel_state.py:480-500, which prefers the custom all-reduce for small
  * messages): sgl-kernel/csrc/allreduce/custom_all_reduce_hip.cuh:261,294,543-549 (one-stage cross-device reduce) and
  * python/sglang/srt/distributed/device_communicators/custom_all_reduce.py (buffer registration over IPC handles).
- * car_alloc: one uncached device allocation per rank (signal block + two data halves of max_bytes) and its 64-byte IPC
- * handle; car_open / car_close: map / unmap a peer's allocation; car_all_reduce: in-place sum over `world` ranks, every
+ * car_alloc: one uncached device allocation per rank (signal block + the data halves of the four kernel families, 16 x
+ * max_bytes: each family -- one-shot plain / gather, one-shot fused, two-stage plain, two-stage fused -- keeps its own flags and
+ * halves because the no-closing-barrier protocol needs ONE packet -> block map per pair of halves) and its 64-byte IPC handle; car_open / car_close: map / unmap a peer's allocation; car_all_reduce: in-place sum over `world` ranks, every
  * rank reads every peer once and adds in rank order with f32 accumulation (bit-identical on all ranks), HIP-graph capturable;
  * car_error: 1 if a peer failed to arrive within the spin bound since the last query (the call's output is then undefined). */
 int sgl_mi355_car_alloc(int64_t max_bytes, void** ptr_out, void* handle_out);
@@ -408,6 +414,13 @@ int sgl_mi355_car_free(void* own_ptr);
 int sgl_mi355_car_error(void* own_ptr);
 int sgl_mi355_car_all_reduce(void* inout, int64_t num_elements, int dtype, const void* const* peer_bufs, int rank, int world,
                              int64_t max_bytes, void* stream);
+/* The same with the algorithm chosen by the caller: algo 0 = the reference's dispatch (custom_all_reduce_hip.cuh:543-549: one
+ * stage at 2 ranks, below 512 KiB at <= 4 ranks, below 256 KiB at <= 8 ranks), 1 = one-shot (cross_device_reduce_1stage, :261),
+ * 2 = two-stage (cross_device_reduce_2stage, :294: every rank sums the 8-KiB chunks it owns -- chunk c belongs to rank c % world --
+ * then collects the other owners' sums; 2 x (world-1)/world of the message come in per rank instead of (world-1) x).  Every rank
+ * must pass the same value.  sgl_mi355_car_all_reduce == algo 0. */
+int sgl_mi355_car_all_reduce_algo(void* inout, int64_t num_elements, int dtype, const void* const* peer_bufs, int rank, int world,
+                                  int64_t max_bytes, int algo, void* stream);
 /* The all-reduce of a row-parallel linear fused with what follows it on the decode path (linear.py:1302-1303 ->
  * layernorm.py:135-171 -> per_token_quant_fp8.cu): x = all_reduce(partial); residual += x; y = rmsnorm(residual) * weight;
  * optional out_norm (T) and out_q / out_s.  Bit-identical to sgl_mi355_car_all_reduce + sgl_mi355_fused_add_rmsnorm_quant_fp8. */
@@ -415,6 +428,12 @@ int sgl_mi355_car_all_reduce_add_rmsnorm_quant(const void* partial, void* residu
                                                void* out_norm, void* out_q, float* out_s, int rows, int hidden, int dtype,
                                                const void* const* peer_bufs, int rank, int world, int64_t max_bytes,
                                                void* stream);
+/* algo as above; in the two-stage form the owner of a row (row % world) finishes it (sum, add, RMSNorm, quant) once and the
+ * other ranks collect the finished row.  hidden % 16 == 0 for the two-stage form (else one-shot); one `hidden` per communicator. */
+int sgl_mi355_car_all_reduce_add_rmsnorm_quant_algo(const void* partial, void* residual, const void* weight, float eps,
+                                                    void* out_norm, void* out_q, float* out_s, int rows, int hidden, int dtype,
+                                                    const void* const* peer_bufs, int rank, int world, int64_t max_bytes,
+                                                    int algo, void* stream);
 /* all-gather along the last dimension with the same buffers and protocol (the logits all-gather of a vocab-sharded lm_head,
  * python/sglang/srt/layers/logits_processor.py:471-500): out [rows, world * row_bytes] <- rank r's in [rows, row_bytes] */
 int sgl_mi355_car_all_gather(const void* in, void* out, int64_t rows, int64_t row_bytes, const void* const* peer_bufs, int rank,

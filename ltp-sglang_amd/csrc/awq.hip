@@ -90,6 +90,9 @@ struct AwqGemmParams {
 #endif
 
 
+#ifndef SGL_AWQ_EXACT_WEIGHTS
+#define SGL_AWQ_EXACT_WEIGHTS 0  // 1 (tools/build_variant.sh): the round-2 per-weight form everywhere (awq_dequantize's rounded weights)
+#endif
 template <int B>
 __device__ __forceinline__ float cvt_ubyte(uint32_t x) {  // float(byte B of x): one VALU op, no shift / mask
   float f;
@@ -146,6 +149,56 @@ struct AwqDequant<__bf16> {
     return __builtin_bit_cast(bf16x8_t, pk);
   }
 };
+
+// (round 3) The offset form, used when one scale group covers a whole 128-k block (SG = 1, G % 128 == 0): the MFMA multiplies X
+// by the RAW nibbles as the floating-point integers 16 + q (one shift + one v_and_or_b32 per two weights: the nibble lands in
+// the mantissa bits of weight 1 of the constant 16.0), accumulates the block in a temporary f32 tile, and the zero point and the
+// scale are applied to that tile:
+//     sum_k x[m,k] (q[k,n] - z) s  =  s * ( sum_k x[m,k] (16 + q[k,n])  -  (16 + z) * sum_k x[m,k] )
+// with the row sums of X per block (X is stationary: computed once per workgroup by an MFMA against a tile of ones).  8 VALU
+// lane-ops per 8 weights + 2 fma per output element and block, against 15 (f16) / 20 (bf16) for the bit-exact per-weight form,
+// which was bound by VALU issue ("int4 dequant GEMM").  The weights this form multiplies by are the EXACT
+// (q - z) * s, not awq_dequantize's values rounded to the scale dtype: closer to exact arithmetic than the reference, no longer
+// bit-identical to dequantise + matmul (parity: the float64 product within the GEMM tolerance; awq_dequantize itself stays
+// bit-exact).  16 rather than the classic 1024 (f16) / 128 (bf16) magic: the f32 tile then holds ~24 x sum|x| instead of ~1040 x,
+// so the subtraction loses one bit, not seven.
+// (No inline asm here: the outputs feed an MFMA directly, and hipcc does not pad the VALU-write -> MFMA-read hazard for an
+// instruction hidden in an asm statement -- the first version returned NaNs.  The two constants are laundered through empty asm
+// statements once per kernel so that they live in an SGPR / a VGPR and `(x & mask) | magic` can become ONE v_and_or_b32.)
+template <typename T>
+struct AwqRaw;
+template <>
+struct AwqRaw<_Float16> {  // 16.0 = 0x4C00: mantissa bits 6..9 have weights 1, 2, 4, 8
+  uint32_t mask, magic;
+  __device__ __forceinline__ void init() {
+    mask = 0x03C003C0u;
+    magic = 0x4C004C00u;
+    asm volatile("" : "+s"(mask));
+    asm volatile("" : "+v"(magic));
+  }
+  __device__ __forceinline__ f16x8_t run(uint32_t wq) const {
+    return __builtin_bit_cast(f16x8_t, u32x4_t{((wq << 6) & mask) | magic, ((wq << 2) & mask) | magic, ((wq >> 2) & mask) | magic,
+                                               ((wq >> 6) & mask) | magic});
+  }
+  static __device__ __forceinline__ f16x8_t ones() { return __builtin_bit_cast(f16x8_t, u32x4_t{0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u}); }
+};
+template <>
+struct AwqRaw<__bf16> {  // 16.0 = 0x4180: mantissa bits 3..6 have weights 1, 2, 4, 8
+  uint32_t mask, magic;
+  __device__ __forceinline__ void init() {
+    mask = 0x00780078u;
+    magic = 0x41804180u;
+    asm volatile("" : "+s"(mask));
+    asm volatile("" : "+v"(magic));
+  }
+  __device__ __forceinline__ bf16x8_t run(uint32_t wq) const {
+    return __builtin_bit_cast(bf16x8_t, u32x4_t{((wq << 3) & mask) | magic, ((wq >> 1) & mask) | magic, ((wq >> 5) & mask) | magic,
+                                                ((wq >> 9) & mask) | magic});
+  }
+  static __device__ __forceinline__ bf16x8_t ones() { return __builtin_bit_cast(bf16x8_t, u32x4_t{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u}); }
+};
+template <typename T>
+__device__ __forceinline__ float awq_scale_f32(uint32_t szw) { return (float)__builtin_bit_cast(T, (uint16_t)(szw & 0xFFFFu)); }
 
 constexpr int kAwqWaves = 8;
 // k-blocks (128 k each) per wave and k-range: 4 (a k-range = 4096 k) while the X fragments of 32 rows fit the register budget,
@@ -206,6 +259,27 @@ __global__ __launch_bounds__(kAwqWaves * 64, 1) void awq_gemm_kernel(const AwqGe
     }
   }
 
+  // offset form: row sums of X over each of this wave's k-blocks (rows 16 mt + 4 g + r of the MFMA output, every column alike)
+  constexpr bool OFFS = (SG == 1) && (SGL_AWQ_EXACT_WEIGHTS == 0);
+  AwqRaw<T> raw;
+  raw.init();
+  // (kept in LDS, 512 bytes per wave, read back as one broadcast ds_read_b128 per block: in registers they were 32 VGPRs too
+  // many for the 256-register budget of two waves per SIMD)
+  __shared__ f32x4_t xsum_l[OFFS ? kAwqWaves : 1][OFFS ? MT : 1][OFFS ? kAwqBpw : 1][4];
+  if constexpr (OFFS) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int bi = 0; bi < kAwqBpw; ++bi) {
+        f32x4_t t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) t = Tr::mfma16(xf[mt][bi][s], AwqRaw<T>::ones(), t);
+        if (a == 0) xsum_l[w][mt][bi][g] = t;
+      }
+    // A barrier, although the data is wave private: the stores sit under a lane condition, and without it hipcc moved the loads
+    // of the lanes that do not store ahead of the store instruction (NaNs in the single-tile instantiation).
+    __syncthreads();
+  }
   AWQ_STAMP(1);  // X fragments built
   const int64_t wbytes64 = (int64_t)(p.N / 16) * p.KB * 1024;
   const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.qpacked, 0, (unsigned)min(wbytes64, (int64_t)0xFFFFFFF0ll), 0x00020000);
@@ -260,13 +334,34 @@ __global__ __launch_bounds__(kAwqWaves * 64, 1) void awq_gemm_kernel(const AwqGe
 #pragma unroll
       for (int bi = 0; bi < kAwqBpw; ++bi) {
         const u32x4_t wq = wreg[slot][bi];
-        AwqDequant<T> dq;
+        if constexpr (OFFS) {
+          f32x4_t tmp[MT];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          if (s % (4 / SG) == 0) dq.setup(szreg[slot][bi][(s * SG) / 4]);
-          const vec8 wfrag = dq.run(wq[s]);
+          for (int mt = 0; mt < MT; ++mt) tmp[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) acc[mt] = Tr::mfma16(xf[mt][bi][s], wfrag, acc[mt]);
+          for (int s = 0; s < 4; ++s) {
+            const vec8 wfrag = raw.run(wq[s]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) tmp[mt] = Tr::mfma16(xf[mt][bi][s], wfrag, tmp[mt]);
+          }
+          const uint32_t szw = szreg[slot][bi][0];
+          const float sf = awq_scale_f32<T>(szw), nzc = -(float)(16u + (szw >> 16));
+          f32x4_t xs[MT];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) xs[mt] = xsum_l[w][mt][bi][g];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[mt][r] = fmaf(fmaf(nzc, xs[mt][r], tmp[mt][r]), sf, acc[mt][r]);
+        } else {
+          AwqDequant<T> dq;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            if (s % (4 / SG) == 0) dq.setup(szreg[slot][bi][(s * SG) / 4]);
+            const vec8 wfrag = dq.run(wq[s]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = Tr::mfma16(xf[mt][bi][s], wfrag, acc[mt]);
+          }
         }
       }
       if constexpr (TPP > 1) issue(slot, j + PD);

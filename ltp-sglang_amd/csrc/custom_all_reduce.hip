@@ -23,6 +23,19 @@
 //  * every spin is bounded: a peer that never arrives sets the signal block's error word instead of hanging the GPU.
 //  * block b of every rank copies and reduces the SAME element range, so a block only ever reads data that the matching block
 //    of a peer published before raising the flag it waits on.
+//  * (round 3) that argument needs the packet -> block map to be the SAME in every call that shares a pair of halves: block b may
+//    re-enter a half only because the peers' blocks b have left it.  The plain / all-gather kernel maps packet i to block
+//    (i / 512) % 64, the fused kernels map row r to a block, the two-stage kernels map 8-KiB chunks to (owner, block): each of
+//    these four FAMILIES therefore has its own flags, epochs and data halves (a mixed sequence -- one decode step at batch 1, the
+//    next at batch 32, hidden 8192 -- could otherwise overwrite rows a lagging peer's other block is still reading).
+//
+// Two-stage form (reduce-scatter + all-gather; custom_all_reduce_hip.cuh:294 cross_device_reduce_2stage, dispatch :543-549: at 8
+// ranks the reference leaves the one-stage kernel at 256 KiB): every rank sums only the chunks it owns (owner of 8-KiB chunk c =
+// c % world -- a map that does not depend on the message size) from the peers' published operands, publishes those sums, and
+// after a second flag round every rank collects the other owners' sums: 2 x 7/8 of the message come in per rank instead of
+// 7 x, and every element is summed ONCE (in rank order), so all ranks hold the same bits.  The fused form gives ROWS to owners
+// (owner of row r = r % world): the owner finishes the row -- sum, residual add, RMSNorm, per-token quant -- and the others
+// collect the finished row (residual, normed, fp8 + scale) instead of the sum, so the row arithmetic also runs once.
 #include "row_helpers.h"
 
 namespace {
@@ -32,11 +45,20 @@ constexpr int kMaxBlocks = 64;
 constexpr int kThreads = 512;
 constexpr uint32_t kSpinLimit = 1u << 26;  // polls of ~64 ns each: a few seconds, then give up
 
-struct alignas(128) CarSignal {
-  uint32_t flag[kMaxBlocks][kMaxRanks];  // written by the peers: flag[b][r] = last epoch rank r's block b has published
-  uint32_t epoch[kMaxBlocks];            // own counter per block
-  uint32_t error;                        // set when a spin ran out
+constexpr int kFamilies = 4;  // 0: one-shot plain + all-gather, 1: one-shot fused, 2: two-stage plain, 3: two-stage fused
+enum { FAM_PLAIN = 0, FAM_FUSED = 1, FAM_2S = 2, FAM_2S_FUSED = 3 };
+struct alignas(256) CarSignal {
+  uint32_t flag[kFamilies][kMaxBlocks][kMaxRanks];  // written by the peers: flag[f][b][r] = last epoch rank r's block b has published
+  uint32_t epoch[kFamilies][kMaxBlocks];            // own counter per family and block
+  uint32_t error;                                   // set when a spin ran out
 };
+// Data layout behind the signal block, in units of max_bytes (H): family 0: 2 halves; 1: 2; 2: 2 operand halves + 2 result halves;
+// 3: 2 operand halves + 2 result halves of 3 H (a finished row = residual + normed + fp8 + scale: at most 5 h + 16 <= 6 h bytes).
+constexpr int kDataUnits = 2 + 2 + 4 + 2 + 6;
+__host__ __device__ inline int64_t fam_off(int fam, int64_t H) {
+  const int64_t units = fam == FAM_PLAIN ? 0 : fam == FAM_FUSED ? 2 : fam == FAM_2S ? 4 : 8;
+  return (int64_t)sizeof(CarSignal) + units * H;
+}
 
 struct CarParams {
   char* buf[kMaxRanks];       // each rank's allocation (signal block first)
@@ -45,9 +67,33 @@ struct CarParams {
   int64_t row16;              // all-gather: 16-byte packets per input row
   int64_t n16;                // 16-byte packets
   int64_t half_bytes;
-  int64_t data_off;           // offset of the first data half inside an allocation
+  int64_t data_off;           // offset of the family's first data half inside an allocation
   int rank, world;
 };
+
+// One flag round of family `fam`, block b: lane r raises flag[fam][b][rank] = epoch at peer r, then waits for peer r's flag here.
+// Returns false (and sets the error word) if a peer never arrived.  `failed`: an int in LDS.
+__device__ __forceinline__ bool flag_round(char* const* buf, int rank, int world, int fam, int b, uint32_t epoch, int tid, int* failed) {
+  CarSignal* me = (CarSignal*)buf[rank];
+  if (tid == 0) *failed = 0;
+  __syncthreads();
+  if (tid < world) {
+    CarSignal* peer = (CarSignal*)buf[tid];
+    __hip_atomic_store(&peer->flag[fam][b][rank], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    uint32_t spins = 0;
+    // (epochs only grow; "< epoch" tolerates a peer that is already one round ahead)
+    while ((int32_t)(__hip_atomic_load(&me->flag[fam][b][tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > kSpinLimit) {
+        *failed = 1;
+        me->error = 1u;
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  return *failed == 0;
+}
 
 template <typename T>
 __device__ __forceinline__ void accumulate(float (&acc)[8], const u32x4_t& v) {
@@ -94,7 +140,7 @@ template <typename T>
 __global__ __launch_bounds__(kThreads) void one_shot_all_reduce_kernel(const CarParams p) {
   const int b = blockIdx.x, tid = threadIdx.x;
   CarSignal* me = (CarSignal*)p.buf[p.rank];
-  const uint32_t epoch = me->epoch[b] + 1;
+  const uint32_t epoch = me->epoch[FAM_PLAIN][b] + 1;
   const int64_t half = p.data_off + (int64_t)(epoch & 1u) * p.half_bytes;
   const int64_t stride = (int64_t)gridDim.x * kThreads;
   // 1. publish this rank's operand in its own (uncached) half
@@ -104,24 +150,8 @@ __global__ __launch_bounds__(kThreads) void one_shot_all_reduce_kernel(const Car
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   // 2. one lane per peer: raise my flag there, then wait for that peer's flag here
-  __shared__ int failed;
-  if (tid == 0) failed = 0;
-  __syncthreads();
-  if (tid < p.world) {
-    CarSignal* peer = (CarSignal*)p.buf[tid];
-    __hip_atomic_store(&peer->flag[b][p.rank], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    uint32_t spins = 0;
-    // (epochs only grow; "< epoch" tolerates a peer that is already one call ahead)
-    while ((int32_t)(__hip_atomic_load(&me->flag[b][tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
-      __builtin_amdgcn_s_sleep(2);
-      if (++spins > kSpinLimit) {
-        failed = 1;
-        me->error = 1u;
-        break;
-      }
-    }
-  }
-  __syncthreads();
+  __shared__ int failed_lds;
+  const bool failed = !flag_round(p.buf, p.rank, p.world, FAM_PLAIN, b, epoch, tid, &failed_lds);
   // 3a. all-gather along the last dimension: out[row][r * row_bytes + ...] = rank r's input row
   if (!failed && p.gather_out != nullptr) {
     for (int64_t i = (int64_t)b * kThreads + tid; i < p.n16; i += stride) {
@@ -141,7 +171,7 @@ __global__ __launch_bounds__(kThreads) void one_shot_all_reduce_kernel(const Car
     }
   }
   __syncthreads();
-  if (tid == 0) me->epoch[b] = epoch;
+  if (tid == 0) me->epoch[FAM_PLAIN][b] = epoch;
 }
 
 // All-reduce fused with the op sequence that follows it on the decode path (linear.py:1302-1303 -> layernorm.py:135-171 ->
@@ -167,10 +197,10 @@ struct CarNormParams {
 template <typename T, int MAXV>
 __global__ __launch_bounds__(256) void all_reduce_add_rmsnorm_quant_kernel(const CarNormParams p) {
   __shared__ float red[4];
-  __shared__ int failed;
+  __shared__ int failed_lds;
   const int b = blockIdx.x, tid = threadIdx.x;
   CarSignal* me = (CarSignal*)p.buf[p.rank];
-  const uint32_t epoch = me->epoch[b] + 1;
+  const uint32_t epoch = me->epoch[FAM_FUSED][b] + 1;
   const int64_t half = p.data_off + (int64_t)(epoch & 1u) * p.half_bytes;
   const int nvec = p.hidden / 8;
   // 1. publish this rank's rows b, b + grid, ...
@@ -182,22 +212,8 @@ __global__ __launch_bounds__(256) void all_reduce_add_rmsnorm_quant_kernel(const
     }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (tid == 0) failed = 0;
   __syncthreads();
-  if (tid < p.world) {
-    CarSignal* peer = (CarSignal*)p.buf[tid];
-    __hip_atomic_store(&peer->flag[b][p.rank], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    uint32_t spins = 0;
-    while ((int32_t)(__hip_atomic_load(&me->flag[b][tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
-      __builtin_amdgcn_s_sleep(2);
-      if (++spins > kSpinLimit) {
-        failed = 1;
-        me->error = 1u;
-        break;
-      }
-    }
-  }
-  __syncthreads();
+  const bool failed = !flag_round(p.buf, p.rank, p.world, FAM_FUSED, b, epoch, tid, &failed_lds);
   if (!failed) {
     for (int row = b; row < p.rows; row += gridDim.x) {
       // operands first (norm weight, residual, every peer's packet), then the arithmetic of the two unfused kernels
@@ -229,7 +245,7 @@ __global__ __launch_bounds__(256) void all_reduce_add_rmsnorm_quant_kernel(const
             st8((T*)p.residual + (int64_t)row * p.hidden + i * 8, ro);
           }
 #pragma unroll
-          for (int j = 0; j < 8; ++j) ss += vals[it][j] * vals[it][j];
+          for (int j = 0; j < 8; ++j) ss = fmaf(vals[it][j], vals[it][j], ss);  // (explicit: a contraction hipcc may or may not make per kernel)
         }
       }
       const float var = block_sum(ss, red) / (float)p.hidden;
@@ -252,16 +268,213 @@ __global__ __launch_bounds__(256) void all_reduce_add_rmsnorm_quant_kernel(const
     }
   }
   __syncthreads();
-  if (tid == 0) me->epoch[b] = epoch;
+  if (tid == 0) me->epoch[FAM_FUSED][b] = epoch;
+}
+
+// ---- two-stage all-reduce (reduce-scatter + all-gather), see the header ----
+constexpr int kChunk = kThreads;  // packets per chunk = one block iteration (8 KiB)
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void two_stage_all_reduce_kernel(const CarParams p) {
+  __shared__ int failed_lds;
+  const int b = blockIdx.x, tid = threadIdx.x, G = gridDim.x, W = p.world;
+  CarSignal* me = (CarSignal*)p.buf[p.rank];
+  const uint32_t e0 = me->epoch[FAM_2S][b];
+  const int64_t par = (int64_t)((e0 >> 1) & 1u);
+  const int64_t in_half = p.data_off + par * p.half_bytes, res_half = p.data_off + (2 + par) * p.half_bytes;
+  const int64_t nchunks = (p.n16 + kChunk - 1) / kChunk, nq = (nchunks + W - 1) / W;  // chunk c = q * W + owner
+  // 1. publish this rank's whole operand (every owner will read its own chunks of it)
+  for (int64_t q = b; q < nq; q += G)
+    for (int r = 0; r < W; ++r) {
+      const int64_t i = (q * W + r) * kChunk + tid;
+      if (i < p.n16) store_sys(p.buf[p.rank], in_half + i * 16, ((const u32x4_t*)p.inout)[i]);
+    }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  bool ok = flag_round(p.buf, p.rank, W, FAM_2S, b, e0 + 1, tid, &failed_lds);
+  // 2. reduce-scatter: the chunks this rank owns, summed in rank order, published in the result half
+  if (ok) {
+    for (int64_t q = b; q < nq; q += G) {
+      const int64_t i = (q * W + p.rank) * kChunk + tid;
+      if (i < p.n16) {
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < W; ++r) accumulate<T>(acc, load_sys(p.buf[r], in_half + i * 16));
+        store_sys(p.buf[p.rank], res_half + i * 16, pack<T>(acc));
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  ok = flag_round(p.buf, p.rank, W, FAM_2S, b, e0 + 2, tid, &failed_lds) && ok;
+  // 3. all-gather: every owner's sums (its own included: the same bits everywhere)
+  if (ok) {
+    for (int64_t q = b; q < nq; q += G)
+      for (int r = 0; r < W; ++r) {
+        const int64_t i = (q * W + r) * kChunk + tid;
+        if (i < p.n16) ((u32x4_t*)p.inout)[i] = load_sys(p.buf[r], res_half + i * 16);
+      }
+  }
+  __syncthreads();
+  if (tid == 0) me->epoch[FAM_2S][b] = e0 + 2;
+}
+
+// Two-stage form of all_reduce_add_rmsnorm_quant_kernel: the owner of a row (row % world) sums it, adds the residual, normalises
+// and quantises it ONCE and publishes the finished row; the other ranks collect it.  Record of a finished row in the result
+// half: [residual T x h | normed T x h | fp8 x h | scale f32, padded to 16 bytes].  Same arithmetic as the one-shot fused kernel
+// on the owner, so bit-identical to it and to the unfused pair.
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256) void two_stage_all_reduce_add_rmsnorm_quant_kernel(const CarNormParams p) {
+  __shared__ float red[4];
+  __shared__ int failed_lds;
+  const int b = blockIdx.x, tid = threadIdx.x, G = gridDim.x, W = p.world;
+  CarSignal* me = (CarSignal*)p.buf[p.rank];
+  const uint32_t e0 = me->epoch[FAM_2S_FUSED][b];
+  const int64_t par = (int64_t)((e0 >> 1) & 1u);
+  const int64_t in_half = p.data_off + par * p.half_bytes, res_half = p.data_off + 2 * p.half_bytes + par * 3 * p.half_bytes;
+  const int nvec = p.hidden / 8;
+  const int64_t rec = (int64_t)p.hidden * 5 + 16;  // bytes of a finished row's record
+  const int nq = (p.rows + W - 1) / W;               // row = q * W + owner
+  // 1. publish this rank's partial rows
+  for (int q = b; q < nq; q += G)
+    for (int r = 0; r < W; ++r) {
+      const int row = q * W + r;
+      if (row < p.rows) {
+#pragma unroll
+        for (int it = 0; it < MAXV; ++it) {
+          const int i = tid + it * 256;
+          if (i < nvec) store_sys(p.buf[p.rank], in_half + ((int64_t)row * nvec + i) * 16, *((const u32x4_t*)p.partial + (int64_t)row * nvec + i));
+        }
+      }
+    }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  bool ok = flag_round(p.buf, p.rank, W, FAM_2S_FUSED, b, e0 + 1, tid, &failed_lds);
+  // 2. the rows this rank owns: all-reduce, add, RMSNorm, quant (add_rmsnorm_quant_kernel's arithmetic), local outputs + record
+  if (ok) {
+    for (int q = b; q < nq; q += G) {
+      const int row = q * W + p.rank;
+      if (row >= p.rows) continue;  // (block-uniform)
+      char* recp = p.buf[p.rank] + res_half + (int64_t)row * rec;
+      V8<T> wreg[MAXV], rreg[MAXV];
+      float vals[MAXV][8];
+      float ss = 0.f;
+#pragma unroll
+      for (int it = 0; it < MAXV; ++it) {
+        const int i = tid + it * 256;
+        const int ic = i < nvec ? i : 0;
+        wreg[it] = ld8((const T*)p.weight + ic * 8);
+        if (p.residual) rreg[it] = ld8((const T*)p.residual + (int64_t)row * p.hidden + ic * 8);
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < W; ++r) accumulate<T>(acc, load_sys(p.buf[r], in_half + ((int64_t)row * nvec + ic) * 16));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) vals[it][j] = round_via<T>(acc[j]);   // = the all-reduce's output element
+      }
+#pragma unroll
+      for (int it = 0; it < MAXV; ++it) {
+        const int i = tid + it * 256;
+        if (i < nvec) {
+          V8<T> ro;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            if (p.residual) vals[it][j] += (float)rreg[it].v[j];
+            ro.v[j] = (T)vals[it][j];
+          }
+          if (p.residual) st8((T*)p.residual + (int64_t)row * p.hidden + i * 8, ro);
+          store_sys(recp, (int64_t)i * 16, __builtin_bit_cast(u32x4_t, ro));
+#pragma unroll
+          for (int j = 0; j < 8; ++j) ss = fmaf(vals[it][j], vals[it][j], ss);  // (explicit: a contraction hipcc may or may not make per kernel)
+        }
+      }
+      const float var = block_sum(ss, red) / (float)p.hidden;
+      const float rs = 1.0f / sqrtf(var + p.eps);
+      float amax = 0.f;
+#pragma unroll
+      for (int it = 0; it < MAXV; ++it) {
+        const int i = tid + it * 256;
+        if (i < nvec) {
+          V8<T> o;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            vals[it][j] = round_via<T>((vals[it][j] * rs) * (float)wreg[it].v[j]);
+            o.v[j] = (T)vals[it][j];
+            amax = fmaxf(amax, fabsf(vals[it][j]));
+          }
+          if (p.out_norm) st8((T*)p.out_norm + (int64_t)row * p.hidden + i * 8, o);
+          store_sys(recp, (int64_t)p.hidden * 2 + (int64_t)i * 16, __builtin_bit_cast(u32x4_t, o));
+        }
+      }
+      // per-token quant (quant_row's arithmetic), 16 fp8 bytes per store: threads pair up
+      amax = block_max(amax, red);
+      const float scale = amax / kFp8Max;
+      const float inv = (scale == 0.f) ? 0.f : 1.0f / scale;
+#pragma unroll
+      for (int it = 0; it < MAXV; ++it) {
+        const int i = tid + it * 256;
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = clamp448(vals[it][j] * inv);
+        const u32x2_t qv = pack8_fp8(f);
+        if (i < nvec) {
+          if (p.out_q) *(u32x2_t*)(p.out_q + (int64_t)row * p.hidden + i * 8) = qv;
+          __hip_atomic_store((unsigned long long*)(recp + (int64_t)p.hidden * 4 + (int64_t)i * 8), ((unsigned long long)qv[1] << 32) | qv[0],
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
+      if (tid == 0) {
+        if (p.out_s) p.out_s[row] = scale;
+        __hip_atomic_store((uint32_t*)(recp + (int64_t)p.hidden * 5), __builtin_bit_cast(uint32_t, scale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      __syncthreads();   // red is reused by the next row
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  ok = flag_round(p.buf, p.rank, W, FAM_2S_FUSED, b, e0 + 2, tid, &failed_lds) && ok;
+  // 3. collect the other owners' finished rows
+  if (ok) {
+    for (int q = b; q < nq; q += G)
+      for (int r = 0; r < W; ++r) {
+        const int row = q * W + r;
+        if (r == p.rank || row >= p.rows) continue;
+        const char* recp = p.buf[r] + res_half + (int64_t)row * rec;
+#pragma unroll
+        for (int it = 0; it < MAXV; ++it) {
+          const int i = tid + it * 256;
+          if (i < nvec) {
+            if (p.residual) *((u32x4_t*)p.residual + (int64_t)row * nvec + i) = load_sys(recp, (int64_t)i * 16);
+            if (p.out_norm) *((u32x4_t*)p.out_norm + (int64_t)row * nvec + i) = load_sys(recp, (int64_t)p.hidden * 2 + (int64_t)i * 16);
+          }
+        }
+        if (p.out_q) {
+          for (int i = tid; i < p.hidden / 16; i += 256)
+            *((u32x4_t*)(p.out_q + (int64_t)row * p.hidden) + i) = load_sys(recp, (int64_t)p.hidden * 4 + (int64_t)i * 16);
+          if (tid == 0)
+            p.out_s[row] = __builtin_bit_cast(float, __hip_atomic_load((const uint32_t*)(recp + (int64_t)p.hidden * 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+        }
+      }
+  }
+  __syncthreads();
+  if (tid == 0) me->epoch[FAM_2S_FUSED][b] = e0 + 2;
+}
+
+// custom_all_reduce_hip.cuh:543-549: two ranks always take the one-stage kernel; up to 4 ranks below 512 KiB; up to 8 below 256 KiB
+inline bool use_two_stage(int world, int64_t bytes) {
+  if (world <= 2) return false;
+  if (world <= 4) return bytes >= 512 * 1024;
+  return bytes >= 256 * 1024;
 }
 
 }  // namespace
 
-// Allocates a rank's uncached buffer (signal block + two data halves of max_bytes each), zeroes the signal block and
-// returns its 64-byte IPC handle.
+// Allocates a rank's uncached buffer (signal block + the data halves of the four kernel families: 16 x max_bytes), zeroes the
+// signal block and returns its 64-byte IPC handle.
 extern "C" int sgl_mi355_car_alloc(int64_t max_bytes, void** ptr_out, void* handle_out) {
   SGL_CHECK(max_bytes > 0 && max_bytes % 16 == 0 && ptr_out && handle_out, "car_alloc: bad arguments");
-  const size_t total = sizeof(CarSignal) + 2 * (size_t)max_bytes;
+  const size_t total = sizeof(CarSignal) + (size_t)kDataUnits * (size_t)max_bytes;
   void* ptr = nullptr;
   hipError_t e = hipExtMallocWithFlags(&ptr, total, hipDeviceMallocUncached);
   SGL_CHECK(e == hipSuccess, "car_alloc: hipExtMallocWithFlags(%zu, uncached) failed: %s", total, hipGetErrorString(e));
@@ -313,9 +526,12 @@ extern "C" int sgl_mi355_car_error(void* own_ptr) {
 // In-place sum of `inout` (num_elements of dtype bf16 / f16 / f32, 16-byte aligned, byte count a multiple of 16 and at most
 // the max_bytes of car_alloc) over the `world` ranks whose allocations are peer_bufs[0 .. world) (this rank's own pointer at
 // [rank], the others as returned by car_open).  Every rank must call with the same size, in the same order.
-extern "C" int sgl_mi355_car_all_reduce(void* inout, int64_t num_elements, int dtype, const void* const* peer_bufs, int rank,
-                                        int world, int64_t max_bytes, void* stream) {
+// algo: 0 = the reference's dispatch rule (custom_all_reduce_hip.cuh:543-549: one stage below 512 KiB at <= 4 ranks / 256 KiB at
+// <= 8 ranks, always at 2), 1 = one-shot, 2 = two-stage (reduce-scatter + all-gather).  All ranks must pass the same value.
+extern "C" int sgl_mi355_car_all_reduce_algo(void* inout, int64_t num_elements, int dtype, const void* const* peer_bufs, int rank,
+                                             int world, int64_t max_bytes, int algo, void* stream) {
   SGL_CHECK(inout && peer_bufs, "car_all_reduce: null pointer");
+  SGL_CHECK(algo >= 0 && algo <= 2, "car_all_reduce: algo %d (0 = rule, 1 = one-shot, 2 = two-stage)", algo);
   SGL_CHECK(world >= 2 && world <= kMaxRanks && rank >= 0 && rank < world, "car_all_reduce: rank %d / world %d unsupported", rank, world);
   SGL_CHECK(dtype == SGL_BF16 || dtype == SGL_F16 || dtype == SGL_F32, "car_all_reduce: dtype code %d unsupported", dtype);
   const int64_t bytes = num_elements * (dtype == SGL_F32 ? 4 : 2);
@@ -328,18 +544,34 @@ extern "C" int sgl_mi355_car_all_reduce(void* inout, int64_t num_elements, int d
   p.row16 = 1;
   p.n16 = bytes / 16;
   p.half_bytes = max_bytes;
-  p.data_off = (int64_t)sizeof(CarSignal);
   p.rank = rank;
   p.world = world;
-  // the grid is a function of the size only: every rank launches the same number of blocks
-  const int64_t want = (p.n16 + kThreads - 1) / kThreads;
-  const unsigned blocks = (unsigned)(want < 1 ? 1 : (want > kMaxBlocks ? kMaxBlocks : want));
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == SGL_BF16) hipLaunchKernelGGL((one_shot_all_reduce_kernel<__bf16>), dim3(blocks), dim3(kThreads), 0, st, p);
-  else if (dtype == SGL_F16) hipLaunchKernelGGL((one_shot_all_reduce_kernel<_Float16>), dim3(blocks), dim3(kThreads), 0, st, p);
-  else hipLaunchKernelGGL((one_shot_all_reduce_kernel<float>), dim3(blocks), dim3(kThreads), 0, st, p);
+  const bool two = algo == 2 || (algo == 0 && use_two_stage(world, bytes));
+  if (two) {
+    p.data_off = fam_off(FAM_2S, max_bytes);
+    // chunk c = q * world + owner; block = q % grid: the grid is a function of the size only, the same on every rank
+    const int64_t nq = ((p.n16 + kChunk - 1) / kChunk + world - 1) / world;
+    const unsigned blocks = (unsigned)(nq < 1 ? 1 : (nq > kMaxBlocks ? kMaxBlocks : nq));
+    if (dtype == SGL_BF16) hipLaunchKernelGGL((two_stage_all_reduce_kernel<__bf16>), dim3(blocks), dim3(kThreads), 0, st, p);
+    else if (dtype == SGL_F16) hipLaunchKernelGGL((two_stage_all_reduce_kernel<_Float16>), dim3(blocks), dim3(kThreads), 0, st, p);
+    else hipLaunchKernelGGL((two_stage_all_reduce_kernel<float>), dim3(blocks), dim3(kThreads), 0, st, p);
+  } else {
+    p.data_off = fam_off(FAM_PLAIN, max_bytes);
+    // the grid is a function of the size only: every rank launches the same number of blocks
+    const int64_t want = (p.n16 + kThreads - 1) / kThreads;
+    const unsigned blocks = (unsigned)(want < 1 ? 1 : (want > kMaxBlocks ? kMaxBlocks : want));
+    if (dtype == SGL_BF16) hipLaunchKernelGGL((one_shot_all_reduce_kernel<__bf16>), dim3(blocks), dim3(kThreads), 0, st, p);
+    else if (dtype == SGL_F16) hipLaunchKernelGGL((one_shot_all_reduce_kernel<_Float16>), dim3(blocks), dim3(kThreads), 0, st, p);
+    else hipLaunchKernelGGL((one_shot_all_reduce_kernel<float>), dim3(blocks), dim3(kThreads), 0, st, p);
+  }
   SGL_HIP_LAUNCH_CHECK();
   return SGL_MI355_OK;
+}
+
+extern "C" int sgl_mi355_car_all_reduce(void* inout, int64_t num_elements, int dtype, const void* const* peer_bufs, int rank,
+                                        int world, int64_t max_bytes, void* stream) {
+  return sgl_mi355_car_all_reduce_algo(inout, num_elements, dtype, peer_bufs, rank, world, max_bytes, 0, stream);
 }
 
 // All-gather along the last dimension through the same buffers and protocol: out [rows, world * row_bytes] receives rank r's
@@ -360,7 +592,7 @@ extern "C" int sgl_mi355_car_all_gather(const void* in, void* out, int64_t rows,
   p.row16 = row_bytes / 16;
   p.n16 = bytes / 16;
   p.half_bytes = max_bytes;
-  p.data_off = (int64_t)sizeof(CarSignal);
+  p.data_off = fam_off(FAM_PLAIN, max_bytes);
   p.rank = rank;
   p.world = world;
   const int64_t want = (p.n16 + kThreads - 1) / kThreads;
@@ -374,11 +606,14 @@ extern "C" int sgl_mi355_car_all_gather(const void* in, void* out, int64_t rows,
 // out_norm (T) and out_q / out_s (per-token e4m3 + f32 scale): sgl_mi355_car_all_reduce followed by
 // sgl_mi355_fused_add_rmsnorm_quant_fp8 in one launch, bit-identical to that pair.  rows * hidden * 2 <= max_bytes,
 // hidden % 8 == 0, hidden <= 8192.
-extern "C" int sgl_mi355_car_all_reduce_add_rmsnorm_quant(const void* partial, void* residual, const void* weight, float eps,
-                                                          void* out_norm, void* out_q, float* out_s, int rows, int hidden,
-                                                          int dtype, const void* const* peer_bufs, int rank, int world,
-                                                          int64_t max_bytes, void* stream) {
+// algo as for sgl_mi355_car_all_reduce_algo (two-stage needs hidden % 16 == 0, else the one-shot form is taken).  On one
+// communicator every fused call must use the same `hidden` (the row -> block map of the no-closing-barrier protocol).
+extern "C" int sgl_mi355_car_all_reduce_add_rmsnorm_quant_algo(const void* partial, void* residual, const void* weight, float eps,
+                                                               void* out_norm, void* out_q, float* out_s, int rows, int hidden,
+                                                               int dtype, const void* const* peer_bufs, int rank, int world,
+                                                               int64_t max_bytes, int algo, void* stream) {
   SGL_CHECK(partial && weight && peer_bufs && (out_norm || out_q) && (!out_q || out_s), "car_all_reduce_add_rmsnorm_quant: null pointer");
+  SGL_CHECK(algo >= 0 && algo <= 2, "car_all_reduce_add_rmsnorm_quant: algo %d (0 = rule, 1 = one-shot, 2 = two-stage)", algo);
   SGL_CHECK(world >= 2 && world <= kMaxRanks && rank >= 0 && rank < world, "car_all_reduce_add_rmsnorm_quant: rank %d / world %d unsupported", rank, world);
   SGL_CHECK(dtype == SGL_BF16 || dtype == SGL_F16, "car_all_reduce_add_rmsnorm_quant: dtype must be bf16 or f16");
   SGL_CHECK(rows > 0 && hidden > 0 && hidden % 8 == 0 && hidden <= 8192 && (int64_t)rows * hidden * 2 <= max_bytes &&
@@ -388,17 +623,40 @@ extern "C" int sgl_mi355_car_all_reduce_add_rmsnorm_quant(const void* partial, v
   CarNormParams p;
   for (int r = 0; r < kMaxRanks; ++r) p.buf[r] = (char*)(r < world ? peer_bufs[r] : peer_bufs[0]);
   p.partial = partial; p.residual = residual; p.weight = weight; p.out_norm = out_norm; p.out_q = (uint8_t*)out_q; p.out_s = out_s;
-  p.half_bytes = max_bytes; p.data_off = (int64_t)sizeof(CarSignal);
+  p.half_bytes = max_bytes;
   p.rows = rows; p.hidden = hidden; p.eps = eps; p.rank = rank; p.world = world;
-  const unsigned blocks = (unsigned)(rows > kMaxBlocks ? kMaxBlocks : rows);
   hipStream_t st = (hipStream_t)stream;
-#define SGL_CARN(Tt, MV) hipLaunchKernelGGL((all_reduce_add_rmsnorm_quant_kernel<Tt, MV>), dim3(blocks), dim3(256), 0, st, p)
-  if (dtype == SGL_BF16) {
-    if (hidden <= 2048) SGL_CARN(__bf16, 1); else if (hidden <= 4096) SGL_CARN(__bf16, 2); else SGL_CARN(__bf16, 4);
+  const bool two = hidden % 16 == 0 && (algo == 2 || (algo == 0 && use_two_stage(world, (int64_t)rows * hidden * 2)));
+  if (two) {
+    p.data_off = fam_off(FAM_2S_FUSED, max_bytes);
+    const int nq = (rows + world - 1) / world;  // row = q * world + owner; block = q % grid
+    const unsigned blocks = (unsigned)(nq > kMaxBlocks ? kMaxBlocks : nq);
+#define SGL_CARN2(Tt, MV) hipLaunchKernelGGL((two_stage_all_reduce_add_rmsnorm_quant_kernel<Tt, MV>), dim3(blocks), dim3(256), 0, st, p)
+    if (dtype == SGL_BF16) {
+      if (hidden <= 2048) SGL_CARN2(__bf16, 1); else if (hidden <= 4096) SGL_CARN2(__bf16, 2); else SGL_CARN2(__bf16, 4);
+    } else {
+      if (hidden <= 2048) SGL_CARN2(_Float16, 1); else if (hidden <= 4096) SGL_CARN2(_Float16, 2); else SGL_CARN2(_Float16, 4);
+    }
+#undef SGL_CARN2
   } else {
-    if (hidden <= 2048) SGL_CARN(_Float16, 1); else if (hidden <= 4096) SGL_CARN(_Float16, 2); else SGL_CARN(_Float16, 4);
-  }
+    p.data_off = fam_off(FAM_FUSED, max_bytes);
+    const unsigned blocks = (unsigned)(rows > kMaxBlocks ? kMaxBlocks : rows);
+#define SGL_CARN(Tt, MV) hipLaunchKernelGGL((all_reduce_add_rmsnorm_quant_kernel<Tt, MV>), dim3(blocks), dim3(256), 0, st, p)
+    if (dtype == SGL_BF16) {
+      if (hidden <= 2048) SGL_CARN(__bf16, 1); else if (hidden <= 4096) SGL_CARN(__bf16, 2); else SGL_CARN(__bf16, 4);
+    } else {
+      if (hidden <= 2048) SGL_CARN(_Float16, 1); else if (hidden <= 4096) SGL_CARN(_Float16, 2); else SGL_CARN(_Float16, 4);
+    }
 #undef SGL_CARN
+  }
   SGL_HIP_LAUNCH_CHECK();
   return SGL_MI355_OK;
+}
+
+extern "C" int sgl_mi355_car_all_reduce_add_rmsnorm_quant(const void* partial, void* residual, const void* weight, float eps,
+                                                          void* out_norm, void* out_q, float* out_s, int rows, int hidden,
+                                                          int dtype, const void* const* peer_bufs, int rank, int world,
+                                                          int64_t max_bytes, void* stream) {
+  return sgl_mi355_car_all_reduce_add_rmsnorm_quant_algo(partial, residual, weight, eps, out_norm, out_q, out_s, rows, hidden, dtype,
+                                                         peer_bufs, rank, world, max_bytes, 0, stream);
 }

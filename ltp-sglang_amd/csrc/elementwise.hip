@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(T* out, const T* x, T* res
         for (int j = 0; j < 8; ++j) vals[it][j] = (float)a.v[j];
       }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) ss += vals[it][j] * vals[it][j];
+      for (int j = 0; j < 8; ++j) ss = fmaf(vals[it][j], vals[it][j], ss);  // (explicit: see fused_decode.hip)
     }
   }
   const float var = block_sum_256(ss, red) / (float)hidden;

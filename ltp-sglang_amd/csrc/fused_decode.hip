@@ -104,7 +104,8 @@ __global__ __launch_bounds__(256) void add_rmsnorm_quant_kernel(const T* x, cons
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         vals[it][j] = f[j];
-        ss += f[j] * f[j];
+        ss = fmaf(f[j], f[j], ss);  // explicit fma: left to hipcc, this contraction is made in some kernels and not in others (packed
+                                    // f32 mul + add), and the fused forms of this arithmetic must round like this one
       }
     }
   }

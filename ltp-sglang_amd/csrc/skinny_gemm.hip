@@ -197,6 +197,10 @@ int launch(const SkinnyParams& p, hipStream_t st) {
 //    slowest of the 8 waves' loads.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kV2Waves = 8;
+#ifndef SGL_SKINNY_PD
+#define SGL_SKINNY_PD 0
+#endif
+constexpr int g_skinny_pd_test = SGL_SKINNY_PD;  // (A/B hook, tools/build_variant.sh: force the prefetch depth of the epilogue-fused launches)
 
 template <int ES, int MT, int DS, int PD, int TPP, typename OutT, int EPI = EPI_NONE, int NWV = kV2Waves>
 __global__ __launch_bounds__(NWV * 64, 1) void skinny_gemm_v2_kernel(const SkinnyParams p, int rpt, int ntiles,
@@ -561,8 +565,19 @@ extern "C" int sgl_mi355_skinny_gemm(const void* x, int64_t x_stride_elems, cons
 // Raw split-K partial sums only: slabs f32 [kranges, M, N] (kranges = sgl_mi355_skinny_gemm_slabs_count(M, K * element size)),
 // no scales; the consumer kernel (sgl_mi355_fused_add_rmsnorm_quant_fp8 with slabs) combines them at its own launch boundary.
 // in_dtype SGL_FP8_E4M3 / SGL_BF16 / SGL_F16 (X and W share it); strides in elements.
-extern "C" int sgl_mi355_skinny_gemm_slabs(const void* x, int64_t x_stride_elems, const void* w, int64_t w_stride_elems,
-                                           float* slabs, int M, int N, int K, int in_dtype, void* stream) {
+// min_kranges > 1 asks for at least that many k-ranges (a shorter K slice per wave: 2048 / 1024 bytes per workgroup instead of
+// 4096): each workgroup then stages a fraction of X before its first MFMA, which is what a short launch is made of (o_proj of
+// Llama-3-8B at batch 32: 8.1 us with one k-range, 7.4 / 6.8 us with two / four) -- worth it where a
+// consumer kernel sums the slabs anyway.  ..._slabs_count_min gives the number of slabs written for the same arguments.
+extern "C" int sgl_mi355_skinny_gemm_slabs_count_min(int M, int K, int min_kranges) {
+  int ds = K <= 1024 ? 2 : (K <= 2048 ? 4 : ((K <= 4096 || M > 32 || K > 8192) ? 8 : 16));
+  while (ds > 2 && (K + kV2Waves * ds * 64 - 1) / (kV2Waves * ds * 64) < min_kranges) ds >>= 1;
+  const int range = kV2Waves * ds * 64;
+  return (K + range - 1) / range;
+}
+
+extern "C" int sgl_mi355_skinny_gemm_slabs_min(const void* x, int64_t x_stride_elems, const void* w, int64_t w_stride_elems,
+                                               float* slabs, int M, int N, int K, int in_dtype, int min_kranges, void* stream) {
   SGL_CHECK(M > 0 && M <= 64 && N > 0 && K > 0, "skinny_gemm_slabs: needs 0 < M <= 64");
   SGL_CHECK(x && w && slabs, "skinny_gemm_slabs: null pointer");
   SGL_CHECK(in_dtype == SGL_FP8_E4M3 || in_dtype == SGL_BF16 || in_dtype == SGL_F16, "skinny_gemm_slabs: bad in_dtype %d", in_dtype);
@@ -577,7 +592,8 @@ extern "C" int sgl_mi355_skinny_gemm_slabs(const void* x, int64_t x_stride_elems
   p.sx = nullptr; p.sw = nullptr; p.bias = nullptr;  // slab mode never reads scales or bias
   p.M = M; p.N = N; p.K = K; p.kbytes = K * es;
   const int kb = p.kbytes;
-  const int ds = kb <= 1024 ? 2 : (kb <= 2048 ? 4 : ((kb <= 4096 || M > 32 || kb > 8192) ? 8 : 16));  // = sgl_mi355_skinny_gemm's choice
+  int ds = kb <= 1024 ? 2 : (kb <= 2048 ? 4 : ((kb <= 4096 || M > 32 || kb > 8192) ? 8 : 16));  // = sgl_mi355_skinny_gemm's choice
+  while (ds > 2 && (kb + kV2Waves * ds * 64 - 1) / (kV2Waves * ds * 64) < min_kranges) ds >>= 1;
   const int range = kV2Waves * ds * 64;
   const int kranges = (kb + range - 1) / range;
   hipStream_t st = (hipStream_t)stream;
@@ -593,6 +609,11 @@ extern "C" int sgl_mi355_skinny_gemm_slabs(const void* x, int64_t x_stride_elems
 #undef SGL_SLABS_BY_M
 }
 
+extern "C" int sgl_mi355_skinny_gemm_slabs(const void* x, int64_t x_stride_elems, const void* w, int64_t w_stride_elems,
+                                           float* slabs, int M, int N, int K, int in_dtype, void* stream) {
+  return sgl_mi355_skinny_gemm_slabs_min(x, x_stride_elems, w, w_stride_elems, slabs, M, N, K, in_dtype, 1, stream);
+}
+
 namespace {
 template <int ES, int MT, int DS, typename OutT, int EPI>
 int launch_v2_epi(const SkinnyParams& p, const EpiParams& ep, int rpt, hipStream_t st) {
@@ -600,11 +621,15 @@ int launch_v2_epi(const SkinnyParams& p, const EpiParams& ep, int rpt, hipStream
   const int ntiles = p.N / rpt;
   const int gx = ntiles < cus ? ntiles : cus;
   constexpr int TPP = (DS >= 16 || MT >= 4) ? 2 : 4;  // (the plain launcher's rule: LDS budget of the reduce buffer)
+  // PD register sets in flight per wave.  One: with two (SGL_SKINNY_PD=2, tools/build_variant.sh) the three 8-row tiles of
+  // qkv_proj need two dependent HBM round trips instead of three, but the deeper queue delays every other load of the CU (X rows,
+  // epilogue operands): same-box A/B in the model (round 3) 4.39 ms/step with two sets against 4.26 with one.
+  constexpr int PDV = (g_skinny_pd_test > 0 && TPP % (g_skinny_pd_test > 0 ? g_skinny_pd_test : 1) == 0) ? g_skinny_pd_test : 1;
   if (ntiles <= gx)
     hipLaunchKernelGGL((skinny_gemm_v2_kernel<ES, MT, DS, 1, 1, OutT, EPI>), dim3(gx, 1), dim3(kV2Waves * 64), 0, st, p, rpt,
                        ntiles, (float*)nullptr, ep);
   else
-    hipLaunchKernelGGL((skinny_gemm_v2_kernel<ES, MT, DS, 1, TPP, OutT, EPI>), dim3(gx, 1), dim3(kV2Waves * 64), 0, st,
+    hipLaunchKernelGGL((skinny_gemm_v2_kernel<ES, MT, DS, PDV, TPP, OutT, EPI>), dim3(gx, 1), dim3(kV2Waves * 64), 0, st,
                        p, rpt, ntiles, (float*)nullptr, ep);
   SGL_HIP_LAUNCH_CHECK();
   return SGL_MI355_OK;

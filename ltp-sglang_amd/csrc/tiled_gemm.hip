@@ -28,6 +28,7 @@ struct GemmParams {
   int group_m;  // row tiles per scheduling group (256x256 kernel)
   float* slabs;  // split-K (128x128 kernel, blockIdx.y = K range of `kt_per` slices): raw f32 sums [splits][M][N], else NULL
   int kt_per;
+  int* counters = nullptr;  // streaming tile, in-launch split-K combine: two words per output tile (arrivals, departures), zero between launches
   int stagger_q, stagger_cus;  // 256x256 kernel: start stagger of each CU's first workgroup (quantum in 1024-cycle units; CU count)
 #ifdef SGL_GEMM_TIMELINE
   long long* tl;  // tools/microbench/gemm256_timeline.hip: s_memtime stamps of workgroup 0, slices 8..11
@@ -627,15 +628,66 @@ __global__ __launch_bounds__(512, 1) void fp8_gemm128s_kernel(const GemmParams p
 
   // ---- epilogue: acc[j][i][r] -> row m0+wm+16i+a, col n0+wn+16j+4g+r ----
   if (p.slabs) {
-    float* sl = p.slabs + (int64_t)blockIdx.y * p.M * p.N;
+    // write-through (sc1) stores when the partial sums are combined inside this launch (hand-off to other workgroups)
+    const auto srs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.slabs + (int64_t)blockIdx.y * p.M * p.N), 0,
+                                                       (unsigned)((int64_t)p.M * p.N * 4), 0x00020000);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int m = m0 + wm + 16 * i + a;
-      if (m >= p.M) continue;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int n = n0 + wn + 16 * j + 4 * g;
-        if (n + 3 < p.N) *(f32x4_t*)(sl + (int64_t)m * p.N + n) = acc[j][i];  // (N % 4 == 0 in slab mode)
+        const unsigned off = (m < p.M && n + 3 < p.N) ? (unsigned)(((int64_t)m * p.N + n) * 4) : 0xFFFFFFF0u;  // (N % 4 == 0 in slab mode)
+        if (p.counters) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[j][i]), srs, off, 0, 16);
+        else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[j][i]), srs, off, 0, 0);
+      }
+    }
+    if (p.counters == nullptr) return;  // the consumer (a reduce launch, or a kernel that takes slabs) combines them
+    // ---- in-launch split-K combine (round 3): the S workgroups of a tile wait for each other, then each combines 1/S of the
+    // tile -- the sums of tiled_splitk_reduce_kernel in the same order, so the same bits, without the extra launch (5.6 us at the
+    // 70B TP-8 shard shapes) and without the second pass over M x N x S floats through HBM.  All S x tiles workgroups are resident
+    // (the launcher makes S x tiles <= CUs and a workgroup takes 128 KiB of LDS), every spin is bounded.  Hand-off form: sc1
+    // stores, every wave drains, barrier, one lane adds; one lane polls with sc1 loads, barrier, sc1 loads
+    // (MI355X_MICROARCH.md, visibility table, first row). ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int S = gridDim.y;
+    int* cnt = p.counters + 2 * blockIdx.x;
+    if (tid == 0) {
+      __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int spin = 0; spin < (1 << 22); ++spin) {
+        if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= S) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    __syncthreads();
+    const auto ars = __builtin_amdgcn_make_buffer_rsrc((void*)p.slabs, 0, (unsigned)min((int64_t)S * p.M * p.N * 4, (int64_t)0xFFFFFFF0ll), 0x00020000);
+    const unsigned slab_b = (unsigned)((int64_t)p.M * p.N * 4);
+    for (int f = tid + 512 * (int)blockIdx.y; f < S_BM * S_BN / 4; f += 512 * S) {
+      const int m = m0 + f / (S_BN / 4), n = n0 + (f % (S_BN / 4)) * 4;
+      if (m >= p.M || n + 3 >= p.N) continue;
+      const unsigned off = (unsigned)(((int64_t)m * p.N + n) * 4);
+      f32x4_t v = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(ars, off, 0, 16));
+      for (int sI = 1; sI < S; ++sI)
+        v += __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(ars, off + (unsigned)sI * slab_b, 0, 16));
+      OutT o[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float r = v[c];
+        if (p.sx) r *= p.sx[m];
+        r = r * (p.sw ? p.sw[n + c] : 1.0f) + (p.bias ? (float)((const OutT*)p.bias)[n + c] : 0.0f);
+        o[c] = (OutT)r;
+      }
+      OutT* yp = (OutT*)p.y + (int64_t)m * p.y_stride + n;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) yp[c] = o[c];
+    }
+    __syncthreads();
+    if (tid == 0) {  // the last workgroup to leave puts both words back to zero (everybody has passed the wait by then)
+      const int d = __hip_atomic_fetch_add(cnt + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (d == S - 1) {
+        __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(cnt + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     return;
@@ -736,6 +788,8 @@ int launch(GemmParams& p, hipStream_t st, float* workspace = nullptr, int64_t wo
   return SGL_MI355_OK;
 }
 
+constexpr int64_t kCounterFloats = 1024;
+int g_tiled_inlaunch = 1;  // measurement hook (sgl_mi355_fp8_gemm_force_tile(2000 / 2001)): 0 = the separate reduce launch
 // split-K ranges of the streaming 128x128 tile for this shape (1: none) and the slices per range
 inline int splits128s(int M, int N, int kbytes, bool have_workspace, int64_t workspace_floats, int* kt_per) {
   const int tiles = ((M + S_BM - 1) / S_BM) * ((N + S_BN - 1) / S_BN), nk = kbytes / BKB, cus = tg_cus();
@@ -767,12 +821,17 @@ int launch128s(GemmParams& p, hipStream_t st, float* workspace, int64_t workspac
   p.tiles_m = (p.M + S_BM - 1) / S_BM;
   p.tiles_n = (p.N + S_BN - 1) / S_BN;
   const int tiles = p.tiles_m * p.tiles_n;
-  const int splits = splits128s(p.M, p.N, p.kbytes, workspace != nullptr, workspace_floats, &p.kt_per);
+  // the last kCounterFloats floats of the workspace hold the in-launch combine's counters (zero between launches)
+  const int64_t slab_floats = workspace_floats > kCounterFloats ? workspace_floats - kCounterFloats : 0;
+  const int splits = splits128s(p.M, p.N, p.kbytes, workspace != nullptr, slab_floats, &p.kt_per);
   p.slabs = splits > 1 ? workspace : nullptr;
   SGL_CHECK(!slabs_only || splits > 1, "fp8_gemm_slabs: this shape runs as one k-range (no slabs): M=%d N=%d", p.M, p.N);
+  const bool in_launch = splits > 1 && !slabs_only && g_tiled_inlaunch && 2 * tiles <= kCounterFloats && p.N % 4 == 0 &&
+                         (int64_t)splits * p.M * p.N * 4 < 0xFFFFFFF0ll && tiles * splits <= tg_cus();
+  p.counters = in_launch ? (int*)(workspace + slab_floats) : nullptr;
   hipLaunchKernelGGL((fp8_gemm128s_kernel<OutT>), dim3(tiles, splits), dim3(512), smem, st, p);
   SGL_HIP_LAUNCH_CHECK();
-  if (splits > 1 && !slabs_only) {
+  if (splits > 1 && !slabs_only && !in_launch) {
     const int64_t items = (int64_t)p.M * (p.N / 4);
     const unsigned blocks = (unsigned)((items + 255) / 256 > 4096 ? 4096 : (items + 255) / 256);
     hipLaunchKernelGGL((tiled_splitk_reduce_kernel<OutT>), dim3(blocks), dim3(256), 0, st, workspace, splits, p.sx, p.sw,
@@ -843,6 +902,10 @@ int run(const void* x, int64_t xs, const void* w, int64_t ws, void* y, int64_t y
 }  // namespace
 
 extern "C" int sgl_mi355_fp8_gemm_force_tile(int mode) {
+  if (mode >= 2000) {  // measurement hook: 2000 = split-K combined by a separate reduce launch, 2001 = inside the GEMM launch (default)
+    g_tiled_inlaunch = mode - 2000;
+    return SGL_MI355_OK;
+  }
   if (mode >= 1000) {  // measurement hook: 1000 + q sets the start-stagger quantum of the 256x256 kernel (0 = off)
     g_tiled_stagger = mode - 1000;
     return SGL_MI355_OK;
@@ -868,7 +931,7 @@ extern "C" int sgl_mi355_fp8_gemm(const void* x, int64_t x_stride_elems, const v
 extern "C" int sgl_mi355_fp8_gemm_num_slabs(int M, int N, int K, int64_t workspace_floats) {
   if (M <= 0 || N <= 0 || K <= 0 || !takes128s(M, N, K, K, K)) return 1;
   int kt_per = 0;
-  return splits128s(M, N, K, true, workspace_floats, &kt_per);
+  return splits128s(M, N, K, true, workspace_floats > kCounterFloats ? workspace_floats - kCounterFloats : 0, &kt_per);
 }
 
 // Producer half of the launch-boundary split-K reduce for 64 < M <= 256: the raw f32 partial sums [num_slabs][M][N] of

@@ -22,7 +22,9 @@ def _workspace(device, need: int):
     if buf is None or buf.numel() < need:
         if buf is not None:
             _RETIRED.append(buf)
-        buf = torch.empty(max(int(need), WORKSPACE_FLOATS), dtype=torch.float32, device=device)
+        # zeros: the last 1024 floats are the in-launch split-K combine's counters of the streaming-tile GEMM (csrc/tiled_gemm.hip),
+        # which that kernel leaves at zero after every launch
+        buf = torch.zeros(max(int(need), WORKSPACE_FLOATS), dtype=torch.float32, device=device)
         _WORKSPACES[device] = buf
     return buf, buf.numel()
 
@@ -182,17 +184,18 @@ def fp8_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype, bias=None):
     return out
 
 
-def fp8_linear_slabs(x_q: torch.Tensor, weight_nk: torch.Tensor, m: int, n: int, k: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def fp8_linear_slabs(x_q: torch.Tensor, weight_nk: torch.Tensor, m: int, n: int, k: int, out: Optional[torch.Tensor] = None,
+                     min_kranges: int = 1) -> torch.Tensor:
     """Raw f32 split-K partial sums [S, M, N] of x_q[M,K] @ weight_nk[N,K]^T (no scales): the producer half of the
     launch-boundary split-K reduce; the consumer (fused_add_rmsnorm_quant_fp8 with ``slabs=``) applies the scales.
     Operands fp8 (fp8_scaled_mm) or bf16 / f16 (the unquantised linear: the consumer gets no scales)."""
     _cuda(x_q, weight_nk)
     assert x_q.dtype == weight_nk.dtype
-    kr = lib.sgl_mi355_skinny_gemm_slabs_count(m, k * x_q.element_size())
+    kr = lib.sgl_mi355_skinny_gemm_slabs_count_min(m, k * x_q.element_size(), int(min_kranges))
     if out is None:
         out = torch.empty((kr, m, n), dtype=torch.float32, device=x_q.device)
-    check(lib.sgl_mi355_skinny_gemm_slabs(ptr(x_q), x_q.stride(0), ptr(weight_nk), weight_nk.stride(0), ptr(out), m, n, k,
-                                          dtype_code(x_q.dtype), current_stream()))
+    check(lib.sgl_mi355_skinny_gemm_slabs_min(ptr(x_q), x_q.stride(0), ptr(weight_nk), weight_nk.stride(0), ptr(out), m, n, k,
+                                              dtype_code(x_q.dtype), int(min_kranges), current_stream()))
     return out
 
 

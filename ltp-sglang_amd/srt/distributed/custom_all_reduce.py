@@ -94,10 +94,12 @@ class CustomAllreduce:
 
     should_custom_ar = should_use
 
-    def all_reduce(self, inp: torch.Tensor) -> torch.Tensor:
-        """In-place sum over the group; returns ``inp``.  Capturable in a HIP graph (epochs live in device memory)."""
-        check(lib.sgl_mi355_car_all_reduce(inp.data_ptr(), inp.numel(), dtype_code(inp.dtype), self._ptrs, self.rank,
-                                           self.world_size, self.max_size, current_stream()))
+    def all_reduce(self, inp: torch.Tensor, algo: int = 0) -> torch.Tensor:
+        """In-place sum over the group; returns ``inp``.  Capturable in a HIP graph (epochs live in device memory).
+        ``algo``: 0 = the reference's dispatch rule (custom_all_reduce_hip.cuh:543-549), 1 = one-shot, 2 = two-stage
+        (reduce-scatter + all-gather); the same value on every rank."""
+        check(lib.sgl_mi355_car_all_reduce_algo(inp.data_ptr(), inp.numel(), dtype_code(inp.dtype), self._ptrs, self.rank,
+                                                self.world_size, self.max_size, int(algo), current_stream()))
         return inp
 
     custom_all_reduce = all_reduce
@@ -106,19 +108,28 @@ class CustomAllreduce:
         return (self.should_use(partial) and partial.dim() == 2 and partial.dtype in (torch.bfloat16, torch.float16)
                 and partial.shape[1] % 8 == 0 and partial.shape[1] <= 8192)
 
-    def all_reduce_add_rmsnorm_quant(self, partial, residual, weight, eps, want_norm=False, want_quant=True):
+    def all_reduce_add_rmsnorm_quant(self, partial, residual, weight, eps, want_norm=False, want_quant=True, algo: int = 0):
         """all_reduce(partial) -> residual += . -> rmsnorm * weight -> per-token fp8 quant, ONE launch, bit-identical to the
-        unfused pair.  Returns (y or None, y_q or None, y_scale [M, 1] or None); ``residual`` is updated in place."""
+        unfused pair.  Returns (y or None, y_q or None, y_scale [M, 1] or None); ``residual`` is updated in place.  ``algo`` as
+        for ``all_reduce`` (two-stage: the owner of a row finishes it once, the other ranks collect it)."""
         m, h = partial.shape
+        if getattr(self, "_fused_hidden", h) != h:
+            # The protocol has no closing barrier: block b may re-enter a data half because the peers' blocks b have left it,
+            # which needs the row -> byte-range map of the fused family to stay the same from call to call.  It depends on
+            # `hidden`; a model keeps one hidden size, a test that changes it pays a host-level barrier here (never inside a
+            # captured step).
+            torch.cuda.synchronize(self.device)
+            dist.barrier(group=self.group)
+        self._fused_hidden = h
         dev = partial.device
         out_norm = torch.empty((m, h), dtype=partial.dtype, device=dev) if want_norm else None
         out_q = torch.empty((m, h), dtype=torch.float8_e4m3fn, device=dev) if want_quant else None
         out_s = torch.empty((m, 1), dtype=torch.float32, device=dev) if want_quant else None
-        check(lib.sgl_mi355_car_all_reduce_add_rmsnorm_quant(
+        check(lib.sgl_mi355_car_all_reduce_add_rmsnorm_quant_algo(
             partial.data_ptr(), None if residual is None else residual.data_ptr(), weight.data_ptr(), float(eps),
             None if out_norm is None else out_norm.data_ptr(), None if out_q is None else out_q.data_ptr(),
             None if out_s is None else out_s.data_ptr(), m, h, dtype_code(partial.dtype), self._ptrs, self.rank, self.world_size,
-            self.max_size, current_stream()))
+            self.max_size, int(algo), current_stream()))
         return out_norm, out_q, out_s
 
     def should_use_gather(self, inp: torch.Tensor) -> bool:

@@ -160,9 +160,12 @@ class LlamaForCausalLM(nn.Module):
         self.fused_attn_merge = True   # decode: stage-2 merge + quant by the last-arriving workgroup of each request
         self.fused_epilogues = True
         # decode, M <= 32: post-attention norm -> gate_up + SiluAndMul -> quant -> down_proj as ONE persistent launch
-        # (csrc/mlp_block.hip) instead of four; SGL_MI355_MLP_BLOCK=0 keeps the four launches
-        self.fused_mlp_block = os.environ.get("SGL_MI355_MLP_BLOCK", "1") != "0"
+        # (csrc/mlp_block.hip) instead of four.  Measured 2.5 % slower than the four launches at the headline shape, so
+        # off unless SGL_MI355_MLP_BLOCK=1
+        self.fused_mlp_block = os.environ.get("SGL_MI355_MLP_BLOCK", "0") != "0"
         self._mlp_scratch = {}
+        # decode, M <= 64: o_proj in this many k-ranges, summed by the add + RMSNorm that follows (1 = one launch with the plain epilogue)
+        self.o_proj_kranges = int(os.environ.get("SGL_MI355_OPROJ_KRANGES", "1"))
         qc = None
         if quantization is not None and not isinstance(quantization, str):
             qc = quantization   # a QuantizationConfig instance (e.g. a serialized-checkpoint config)
@@ -337,7 +340,14 @@ class LlamaForCausalLM(nn.Module):
                                                       backend.max_kv_splits, self.dtype)
             ln2 = layer.post_attention_layernorm
             wo = attn.o_proj.weight   # [K, N] column-major view of the [N, K] parameter
-            if tp == 1 and K.fp8_gemm_num_slabs(m, wo.shape[1], wo.shape[0], wo.device) > 1:
+            if tp == 1 and m <= 64 and self.o_proj_kranges > 1 and not (mlp_scratch is not None and fw is not None and "mlp_down" in fw):
+                # o_proj as split-K partial sums straight into the add + RMSNorm + quant (no bit-identity with the per-op path:
+                # the accumulation order follows the K partition; the contract is the oracle tolerance)
+                o_slabs = K.fp8_linear_slabs(oq, wo.t(), m, wo.shape[1], wo.shape[0], min_kranges=self.o_proj_kranges)
+                _, hq2, hs2 = K.fused_add_rmsnorm_quant_fp8(None, residual, ln2.weight.data, ln2.variance_epsilon, slabs=o_slabs,
+                                                            slab_sx=osc.view(-1), slab_sw=attn.o_proj.weight_scale.view(-1),
+                                                            dtype=self.dtype)
+            elif tp == 1 and K.fp8_gemm_num_slabs(m, wo.shape[1], wo.shape[0], wo.device) > 1:
                 # 64 < M <= 256: o_proj's split-K partial sums go straight into the add + RMSNorm + quant (no reduce launch)
                 o_slabs = K.fp8_gemm_slabs(oq, wo.t())
                 _, hq2, hs2 = K.fused_add_rmsnorm_quant_fp8(None, residual, ln2.weight.data, ln2.variance_epsilon, slabs=o_slabs,

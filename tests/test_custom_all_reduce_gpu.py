@@ -1,4 +1,4 @@
-"""One-shot P2P all-reduce (csrc/custom_all_reduce.hip, srt/distributed/custom_all_reduce.py) validated with 2 and 4
+"""One-shot and two-stage P2P all-reduce (csrc/custom_all_reduce.hip, srt/distributed/custom_all_reduce.py) validated with 2 and 4
 PROCESSES ON ONE GPU: every rank maps its peers' buffers through hipIpcGetMemHandle / hipIpcOpenMemHandle -- the code path an
 8-GPU node runs over xGMI -- and the result is compared BIT-EXACTLY with the host-staged sum in rank order (f32 accumulate,
 one rounding), eagerly and replayed from a HIP graph.  (The box allows at most 6 processes on its GPU: no 8-rank case here.)
@@ -58,25 +58,73 @@ def _worker(rank, world, port, q):
         for part in parts:
             ref += part.float()
         ref = ref.to(dtype)
-        xd = x.to(dev)
-        assert car.should_use(xd)
-        out = car.all_reduce(xd)
-        car.check_error()
-        assert out.data_ptr() == xd.data_ptr()
-        same = torch.equal(out.cpu(), ref)
-        if not same:
-            bad = (out.cpu() != ref)
-            print(f"[rank {rank}] call {it} {shape} {dtype}: {int(bad.sum())} of {bad.numel()} elements differ; first at {bad.flatten().nonzero()[:4].flatten().tolist()}",
-                  flush=True)
-        ok = ok and same
-        worst = max(worst, float((out.cpu().float() - ref.float()).abs().max()))
+        for algo in (0, 1, 2):   # the reference's dispatch rule, one-shot, two-stage (reduce-scatter + all-gather): the same bits
+            xd = x.to(dev)
+            assert car.should_use(xd)
+            out = car.all_reduce(xd, algo=algo)
+            car.check_error()
+            assert out.data_ptr() == xd.data_ptr()
+            same = torch.equal(out.cpu(), ref)
+            if not same:
+                bad = (out.cpu() != ref)
+                print(f"[rank {rank}] call {it} algo {algo} {shape} {dtype}: {int(bad.sum())} of {bad.numel()} elements differ; first at "
+                      f"{bad.flatten().nonzero()[:4].flatten().tolist()}", flush=True)
+            ok = ok and same
+            worst = max(worst, float((out.cpu().float() - ref.float()).abs().max()))
     # back-to-back calls without host synchronisation in between (a rank may run one call ahead of its peers)
-    xs = [torch.full((32, 4096), float(rank + 1 + k), dtype=torch.bfloat16, device=dev) for k in range(16)]
-    for t in xs:
-        car.all_reduce(t)
+    for algo in (1, 2):
+        xs = [torch.full((32, 4096), float(rank + 1 + k), dtype=torch.bfloat16, device=dev) for k in range(16)]
+        for t in xs:
+            car.all_reduce(t, algo=algo)
+        car.check_error()
+        for k, t in enumerate(xs):
+            ok = ok and bool((t == float(sum(r + 1 + k for r in range(world)))).all())
+    # The four kernel families interleaved with CHANGING sizes, no host synchronisation, one rank delayed before every call: a
+    # family's packet -> block map must not depend on the call (round-2 advisor finding: the fused kernel's row map and the
+    # plain kernel's packet map used to share one pair of halves; a lagging peer could read rows the next-but-one call had
+    # already overwritten).  hidden stays 2048 for the fused calls (one hidden per communicator without a host barrier).
+    from ltp_sglang_amd import sgl_kernel as K0
+    gw = torch.Generator().manual_seed(99)
+    w_ln = (1 + 0.1 * torch.randn(2048, generator=gw)).to(torch.bfloat16).to(dev)
+    seqs = []
+    for k in range(12):
+        m = (1, 32, 4, 128, 9, 64)[k % 6]
+        g = torch.Generator().manual_seed(500 + 17 * k + rank)
+        plain = (torch.randn(m, 8192, generator=g) * 2).to(torch.bfloat16)
+        part = torch.randn(m, 2048, generator=g).to(torch.bfloat16)
+        gat = torch.randn(m, 1024, generator=g).to(torch.bfloat16)
+        res0 = torch.randn(m, 2048, generator=torch.Generator().manual_seed(k)).to(torch.bfloat16)
+        seqs.append((k, plain, part, gat, res0))
+    outs = []
+    for k, plain, part, gat, res0 in seqs:
+        if rank == k % world:
+            torch.cuda._sleep(3_000_000)   # ~ a millisecond of GPU time on this rank only: the peers run ahead
+        a1 = car.all_reduce(plain.to(dev), algo=1)
+        r1 = res0.clone().to(dev)
+        f1 = car.all_reduce_add_rmsnorm_quant(part.to(dev), r1, w_ln, 1e-5, want_norm=True, want_quant=True, algo=1)
+        a2 = car.all_reduce(plain.to(dev), algo=2)
+        r2 = res0.clone().to(dev)
+        f2 = car.all_reduce_add_rmsnorm_quant(part.to(dev), r2, w_ln, 1e-5, want_norm=True, want_quant=True, algo=2)
+        ga = car.all_gather_last_dim(gat.to(dev))
+        outs.append((a1, a2, f1, f2, r1, r2, ga))
     car.check_error()
-    for k, t in enumerate(xs):
-        ok = ok and bool((t == float(sum(r + 1 + k for r in range(world)))).all())
+    for (k, plain, part, gat, res0), (a1, a2, f1, f2, r1, r2, ga) in zip(seqs, outs):
+        parts = [torch.empty_like(plain) for _ in range(world)]
+        dist.all_gather(parts, plain)
+        ref = sum((t.float() for t in parts[1:]), parts[0].float()).to(torch.bfloat16)
+        pp = [torch.empty_like(part) for _ in range(world)]
+        dist.all_gather(pp, part)
+        summed = sum((t.float() for t in pp[1:]), pp[0].float()).to(torch.bfloat16).to(dev)
+        rr = res0.clone().to(dev)
+        yn, yq, ys = K0.fused_add_rmsnorm_quant_fp8(summed, rr, w_ln, 1e-5, want_norm=True, want_quant=True)
+        gg = [torch.empty_like(gat) for _ in range(world)]
+        dist.all_gather(gg, gat)
+        good = (torch.equal(a1.cpu(), ref) and torch.equal(a2.cpu(), ref) and torch.equal(ga.cpu(), torch.cat(gg, dim=-1))
+                and all(torch.equal(f[0], yn) and torch.equal(f[1].view(torch.uint8), yq.view(torch.uint8)) and torch.equal(f[2], ys)
+                        for f in (f1, f2)) and torch.equal(r1, rr) and torch.equal(r2, rr))
+        if not good:
+            print(f"[rank {rank}] interleaved call {k} (m={plain.shape[0]}) differs", flush=True)
+        ok = ok and good
     # through the reference's call site: tensor_model_parallel_all_reduce prefers the custom path for small messages
     comm.init_tensor_parallel()
     comm.set_custom_all_reduce(car)
@@ -104,6 +152,22 @@ def _worker(rank, world, port, q):
         if not same:
             print(f"[rank {rank}] fused all-reduce + norm differs at {(m, h)} {dtype}", flush=True)
         ok = ok and same
+        # the two-stage fused form (the owner of a row finishes it once, the others collect the finished row): the same bits
+        res_c = res0.clone()
+        y2, q2, s2 = car.all_reduce_add_rmsnorm_quant(part.clone(), res_c, w, 1e-5, want_norm=True, want_quant=True, algo=2)
+        car.check_error()
+        same2 = (torch.equal(ya, y2) and torch.equal(qa.view(torch.uint8), q2.view(torch.uint8)) and torch.equal(sa, s2)
+                 and torch.equal(res_a, res_c))
+        if not same2:
+            def nd(a, b):
+                d = (a != b)
+                rows_bad = sorted(set(d.nonzero()[:, 0].tolist()))[:12] if d.dim() == 2 else []
+                return f"{int(d.sum())} differ (rows {rows_bad})"
+            print(f"[rank {rank}] two-stage fused all-reduce + norm differs at {(m, h)} {dtype}: y {nd(ya, y2)}; q "
+                  f"{nd(qa.view(torch.uint8), q2.view(torch.uint8))}; s {nd(sa, s2)}; residual {nd(res_a, res_c)}", flush=True)
+        ok = ok and same2
+        y3, _, _ = car.all_reduce_add_rmsnorm_quant(part.clone(), None, w, 1e-5, want_norm=True, want_quant=False, algo=2)
+        ok = ok and torch.equal(y3, K.fused_add_rmsnorm_quant_fp8(summed, None, w, 1e-5, want_norm=True, want_quant=False)[0])
         yc, _, _ = comm.tensor_model_parallel_all_reduce_add_rmsnorm_quant(part.clone(), None, w, 1e-5, want_norm=True, want_quant=False)
         yd, _, _ = K.fused_add_rmsnorm_quant_fp8(summed, None, w, 1e-5, want_norm=True, want_quant=False)
         ok = ok and torch.equal(yc, yd)
@@ -134,10 +198,35 @@ def _worker(rank, world, port, q):
         graph.replay()
         car.check_error()
         ok = ok and bool((z == float(sum(r + k for r in range(world)))).all())
+    # the same for the two-stage kernels (plain and fused), both in one captured graph
+    z2 = torch.zeros((128, 2048), dtype=torch.bfloat16, device=dev)
+    pz = torch.zeros((128, 2048), dtype=torch.bfloat16, device=dev)
+    rz = torch.zeros((128, 2048), dtype=torch.bfloat16, device=dev)
+    graph2 = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        car.all_reduce(z2, algo=2)
+        car.all_reduce_add_rmsnorm_quant(pz, rz, w_ln, 1e-5, want_norm=True, want_quant=True, algo=2)
+        torch.cuda.synchronize()
+        dist.barrier()
+        with torch.cuda.graph(graph2, stream=side, capture_error_mode="thread_local"):
+            car.all_reduce(z2, algo=2)
+            gy, gq, gs = car.all_reduce_add_rmsnorm_quant(pz, rz, w_ln, 1e-5, want_norm=True, want_quant=True, algo=2)
+    for k in range(4):
+        z2.fill_(float(rank + k))
+        pz.fill_(0.25 * (rank + 1) + k)
+        rz.fill_(1.0)
+        torch.cuda.synchronize()
+        dist.barrier()
+        graph2.replay()
+        car.check_error()
+        ok = ok and bool((z2 == float(sum(r + k for r in range(world)))).all())
+        tot = torch.full((128, 2048), float(sum(0.25 * (r + 1) + k for r in range(world))), dtype=torch.bfloat16, device=dev)
+        rr = torch.ones((128, 2048), dtype=torch.bfloat16, device=dev)
+        ey, eq, es = K.fused_add_rmsnorm_quant_fp8(tot, rr, w_ln, 1e-5, want_norm=True, want_quant=True)
+        ok = ok and torch.equal(gy, ey) and torch.equal(gq.view(torch.uint8), eq.view(torch.uint8)) and torch.equal(gs, es) and torch.equal(rz, rr)
     comm.set_custom_all_reduce(None)
     car.close()
-    if rank == 0:
-        q.put((ok, worst))
+    q.put((rank, bool(ok), worst))   # EVERY rank reports: a mismatch on rank 3 must fail the test too
     dist.barrier()
     dist.destroy_process_group()
 
@@ -150,8 +239,16 @@ def test_one_shot_all_reduce_bit_exact_over_ipc(world, pkg):
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    ok, worst = q.get(timeout=150)
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
-    assert ok, f"custom all-reduce differs from the host-staged rank-order sum (max |diff| {worst})"
+    try:
+        reports = [q.get(timeout=240) for _ in range(world)]
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:   # a rank that died before reporting must not leave its peers spinning behind the test
+            if p.is_alive():
+                p.terminate()
+                p.join(timeout=10)
+    assert sorted(r for r, _, _ in reports) == list(range(world))
+    bad = [(r, w) for r, ok, w in reports if not ok]
+    assert not bad, f"custom all-reduce differs from the host-staged rank-order sum on ranks {bad}"

@@ -10,6 +10,9 @@ cd /tmp && export TMPDIR=/tmp
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o bench -- \
   python3 $R/bench.py --no-cpu-baseline > $OUT/${TAG}_bench_under_rocprof.log 2>&1
 cp $(find $OUT/prof_$TAG -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_kernel_stats.csv
+# the same trace split by launch geometry: rocprofv3's summary averages a kernel NAME over every role the bench launches it in
+# (in-model launches, graph-capture warm-ups at one token, stage-1-only roofline probes; prefill- and decode-sized row kernels)
+python3 $R/tools/kernel_stats_by_grid.py $OUT/prof_$TAG > $OUT/${TAG}_kernel_stats_by_grid.csv
 echo "[profile] kernel stats done"
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_$TAG -o pmc -- \
   python3 $R/bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline > $OUT/${TAG}_pmc_fetch.log 2>&1
