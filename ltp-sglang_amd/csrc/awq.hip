@@ -150,7 +150,7 @@ struct AwqDequant<__bf16> {
   }
 };
 
-// (round 3) The offset form, used when one scale group covers a whole 128-k block (SG = 1, G % 128 == 0): the MFMA multiplies X
+// (round 3) The offset form, used for bf16 operands when one scale group covers a whole 128-k block (SG = 1, G % 128 == 0): the MFMA multiplies X
 // by the RAW nibbles as the floating-point integers 16 + q (one shift + one v_and_or_b32 per two weights: the nibble lands in
 // the mantissa bits of weight 1 of the constant 16.0), accumulates the block in a temporary f32 tile, and the zero point and the
 // scale are applied to that tile:
@@ -260,7 +260,10 @@ __global__ __launch_bounds__(kAwqWaves * 64, 1) void awq_gemm_kernel(const AwqGe
   }
 
   // offset form: row sums of X over each of this wave's k-blocks (rows 16 mt + 4 g + r of the MFMA output, every column alike)
-  constexpr bool OFFS = (SG == 1) && (SGL_AWQ_EXACT_WEIGHTS == 0);
+  // bf16 only: with f16 operands the per-weight form is 2 PACKED f16 ops per two weights and the offset form measured 5 % slower
+  // in the model (Qwen2-7B AWQ f16, same box: 3.03 vs 3.19 ms/step, with the correction applied one block late as well as in
+  // place); with bf16 operands (no packed bf16 arithmetic: cvt_ubyte + fma in f32 + cvt_pk) it is 7 % faster (3.16 vs 3.40).
+  constexpr bool OFFS = (SG == 1) && (SGL_AWQ_EXACT_WEIGHTS == 0) && (sizeof(T) == 2 && !__is_same(T, _Float16));
   AwqRaw<T> raw;
   raw.init();
   // (kept in LDS, 512 bytes per wave, read back as one broadcast ds_read_b128 per block: in registers they were 32 VGPRs too
@@ -331,29 +334,39 @@ __global__ __launch_bounds__(kAwqWaves * 64, 1) void awq_gemm_kernel(const AwqGe
       AWQ_STAMP(2 + 7 * (j0 / TPP) + jj);  // tile jj of the phase starts
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      if constexpr (OFFS) {
+        // The correction of a block reads that block's MFMA results with VALU instructions: applied right behind the MFMAs it
+        // stalled on their latency four times per tile (f16: 5 % SLOWER than the per-weight form).  It is applied one block late
+        // (two temporary tiles, ping-pong), under the next block's dequantisation and MFMAs.
+        f32x4_t tmp[2][MT];
+        auto correct = [&](int bi, const f32x4_t (&t)[MT]) __attribute__((always_inline)) {
+          const uint32_t szw = szreg[slot][bi][0];
+          const float sf = awq_scale_f32<T>(szw), nzc = -(float)(16u + (szw >> 16));
 #pragma unroll
-      for (int bi = 0; bi < kAwqBpw; ++bi) {
-        const u32x4_t wq = wreg[slot][bi];
-        if constexpr (OFFS) {
-          f32x4_t tmp[MT];
+          for (int mt = 0; mt < MT; ++mt) {
+            const f32x4_t xs = xsum_l[w][mt][bi][g];
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) tmp[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            for (int r = 0; r < 4; ++r) acc[mt][r] = fmaf(fmaf(nzc, xs[r], t[mt][r]), sf, acc[mt][r]);
+          }
+        };
+#pragma unroll
+        for (int bi = 0; bi < kAwqBpw; ++bi) {
+          const u32x4_t wq = wreg[slot][bi];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) tmp[bi & 1][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
             const vec8 wfrag = raw.run(wq[s]);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) tmp[mt] = Tr::mfma16(xf[mt][bi][s], wfrag, tmp[mt]);
+            for (int mt = 0; mt < MT; ++mt) tmp[bi & 1][mt] = Tr::mfma16(xf[mt][bi][s], wfrag, tmp[bi & 1][mt]);
           }
-          const uint32_t szw = szreg[slot][bi][0];
-          const float sf = awq_scale_f32<T>(szw), nzc = -(float)(16u + (szw >> 16));
-          f32x4_t xs[MT];
+          if (bi > 0) correct(bi - 1, tmp[(bi - 1) & 1]);
+        }
+        correct(kAwqBpw - 1, tmp[(kAwqBpw - 1) & 1]);
+      } else {
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) xs[mt] = xsum_l[w][mt][bi][g];
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[mt][r] = fmaf(fmaf(nzc, xs[mt][r], tmp[mt][r]), sf, acc[mt][r]);
-        } else {
+        for (int bi = 0; bi < kAwqBpw; ++bi) {
+          const u32x4_t wq = wreg[slot][bi];
           AwqDequant<T> dq;
 #pragma unroll
           for (int s = 0; s < 4; ++s) {

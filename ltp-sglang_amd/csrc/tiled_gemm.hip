@@ -789,7 +789,12 @@ int launch(GemmParams& p, hipStream_t st, float* workspace = nullptr, int64_t wo
 }
 
 constexpr int64_t kCounterFloats = 1024;
-int g_tiled_inlaunch = 1;  // measurement hook (sgl_mi355_fp8_gemm_force_tile(2000 / 2001)): 0 = the separate reduce launch
+// In-launch split-K combine: OFF by default.  Same-box A/B in the model (round 3): Llama-3-70B TP-8 shard, batch 128: 10.70 ms/step
+// with it against 10.16 with the separate reduce launch; Llama-3-8B batch 128: 9.99 against 9.95 -- the workgroups of a tile wait
+// for the slowest one and then read the slabs behind their own still-draining stores, which costs more than the 1.7 us launch
+// boundary + 5.6 us reduce kernel it removes (the "splitk-seam" row of MI355X_MICROARCH.md's price list says the same).  Kept as
+// a tested option: sgl_mi355_fp8_gemm_force_tile(2001) turns it on, 2000 off.
+int g_tiled_inlaunch = 0;
 // split-K ranges of the streaming 128x128 tile for this shape (1: none) and the slices per range
 inline int splits128s(int M, int N, int kbytes, bool have_workspace, int64_t workspace_floats, int* kt_per) {
   const int tiles = ((M + S_BM - 1) / S_BM) * ((N + S_BN - 1) / S_BN), nk = kbytes / BKB, cus = tg_cus();
@@ -902,7 +907,7 @@ int run(const void* x, int64_t xs, const void* w, int64_t ws, void* y, int64_t y
 }  // namespace
 
 extern "C" int sgl_mi355_fp8_gemm_force_tile(int mode) {
-  if (mode >= 2000) {  // measurement hook: 2000 = split-K combined by a separate reduce launch, 2001 = inside the GEMM launch (default)
+  if (mode >= 2000) {  // measurement hook: 2000 = split-K combined by a separate reduce launch (default), 2001 = inside the GEMM launch
     g_tiled_inlaunch = mode - 2000;
     return SGL_MI355_OK;
   }

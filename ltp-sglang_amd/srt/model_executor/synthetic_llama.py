@@ -342,7 +342,7 @@ class LlamaForCausalLM(nn.Module):
             wo = attn.o_proj.weight   # [K, N] column-major view of the [N, K] parameter
             if tp == 1 and m <= 64 and self.o_proj_kranges > 1 and not (mlp_scratch is not None and fw is not None and "mlp_down" in fw):
                 # o_proj as split-K partial sums straight into the add + RMSNorm + quant (no bit-identity with the per-op path:
-                # the accumulation order follows the K partition; the contract is the oracle tolerance)
+                # the accumulation order follows the K partition; the parity contract is a tolerance, tests/test_model_gpu.py)
                 o_slabs = K.fp8_linear_slabs(oq, wo.t(), m, wo.shape[1], wo.shape[0], min_kranges=self.o_proj_kranges)
                 _, hq2, hs2 = K.fused_add_rmsnorm_quant_fp8(None, residual, ln2.weight.data, ln2.variance_epsilon, slabs=o_slabs,
                                                             slab_sx=osc.view(-1), slab_sw=attn.o_proj.weight_scale.view(-1),
