@@ -318,6 +318,12 @@ def main():
         next_ids = K_argmax(step_fn(state, next_ids))
     barrier()
     elapsed = time.perf_counter() - t0
+    if world > 1 and comm._CUSTOM_AR is not None:
+        comm._CUSTOM_AR.check_error()   # a peer that missed a spin bound leaves sums unreduced: fail instead of reporting a time
+    mlp_sc = getattr(runner.model, "_mlp_scratch", {})
+    for sc in mlp_sc.values():   # persistent MLP launch (SGL_MI355_MLP_BLOCK=1): a hand-off that timed out
+        if int(sc.error_codes().abs().sum()) != 0:
+            raise SystemExit(f"[bench] rank {rank}: fp8_mlp_block hand-off timed out: {sc.error_codes().tolist()}")
     phase("decode")
     if world > 1:
         import torch.distributed as dist

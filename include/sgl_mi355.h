@@ -228,7 +228,8 @@ int sgl_mi355_fp8_gemm_force_tile(int mode);
 int sgl_mi355_fp8_gemm(const void* x, int64_t x_stride_elems, const void* w, int64_t w_stride_elems, void* y,
                        int64_t y_stride_elems, const float* scales_x, const float* scales_w, const void* bias, int M,
                        int N, int K, int out_dtype, float* workspace, int64_t workspace_floats, void* stream);
-/* Split-K of sgl_mi355_fp8_gemm at 64 < M <= 256 (the streaming tile) left to the consumer: num_slabs = how many f32 [M, N]
+/* Split-K of sgl_mi355_fp8_gemm where it runs the streaming tile with fewer tiles than CUs (64 < M <= 256 always; larger M when the
+ * 256x256 tile would leave CUs idle) left to the consumer: num_slabs = how many f32 [M, N]
  * partial sums it forms for this shape and scratch size (1: none); fp8_gemm_slabs writes them raw (no scales) for
  * sgl_mi355_fused_add_rmsnorm_quant_fp8 (slabs + sx + sw), with fp8_gemm's own k-range partition. */
 int sgl_mi355_fp8_gemm_num_slabs(int M, int N, int K, int64_t workspace_floats);

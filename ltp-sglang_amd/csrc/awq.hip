@@ -689,6 +689,7 @@ extern "C" int sgl_mi355_awq_gemm_slabs(const void* x, int64_t x_stride_elems, c
   const int prc = awq_params(p, "awq_gemm_slabs", x, x_stride_elems, qpacked, sz, slabs, N, nullptr, M, N, K, group_size, dtype);
   if (prc != SGL_MI355_OK) return prc;
   const int kranges = sgl_mi355_awq_gemm_num_kranges(M, K);
+  SGL_CHECK(kranges > 1, "awq_gemm_slabs: M=%d K=%d runs as one k-range (no slabs: the kernel would store T-typed outputs into the f32 buffer); use awq_gemm", M, K);
   return dtype == SGL_BF16 ? awq_dispatch<__bf16>(p, kranges, slabs, (hipStream_t)stream)
                            : awq_dispatch<_Float16>(p, kranges, slabs, (hipStream_t)stream);
 }

@@ -846,10 +846,28 @@ int launch128s(GemmParams& p, hipStream_t st, float* workspace, int64_t workspac
   return SGL_MI355_OK;
 }
 
-// does sgl_mi355_fp8_gemm send this fp8 problem to the streaming 128x128 tile?
-inline bool takes128s(int M, int N, int kbytes, int64_t x_stride_b, int64_t w_stride_b) {
+// Does sgl_mi355_fp8_gemm send this fp8 problem to the streaming 128x128 tile?  Always at decode-sized M (<= 256: the weights are
+// read once and bytes in flight decide).  Above that the 256x256 tile wins whenever it fills the chip, but between the two lies a
+// band (256 < M <= ~1024 with few 256-wide tiles) where it leaves CUs idle and the streaming tile, with split-K when even its
+// tiles are fewer than CUs, is up to 2x faster (tools/debug/mid_m.py, round 3: M = 1024, N = 4096, K = 14336: 79 us against 167 us
+// for 256x256 and 156 us for the old 128x128 kernel; M = 512, N = 28672, K = 4096: 100 us against 62 us for 256x256).  The choice
+// is the smaller of two measured cost lines: one round of 256x256 tiles takes 46 us per 4096 bytes of K, one round of streaming
+// tiles 24 us; a partly filled last round costs about half its share (fewer CUs contend for L2 / HBM).
+inline bool takes128s(int M, int N, int kbytes, int64_t x_stride_b, int64_t w_stride_b, bool have_workspace = true,
+                      int64_t workspace_floats = (1ll << 40)) {
   const bool can256 = kbytes % BKB == 0 && kbytes >= BKB && (int64_t)N * w_stride_b < 0xFFFFFFF0ll && (int64_t)M * x_stride_b < 0xFFFFFFF0ll;
-  return can256 && (g_tiled_force == 5 || (g_tiled_force == 0 && M <= 256));
+  if (!can256 || g_tiled_force == 5) return can256;
+  if (g_tiled_force != 0) return false;
+  if (M <= 256) return true;
+  const double cus = tg_cus(), k4 = kbytes / 4096.0;
+  const int64_t t256 = (int64_t)((M + T2 - 1) / T2) * ((N + T2 - 1) / T2), t128 = (int64_t)((M + S_BM - 1) / S_BM) * ((N + S_BN - 1) / S_BN);
+  if (t128 > 8 * (int64_t)cus) return false;   // many rounds either way: the larger tile has the higher arithmetic intensity
+  int kt_per = 0;
+  const int splits = splits128s(M, N, kbytes, have_workspace, workspace_floats > kCounterFloats ? workspace_floats - kCounterFloats : 0, &kt_per);
+  const double r = (double)t128 * splits / cus, rounds = r <= 1.0 ? 1.0 : 0.5 * (ceil(r) + r);
+  const double cost128 = rounds * 24.0 * k4 / splits + (splits > 1 ? 7.0 : 0.0);
+  const double cost256 = ceil((double)t256 / cus) * 46.0 * k4;
+  return cost128 < cost256;
 }
 
 int run(const void* x, int64_t xs, const void* w, int64_t ws, void* y, int64_t ys, const float* sx, const float* sw,
@@ -872,17 +890,17 @@ int run(const void* x, int64_t xs, const void* w, int64_t ws, void* y, int64_t y
   p.M = M; p.N = N; p.kbytes = K * es;
   hipStream_t st = (hipStream_t)stream;
   if (in_dtype == SGL_FP8_E4M3) {
-    // the 256x256 kernel wants whole 128-byte K slices and enough tiles to fill every CU at least once
-    const int64_t tiles256 = (int64_t)((M + T2 - 1) / T2) * ((N + T2 - 1) / T2);
+    // both LDS-DMA kernels want whole 128-byte K slices
     const bool can256 = p.kbytes % BKB == 0 && p.kbytes >= BKB && (int64_t)N * p.w_stride < 0xFFFFFFF0ll &&
                         (int64_t)M * p.x_stride < 0xFFFFFFF0ll;  // 32-bit buffer offsets
     // decode-sized M: the streaming tile (weights read once; bytes in flight decide)
-    if (takes128s(M, N, p.kbytes, p.x_stride, p.w_stride))
+    if (takes128s(M, N, p.kbytes, p.x_stride, p.w_stride, workspace != nullptr, workspace_floats))
       return out_dtype == SGL_BF16 ? launch128s<__bf16>(p, st, workspace, workspace_floats)
                                    : launch128s<_Float16>(p, st, workspace, workspace_floats);
     if (can256 && g_tiled_force == 4) return out_dtype == SGL_BF16 ? launch256<__bf16, 8, false>(p, st) : launch256<_Float16, 8, false>(p, st);
     if (can256 && g_tiled_force == 3) return out_dtype == SGL_BF16 ? launch256<__bf16, 4>(p, st) : launch256<_Float16, 4>(p, st);
-    if (can256 && g_tiled_force != 1 && (g_tiled_force == 2 || tiles256 >= tg_cus()))
+    // (the old 128x128 kernel is left with the shapes neither LDS-DMA kernel accepts: K not whole 128-byte slices, > 4 GiB operands)
+    if (can256 && g_tiled_force != 1)
       return out_dtype == SGL_BF16 ? launch256<__bf16, 8>(p, st) : launch256<_Float16, 8>(p, st);
     return out_dtype == SGL_BF16 ? launch<TG_FP8, __bf16>(p, st, workspace, workspace_floats)
                                  : launch<TG_FP8, _Float16>(p, st, workspace, workspace_floats);
@@ -932,9 +950,9 @@ extern "C" int sgl_mi355_fp8_gemm(const void* x, int64_t x_stride_elems, const v
 }
 
 // How many f32 [M, N] slabs sgl_mi355_fp8_gemm sums for this shape when given `workspace_floats` of scratch (1: it runs as one
-// k-range; > 1 only for the streaming tile, 64 < M <= 256 with fewer tiles than CUs).  Contiguous rows assumed.
+// k-range; > 1 only where takes128s() picks the streaming tile and its tiles are fewer than CUs).  Contiguous rows assumed.
 extern "C" int sgl_mi355_fp8_gemm_num_slabs(int M, int N, int K, int64_t workspace_floats) {
-  if (M <= 0 || N <= 0 || K <= 0 || !takes128s(M, N, K, K, K)) return 1;
+  if (M <= 0 || N <= 0 || K <= 0 || !takes128s(M, N, K, K, K, true, workspace_floats)) return 1;
   int kt_per = 0;
   return splits128s(M, N, K, true, workspace_floats > kCounterFloats ? workspace_floats - kCounterFloats : 0, &kt_per);
 }
@@ -947,7 +965,7 @@ extern "C" int sgl_mi355_fp8_gemm_slabs(const void* x, int64_t x_stride_elems, c
   SGL_CHECK(x && w && slabs && M > 0 && N > 0 && K > 0, "fp8_gemm_slabs: bad arguments");
   SGL_CHECK(K % 16 == 0 && x_stride_elems % 16 == 0 && w_stride_elems % 16 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0,
             "fp8_gemm_slabs: rows must be 16-byte aligned (K=%d)", K);
-  SGL_CHECK(takes128s(M, N, K, x_stride_elems, w_stride_elems), "fp8_gemm_slabs: M=%d N=%d K=%d is not a streaming-tile shape", M, N, K);
+  SGL_CHECK(takes128s(M, N, K, x_stride_elems, w_stride_elems, true, workspace_floats), "fp8_gemm_slabs: M=%d N=%d K=%d is not a streaming-tile shape", M, N, K);
   GemmParams p;
   p.x = (const char*)x; p.x_stride = x_stride_elems;
   p.w = (const char*)w; p.w_stride = w_stride_elems;

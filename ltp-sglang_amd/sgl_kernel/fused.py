@@ -195,6 +195,8 @@ def awq_gemm_slabs(x, qpacked, sz, group_size: int):
     m, k = x.shape
     n = sz.shape[1]
     kr = lib.sgl_mi355_awq_gemm_num_kranges(m, k)
+    if kr <= 1:   # one k-range: the kernel would take its plain-epilogue store path and write T-typed outputs into an f32 buffer
+        raise RuntimeError(f"awq_gemm_slabs: M={m} K={k} runs as one k-range (no slabs); use awq_gemm")
     out = torch.empty((kr, m, n), dtype=torch.float32, device=x.device)
     check(lib.sgl_mi355_awq_gemm_slabs(ptr(x), x.stride(0), ptr(qpacked), ptr(sz), ptr(out), m, n, k, int(group_size),
                                        dtype_code(x.dtype), current_stream()))

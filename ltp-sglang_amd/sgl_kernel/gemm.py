@@ -200,7 +200,8 @@ def fp8_linear_slabs(x_q: torch.Tensor, weight_nk: torch.Tensor, m: int, n: int,
 
 
 def fp8_gemm_num_slabs(m: int, n: int, k: int, device) -> int:
-    """How many f32 [M, N] split-K slabs fp8_scaled_mm forms for this shape at 64 < M <= 256 (the streaming tile; 1: none)."""
+    """How many f32 [M, N] split-K slabs fp8_scaled_mm forms for this shape where it runs the streaming tile (64 < M <= 256, and
+    larger M with too few 256-wide tiles to fill the chip; 1: none)."""
     if not 64 < m <= 256:
         return 1
     _, ws_n = _tiled_workspace(device)

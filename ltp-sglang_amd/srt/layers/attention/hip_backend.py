@@ -160,7 +160,9 @@ class HipAttnBackend(AttentionBackend):
             kv_indices = torch.empty(max(int(seq_lens_sum) - bs * shared_prefix_len, 1), dtype=torch.int32, device=self.device)
         K.create_kv_indices(self.req_to_token, req_pool_indices, suffix_lens, kv_indptr,
                             torch.full_like(suffix_lens, shared_prefix_len), kv_indices)
-        row0 = self.req_to_token[req_pool_indices[0], :shared_prefix_len]
+        # (index_select with a one-element device index: `req_to_token[req_pool_indices[0], ...]` resolves the 0-dim CUDA index on
+        # the host -- a device sync in every cascade step and graph replay)
+        row0 = self.req_to_token.index_select(0, req_pool_indices[:1].long())[0, :shared_prefix_len]
         if prefix_buf is None:
             prefix = row0.contiguous()
         else:   # HIP graph: the kernel arguments hold this buffer's address

@@ -499,7 +499,9 @@ class LlamaForCausalLM(nn.Module):
             else:
                 act = K.silu_and_mul(linear(mlp.gate_up_proj, h2))
             down = mlp.down_proj
-            if awq and K.awq_gemm_num_kranges(m, act.shape[1]) > 1:
+            if down.bias is not None:   # the slab hand-off into the next RMSNorm carries no bias term
+                slabs, hidden = None, linear(down, act)
+            elif awq and K.awq_gemm_num_kranges(m, act.shape[1]) > 1:
                 slabs = K.awq_gemm_slabs(act, down._awq_packed[0], down._awq_packed[1], gsz)
             elif not awq and m <= 64 and K.dense_linear_kranges(m, down.weight.shape[0], down.weight.shape[1], down.weight.dtype) > 1:
                 slabs = K.fp8_linear_slabs(act, down.weight.data, m, down.weight.shape[0], down.weight.shape[1])

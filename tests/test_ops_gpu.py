@@ -474,6 +474,24 @@ def test_fp8_scaled_mm_large_m_vs_oracle(m, n, k, out, tile_mode, sk):
     torch.testing.assert_close(o.cpu().float(), ref.float(), rtol=1.6e-2, atol=0.3)
 
 
+@pytest.mark.parametrize("m,n,k,kr_gt1", [(512, 1024, 4096, True), (320, 4096, 2048, True), (1024, 4096, 2048, False), (1000, 3000, 1152, False),
+                                           (768, 6144, 1024, False)])
+def test_fp8_scaled_mm_mid_m_dispatch_vs_oracle(m, n, k, kr_gt1, sk):
+    """256 < M <= ~1024 with too few 256-wide tiles to fill the chip: the default dispatch (csrc/tiled_gemm.hip takes128s: the smaller
+    of two measured cost lines) sends these to the streaming 128x128 tile, with split-K when even its tiles are fewer than CUs;
+    fp8_gemm_num_slabs reports the same choice, and every kernel agrees with the oracle."""
+    c = _cases.build_gemm_case(dict(m=m, n=n, k=k, bias=True, out="bf16"), seed=m + k)
+    a, wt, sa, sb, bias = (c[x].to(DEV) for x in ("a", "w", "sa", "sb", "bias"))
+    assert (sk.fp8_gemm_num_slabs(m, n, k, DEV) > 1) == kr_gt1
+    o = sk.fp8_scaled_mm(a, wt.t(), sa, sb, torch.bfloat16, bias)
+    ref = oq.scaled_mm(c["a"], c["w"].t(), c["sa"], c["sb"], torch.bfloat16, c["bias"])
+    torch.testing.assert_close(o.cpu().float(), ref.float(), rtol=1.6e-2, atol=0.3)
+    if kr_gt1:   # the consumer-side combine sees the same partition
+        slabs = sk.fp8_gemm_slabs(a, wt)
+        y = (slabs.sum(0) * sa.view(-1, 1) * sb.view(1, -1) + bias.float()).to(torch.bfloat16)
+        torch.testing.assert_close(y.float(), o.float(), rtol=1e-2, atol=0.05)
+
+
 @pytest.mark.parametrize("m,n,k", [(128, 1280, 8192), (128, 7168, 8192), (128, 8192, 3584), (200, 520, 4096), (96, 1024, 2048), (256, 384, 4096)])
 def test_streaming_tile_in_launch_splitk_combine_bit_exact(m, n, k, sk):
     """fp8_scaled_mm at 64 < M <= 256 with fewer tiles than CUs splits K over workgroups; the partial sums can be combined INSIDE

@@ -33,13 +33,20 @@ def main():
                 groups[(short(row["Kernel_Name"]), g, wg)].append(dur)
     total = sum(sum(v) for v in groups.values()) or 1
     w = csv.writer(sys.stdout)
-    w.writerow(["kernel", "grid_threads_xyz", "workgroup_xyz", "workgroups", "calls", "avg_us", "min_us", "max_us", "total_ms", "pct"])
+    # main_*: the launches that last at least half the median -- a kernel's graph-capture warm-ups (one-token sequences) share the
+    # geometry of its in-model launches and can only be told apart by their duration
+    w.writerow(["kernel", "grid_threads_xyz", "workgroup_xyz", "workgroups", "calls", "avg_us", "median_us", "min_us", "max_us", "main_calls",
+                "main_avg_us", "total_ms", "pct"])
     for (name, g, wg), v in sorted(groups.items(), key=lambda kv: -sum(kv[1])):
         nwg = 1
         for a, b in zip(g, wg):
             nwg *= max(1, a // max(1, b))
-        w.writerow([name, "x".join(map(str, g)), "x".join(map(str, wg)), nwg, len(v), f"{sum(v) / len(v) / 1e3:.2f}", f"{min(v) / 1e3:.2f}",
-                    f"{max(v) / 1e3:.2f}", f"{sum(v) / 1e6:.3f}", f"{100.0 * sum(v) / total:.2f}"])
+        sv = sorted(v)
+        med = sv[len(sv) // 2]
+        main = [x for x in v if 2 * x >= med]
+        w.writerow([name, "x".join(map(str, g)), "x".join(map(str, wg)), nwg, len(v), f"{sum(v) / len(v) / 1e3:.2f}", f"{med / 1e3:.2f}",
+                    f"{min(v) / 1e3:.2f}", f"{max(v) / 1e3:.2f}", len(main), f"{sum(main) / len(main) / 1e3:.2f}", f"{sum(v) / 1e6:.3f}",
+                    f"{100.0 * sum(v) / total:.2f}"])
 
 
 if __name__ == "__main__":
