@@ -206,6 +206,18 @@ def main():
                 gathered = car.all_gather_last_dim(shard)
                 car.check_error()
                 ok = ok and all(bool((gathered[:, r * 64:(r + 1) * 64] == float(r)).all()) for r in range(world))
+                if ok:   # the form the decode step uses: all-reduce + residual add + RMSNorm + per-token fp8 quant in one launch
+                    from ltp_sglang_amd.sgl_kernel import fused_add_rmsnorm_quant_fp8
+
+                    gw = (1 + 0.1 * torch.randn(4096, device=dev, generator=torch.Generator(device=dev).manual_seed(7))).to(torch.bfloat16)
+                    res0 = torch.randn(32, 4096, device=dev, generator=torch.Generator(device=dev).manual_seed(11)).to(torch.bfloat16)
+                    r1, r2 = res0.clone(), res0.clone()
+                    n1, _, s1 = fused_add_rmsnorm_quant_fp8(want.to(torch.bfloat16), r1, gw, 1e-5, want_norm=True)
+                    n2, _, s2 = car.all_reduce_add_rmsnorm_quant(probe.clone(), r2, gw, 1e-5, want_norm=True)
+                    car.check_error()
+                    ok = (bool(((n2.float() - n1.float()).abs() <= 0.03 * n1.float().abs() + 0.06).all())
+                          and bool(((r2.float() - r1.float()).abs() <= 0.03 * r1.float().abs() + 0.06).all())
+                          and bool(((s2 - s1).abs() <= 0.03 * s1.abs() + 1e-6).all()))
                 why = "" if ok else "self-check against RCCL failed"
         except Exception as e:   # IPC not available between these devices, driver limits, ...
             ok, why = False, f"{type(e).__name__}: {e}"
@@ -213,7 +225,7 @@ def main():
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)   # all ranks or none
         if int(flag.item()) == 1:
             comm.set_custom_all_reduce(car)
-            ar_kind = "p2p-one-shot"
+            ar_kind = "p2p (one-shot below the reference's size rule, two-stage above; fused with add + RMSNorm + quant)"
         elif args.all_reduce == "p2p":
             raise SystemExit(f"[bench] rank {rank}: --all-reduce p2p requested but unusable ({why or 'a peer failed'})")
         elif rank == 0:

@@ -851,7 +851,7 @@ int launch128s(GemmParams& p, hipStream_t st, float* workspace, int64_t workspac
 // band (256 < M <= ~1024 with few 256-wide tiles) where it leaves CUs idle and the streaming tile, with split-K when even its
 // tiles are fewer than CUs, is up to 2x faster (tools/debug/mid_m.py, round 3: M = 1024, N = 4096, K = 14336: 79 us against 167 us
 // for 256x256 and 156 us for the old 128x128 kernel; M = 512, N = 28672, K = 4096: 100 us against 62 us for 256x256).  The choice
-// is the smaller of two measured cost lines: one round of 256x256 tiles takes 46 us per 4096 bytes of K, one round of streaming
+// is the smaller of two measured cost lines: one round of 256x256 tiles takes 46-50 us per 4096 bytes of K, one round of streaming
 // tiles 24 us; a partly filled last round costs about half its share (fewer CUs contend for L2 / HBM).
 inline bool takes128s(int M, int N, int kbytes, int64_t x_stride_b, int64_t w_stride_b, bool have_workspace = true,
                       int64_t workspace_floats = (1ll << 40)) {
@@ -866,7 +866,7 @@ inline bool takes128s(int M, int N, int kbytes, int64_t x_stride_b, int64_t w_st
   const int splits = splits128s(M, N, kbytes, have_workspace, workspace_floats > kCounterFloats ? workspace_floats - kCounterFloats : 0, &kt_per);
   const double r = (double)t128 * splits / cus, rounds = r <= 1.0 ? 1.0 : 0.5 * (ceil(r) + r);
   const double cost128 = rounds * 24.0 * k4 / splits + (splits > 1 ? 7.0 : 0.0);
-  const double cost256 = ceil((double)t256 / cus) * 46.0 * k4;
+  const double cost256 = ceil((double)t256 / cus) * 49.0 * k4;
   return cost128 < cost256;
 }
 

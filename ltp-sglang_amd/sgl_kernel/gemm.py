@@ -202,14 +202,14 @@ def fp8_linear_slabs(x_q: torch.Tensor, weight_nk: torch.Tensor, m: int, n: int,
 def fp8_gemm_num_slabs(m: int, n: int, k: int, device) -> int:
     """How many f32 [M, N] split-K slabs fp8_scaled_mm forms for this shape where it runs the streaming tile (64 < M <= 256, and
     larger M with too few 256-wide tiles to fill the chip; 1: none)."""
-    if not 64 < m <= 256:
+    if m <= 64:
         return 1
     _, ws_n = _tiled_workspace(device)
     return int(lib.sgl_mi355_fp8_gemm_num_slabs(int(m), int(n), int(k), ws_n))
 
 
 def fp8_gemm_slabs(x_q: torch.Tensor, weight_nk: torch.Tensor) -> torch.Tensor:
-    """The 64 < M <= 256 form of fp8_linear_slabs: raw f32 partial sums [S, M, N] of fp8_scaled_mm's streaming tile, with its
+    """The M > 64 form of fp8_linear_slabs: raw f32 partial sums [S, M, N] of fp8_scaled_mm's streaming tile, with its
     own k-range partition (so the consumer's sum equals fp8_scaled_mm's); requires fp8_gemm_num_slabs(...) > 1."""
     _cuda(x_q, weight_nk)
     assert x_q.dtype == torch.float8_e4m3fn and weight_nk.dtype == torch.float8_e4m3fn

@@ -772,9 +772,9 @@ def test_dense_slabs_into_norm_bit_exact(m, n, k, dtype, sk):
     assert torch.equal(r1, r2) and torch.equal(out, y)
 
 
-@pytest.mark.parametrize("m,n,k", [(128, 4096, 4096), (128, 8192, 3584), (96, 1280, 8192), (200, 2048, 2048)])
+@pytest.mark.parametrize("m,n,k", [(128, 4096, 4096), (128, 8192, 3584), (96, 1280, 8192), (200, 2048, 2048), (512, 4096, 4096), (320, 1024, 8192)])
 def test_streaming_tile_slabs_into_norm_bit_exact(m, n, k, sk):
-    """64 < M <= 256: fp8_scaled_mm's split-K partial sums handed raw to add + RMSNorm + quant == fp8_scaled_mm -> the same op."""
+    """64 < M <= 256 (and larger M where the dispatch keeps the streaming tile with split-K): fp8_scaled_mm's split-K partial sums handed raw to add + RMSNorm + quant == fp8_scaled_mm -> the same op."""
     c = _cases.build_gemm_case(dict(m=m, n=n, k=k, bias=False, out="bf16"), seed=m + n)
     a, wt, sa, sb = c["a"].to(DEV), c["w"].to(DEV), c["sa"].to(DEV) * 3, c["sb"].to(DEV) * 3
     g = torch.Generator().manual_seed(k)
