@@ -308,18 +308,25 @@ def main():
     # ---- decode: W warm-up + K timed steps ----
     use_graph = not args.no_graph
     if use_graph:
+        why = ""
         try:
             runner.capture_decode_graph(bs)
         except Exception as e:
-            if world > 1 and args.dist_backend == "nccl":
-                # the measured N > 1 configuration is the graph-captured step: an eager fallback would silently report a
-                # different (launch-bound) number, so fail instead
-                print(f"[bench] rank {rank}: HIP-graph capture of the decode step failed under RCCL "
-                      f"({type(e).__name__}: {e})", file=sys.stderr)
-                raise SystemExit(3)
-            if rank == 0:   # gloo rehearsal (host-staged collectives cannot be captured): eager by design
-                print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            why = f"{type(e).__name__}: {e}"
             use_graph = False
+        if world > 1:
+            # all ranks replay the graph or none does (a rank that alone fell back to eager launches would still match its peers'
+            # collectives one for one, but the job's time would be that rank's): agree over the process group
+            import torch.distributed as dist
+
+            flag = torch.tensor([1 if use_graph else 0], device=dev if args.dist_backend == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            use_graph = bool(int(flag.item()))
+        if not use_graph and rank == 0:
+            # stated, not silent: config.hip_graph in the JSON line is false and the step is launch-bound (gloo rehearsal: host-staged
+            # collectives cannot be captured, eager by design)
+            print(f"[bench] HIP-graph capture of the decode step not used ({why or 'a peer rank could not capture'}); timing eager steps",
+                  file=sys.stderr)
     phase("capture")
     step_fn = runner.decode_graph if use_graph else runner.decode
     for _ in range(args.warmup):
