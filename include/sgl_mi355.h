@@ -318,6 +318,9 @@ int sgl_mi355_fp8_mlp_block(const void* x, void* residual, const void* ln_weight
                             const float* scales_gate_up_interleaved, const void* w_down, float* out_slabs, float* act_scales,
                             void* xq_scratch, float* xs_scratch, void* actq_scratch, void* pmax_scratch, void* sync, int M,
                             int hidden, int inter, int dtype, long long* timeline, void* stream);
+/* Measurement / test hook for sgl_mi355_silu_and_mul_quant_fp8: 1 (default) = prefill-sized bf16 launches (tokens >= 1024) take the
+ * kernel that tabulates T(silu(a)) over a's 16 bits in LDS (bit-identical by construction), 0 = always the exact-expression kernel. */
+int sgl_mi355_silu_and_mul_quant_set_mode(int table);
 /* silu_and_mul (activation.py:60-63) -> sgl_per_token_quant_fp8 */
 int sgl_mi355_silu_and_mul_quant_fp8(const void* x, void* out_q, float* out_s, int tokens, int d, int dtype, void* stream);
 /* rotary_embedding (rotary_embedding.py:138-165) on q, k in place -> set_kv_buffer (memory_pool.py:369-407) of (k, v) */

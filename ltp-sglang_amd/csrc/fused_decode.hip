@@ -149,6 +149,84 @@ __global__ __launch_bounds__(256) void silu_mul_quant_kernel(const T* x, uint8_t
   quant_row<MAXV>(vals, nvec, out_q + row * d, out_s + row, red);
 }
 
+// Prefill-sized form for bf16 (round 3).  The exact silu -- expf + IEEE division, ~25 of the kernel's ~40 VALU instructions per
+// element -- makes silu_mul_quant_kernel VALU-bound at 65 536 x 14 336 (1.03 ms for 4.7 GB = 4.6 TB/s; add_rmsnorm_quant moves
+// its bytes at 6.3).  T(silu(a)) is a function of a's 16 bits: every workgroup tabulates it ONCE with the exact expression above
+// (so the table cannot differ from it), 2 x 37 exponents x 128 mantissas = 9 472 entries = 18.5 KiB of LDS covering 2^-30 <= |a|
+// < 128, and walks `rows_per_wg` rows with one ds_read_u16 per element; anything outside the table (zeros, denormals, tiny or
+// huge values, inf, nan) takes the exact expression.  Bit-identical to silu_mul_quant_kernel by construction.
+constexpr int kSiluE0 = 97, kSiluNE = 37;
+constexpr int kSiluHalf = kSiluNE * 128, kSiluLut = 2 * kSiluHalf;
+
+template <int MAXV>
+__global__ __launch_bounds__(256) void silu_mul_quant_lut_kernel(const __bf16* x, uint8_t* out_q, float* out_s, int d, int tokens,
+                                                                 int rows_per_wg) {
+  using T = __bf16;
+  __shared__ float red[4];
+  __shared__ uint16_t lut[kSiluLut];
+  for (int i = threadIdx.x; i < kSiluLut; i += 256) {
+    const int sgn = i >= kSiluHalf, r = i - sgn * kSiluHalf;
+    const uint16_t bits = (uint16_t)((sgn << 15) | (((r >> 7) + kSiluE0) << 7) | (r & 127));
+    const float af = (float)__builtin_bit_cast(T, bits);
+    const float sI = round_via<T>(af / (1.0f + expf(-af)));
+    lut[i] = __builtin_bit_cast(uint16_t, (T)sI);
+  }
+  __syncthreads();
+  const int nvec = d / 8;
+  const int row_end = min(tokens, ((int)blockIdx.x + 1) * rows_per_wg);
+  for (int64_t row = (int64_t)blockIdx.x * rows_per_wg; row < row_end; ++row) {
+    float vals[MAXV][8];
+#pragma unroll
+    for (int it = 0; it < MAXV; ++it) {
+      const int i = threadIdx.x + it * 256;
+      if (i < nvec) {
+        const V8<T> a = ld8(x + row * 2 * d + i * 8), b = ld8(x + row * 2 * d + d + i * 8);
+        // eight lookups in flight behind ONE wait; a wave with any element outside the table (rare: zeros, tiny / huge values)
+        // evaluates the exact expression for the whole vector -- a wave-uniform branch, not a per-element exec mask (with the test
+        // per element every ds_read was waited for on its own)
+        uint32_t rel[8];
+        bool outside = false;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const uint32_t ab = __builtin_bit_cast(uint16_t, a.v[j]);
+          rel[j] = (ab & 0x7FFFu) - (uint32_t)(kSiluE0 << 7);   // wraps to a huge value below the table
+          outside = outside || rel[j] >= (uint32_t)kSiluHalf;
+          rel[j] += (ab >> 15) * kSiluHalf;
+        }
+        float sI[8];
+        if (__any(outside)) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float af = (float)a.v[j];
+            sI[j] = round_via<T>(af / (1.0f + expf(-af)));
+          }
+        } else {
+          uint16_t e[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) e[j] = lut[rel[j]];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) sI[j] = __uint_as_float((uint32_t)e[j] << 16);
+        }
+        // T(sI * b): the products as f32 first (an empty asm keeps them from being folded into a mixed-precision fma), rounded in
+        // pairs by v_cvt_pk_bf16_f32 and widened again by a shift -- round_via's v_mov per value is what the exact kernel spends here
+        V8<T> pr;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float m = sI[j] * (float)b.v[j];
+          asm volatile("" : "+v"(m));
+          pr.v[j] = (T)m;
+        }
+        u32x4_t pw = __builtin_bit_cast(u32x4_t, pr);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(pw[q]));   // the rounded bits exist as such
+#pragma unroll
+        for (int j = 0; j < 8; ++j) vals[it][j] = __uint_as_float((j & 1) ? (pw[j >> 1] & 0xFFFF0000u) : (pw[j >> 1] << 16));
+      }
+    }
+    quant_row<MAXV>(vals, nvec, out_q + row * d, out_s + row, red);
+  }
+}
+
 // one workgroup per token: rotate q (in place) and k (in place + into the pool), copy v into the pool
 template <typename T>
 __global__ __launch_bounds__(256) void rope_set_kv_kernel(const int64_t* positions, T* q, T* k, const T* v, const float* cache,
@@ -327,6 +405,12 @@ extern "C" int sgl_mi355_fused_add_rmsnorm_quant_fp8(const void* x, const float*
   return SGL_MI355_OK;
 }
 
+int g_silu_lut = 1;   // measurement hook: 0 = always the exact-expression kernel
+extern "C" int sgl_mi355_silu_and_mul_quant_set_mode(int table) {
+  g_silu_lut = table ? 1 : 0;
+  return SGL_MI355_OK;
+}
+
 extern "C" int sgl_mi355_silu_and_mul_quant_fp8(const void* x, void* out_q, float* out_s, int tokens, int d, int dtype,
                                                 void* stream) {
   SGL_CHECK(tokens >= 0 && d > 0, "silu_and_mul_quant_fp8: bad shape");
@@ -335,6 +419,17 @@ extern "C" int sgl_mi355_silu_and_mul_quant_fp8(const void* x, void* out_q, floa
   SGL_CHECK(d % 8 == 0 && d <= 32768, "silu_and_mul_quant_fp8: d=%d must be a multiple of 8 and <= 32768", d);
   SGL_CHECK(dtype == SGL_BF16 || dtype == SGL_F16, "silu_and_mul_quant_fp8: dtype must be bf16 or f16");
   hipStream_t st = (hipStream_t)stream;
+  if (dtype == SGL_BF16 && tokens >= 1024 && g_silu_lut) {   // prefill-sized: the table pays for itself from a few rows per workgroup on
+    int rpw = tokens / 2048;
+    rpw = rpw < 4 ? 4 : (rpw > 32 ? 32 : rpw);
+    const unsigned grid = (unsigned)((tokens + rpw - 1) / rpw);
+    if (d <= 16384)
+      hipLaunchKernelGGL((silu_mul_quant_lut_kernel<8>), dim3(grid), dim3(256), 0, st, (const __bf16*)x, (uint8_t*)out_q, out_s, d, tokens, rpw);
+    else
+      hipLaunchKernelGGL((silu_mul_quant_lut_kernel<16>), dim3(grid), dim3(256), 0, st, (const __bf16*)x, (uint8_t*)out_q, out_s, d, tokens, rpw);
+    SGL_HIP_LAUNCH_CHECK();
+    return SGL_MI355_OK;
+  }
   DISPATCH_HALF(dtype, {
     if (d <= 16384)
       hipLaunchKernelGGL((silu_mul_quant_kernel<T, 8>), dim3(tokens), dim3(256), 0, st, (const T*)x, (uint8_t*)out_q, out_s, d);

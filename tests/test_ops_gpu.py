@@ -622,6 +622,37 @@ def test_silu_and_mul_quant_bit_exact(dtype, sk):
     assert torch.equal(s1, s2) and torch.equal(q1.view(torch.uint8), q2.view(torch.uint8))
 
 
+@pytest.mark.parametrize("tokens,d", [(1024, 14336), (2051, 1408), (4096, 18944)])
+def test_silu_and_mul_quant_prefill_table_form_bit_exact(tokens, d, sk):
+    """Prefill-sized bf16 launches tabulate T(silu(a)) over a's 16 bits (csrc/fused_decode.hip, silu_mul_quant_lut_kernel): the same bits
+    as silu_and_mul -> sgl_per_token_quant_fp8 and as the exact-expression kernel, including everything outside the table (zeros of
+    both signs, denormals, |a| < 2^-30, |a| >= 128, +-inf) and the table's edges; NaN inputs give NaN scales on both paths."""
+    from ltp_sglang_amd import _cabi
+    g = torch.Generator().manual_seed(tokens + d)
+    x = (torch.randn(tokens, 2 * d, generator=g) * 2).to(torch.bfloat16)
+    edge = torch.tensor([0.0, -0.0, 1e-40, -1e-40, 2.0 ** -31, -(2.0 ** -31), 2.0 ** -30, -(2.0 ** -30), 127.5, -127.5, 128.0, -128.0, 3e4, -3e4,
+                         88.0, -88.0, 89.0, -89.0, float("inf"), float("-inf"), 1e-9, -1e-9, 6e-5, -6e-5], dtype=torch.float32).to(torch.bfloat16)
+    x[0, : edge.numel()] = edge                       # gate values
+    x[0, d : d + edge.numel()] = 1.5                  # their multipliers
+    x[1, :d] = (torch.arange(d) % 300 - 150).float().to(torch.bfloat16) * 0.9   # a sweep through the exponents around 1 .. 128
+    x[2] = x[2] * 1e-7                                # a whole row below the table
+    x = x.to(DEV)
+    act = sk.silu_and_mul(x)
+    q1 = torch.empty(tokens, d, dtype=torch.float8_e4m3fn, device=DEV)
+    s1 = torch.empty(tokens, 1, dtype=torch.float32, device=DEV)
+    sk.sgl_per_token_quant_fp8(act, q1, s1)
+    q2, s2 = sk.silu_and_mul_quant_fp8(x)
+    try:
+        _cabi.check(_cabi.lib.sgl_mi355_silu_and_mul_quant_set_mode(0))
+        q3, s3 = sk.silu_and_mul_quant_fp8(x)
+    finally:
+        _cabi.lib.sgl_mi355_silu_and_mul_quant_set_mode(1)
+    ok = ~torch.isnan(s1.view(-1))                    # (row 0 holds inf * 1.5 -> its scale is inf / nan on every path alike)
+    assert torch.equal(torch.isnan(s1), torch.isnan(s2)) and torch.equal(s1[ok], s2[ok]) and torch.equal(s1[ok], s3[ok])
+    assert torch.equal(q1.view(torch.uint8)[ok], q2.view(torch.uint8)[ok]) and torch.equal(q1.view(torch.uint8)[ok], q3.view(torch.uint8)[ok])
+    assert int(ok.sum()) >= tokens - 1
+
+
 @pytest.mark.parametrize("case", _cases.ROPE_CASES, ids=lambda c: c["name"])
 def test_rope_set_kv_bit_exact(case, sk, golden):
     g = golden("elementwise")
