@@ -219,7 +219,13 @@ __global__ __launch_bounds__(256) void per_token_quant_row_kernel(const T* __res
 
 template <typename T>
 int launch_per_token(const void* in, void* q, float* s, int64_t tokens, int64_t hidden, int64_t in_stride, hipStream_t st) {
-  if (tokens <= 512 && hidden <= 256 * 8 * 8 && in_stride % 8 == 0 && ((uintptr_t)in % 16) == 0) {
+#ifndef SGL_QUANT_ROW_WIDE
+#define SGL_QUANT_ROW_WIDE 1
+#endif
+  // the register-resident row kernel: decode-sized batches, and (round 3) any batch of WIDE rows -- the general kernel walks a row
+  // twice with one wave (the second pass out of L2); at 65 536 x 14 336 it moved its 2.8 GB in 790 us = 3.6 TB/s
+  const bool wide = SGL_QUANT_ROW_WIDE && hidden >= 4096;
+  if ((tokens <= 512 || wide) && tokens < (1ll << 31) && hidden <= 256 * 8 * 8 && in_stride % 8 == 0 && ((uintptr_t)in % 16) == 0) {
     if (hidden <= 256 * 8 * 2)
       hipLaunchKernelGGL((per_token_quant_row_kernel<T, 2>), dim3((unsigned)tokens), dim3(256), 0, st, (const T*)in, (uint8_t*)q, s,
                          (int)hidden, in_stride);

@@ -11,6 +11,7 @@
 //       (decode_attention.py:492-552)
 // All HBM/L2-bound byte work: one 256-thread workgroup per token, 16-byte accesses.
 #include "row_helpers.h"
+#include "silu_lut.h"
 
 namespace {
 
@@ -155,8 +156,6 @@ __global__ __launch_bounds__(256) void silu_mul_quant_kernel(const T* x, uint8_t
 // (so the table cannot differ from it), 2 x 37 exponents x 128 mantissas = 9 472 entries = 18.5 KiB of LDS covering 2^-30 <= |a|
 // < 128, and walks `rows_per_wg` rows with one ds_read_u16 per element; anything outside the table (zeros, denormals, tiny or
 // huge values, inf, nan) takes the exact expression.  Bit-identical to silu_mul_quant_kernel by construction.
-constexpr int kSiluE0 = 97, kSiluNE = 37;
-constexpr int kSiluHalf = kSiluNE * 128, kSiluLut = 2 * kSiluHalf;
 
 template <int MAXV>
 __global__ __launch_bounds__(256) void silu_mul_quant_lut_kernel(const __bf16* x, uint8_t* out_q, float* out_s, int d, int tokens,
@@ -164,13 +163,7 @@ __global__ __launch_bounds__(256) void silu_mul_quant_lut_kernel(const __bf16* x
   using T = __bf16;
   __shared__ float red[4];
   __shared__ uint16_t lut[kSiluLut];
-  for (int i = threadIdx.x; i < kSiluLut; i += 256) {
-    const int sgn = i >= kSiluHalf, r = i - sgn * kSiluHalf;
-    const uint16_t bits = (uint16_t)((sgn << 15) | (((r >> 7) + kSiluE0) << 7) | (r & 127));
-    const float af = (float)__builtin_bit_cast(T, bits);
-    const float sI = round_via<T>(af / (1.0f + expf(-af)));
-    lut[i] = __builtin_bit_cast(uint16_t, (T)sI);
-  }
+  for (int i = threadIdx.x; i < kSiluLut; i += 256) lut[i] = silu_lut_entry(i);
   __syncthreads();
   const int nvec = d / 8;
   const int row_end = min(tokens, ((int)blockIdx.x + 1) * rows_per_wg);
@@ -188,17 +181,14 @@ __global__ __launch_bounds__(256) void silu_mul_quant_lut_kernel(const __bf16* x
         bool outside = false;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const uint32_t ab = __builtin_bit_cast(uint16_t, a.v[j]);
-          rel[j] = (ab & 0x7FFFu) - (uint32_t)(kSiluE0 << 7);   // wraps to a huge value below the table
-          outside = outside || rel[j] >= (uint32_t)kSiluHalf;
-          rel[j] += (ab >> 15) * kSiluHalf;
+          rel[j] = silu_lut_index(__builtin_bit_cast(uint16_t, a.v[j]));
+          outside = outside || rel[j] >= (uint32_t)kSiluLut;
         }
         float sI[8];
         if (__any(outside)) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            const float af = (float)a.v[j];
-            sI[j] = round_via<T>(af / (1.0f + expf(-af)));
+            sI[j] = silu_exact_bf16((float)a.v[j]);
           }
         } else {
           uint16_t e[8];

@@ -17,6 +17,9 @@
 #include "common.h"
 #include "gemm_epilogue.h"
 
+int sgl_mi355_internal_tiled_gemm_silu_mul(const void* x, int64_t x_stride_b, const void* w, int64_t w_stride_b, void* act,
+                                           int64_t act_stride, const float* sx, const float* sw, int M, int N, int K, hipStream_t st);
+
 namespace {
 
 struct SkinnyParams {
@@ -704,6 +707,14 @@ extern "C" int sgl_mi355_gemm_silu_mul(const void* x, int64_t x_stride_elems, co
                                        const float* scales_w_interleaved, int M, int N, int K, int in_dtype, int out_dtype,
                                        int tile_rows, void* stream) {
   SGL_CHECK(x && w_interleaved && act, "gemm_silu_mul: null pointer");
+  if (M > 64) {   // prefill-sized: the 256x256 tile with the SiluAndMul epilogue (tiled_gemm.hip)
+    SGL_CHECK(in_dtype == SGL_FP8_E4M3 && out_dtype == SGL_BF16 && tile_rows == 16 && scales_x && scales_w_interleaved,
+              "gemm_silu_mul: M > 64 takes fp8 operands with both scale vectors, a bf16 result and 16-row interleaving");
+    SGL_CHECK(x_stride_elems % 16 == 0 && w_stride_elems % 16 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)w_interleaved % 16) == 0,
+              "gemm_silu_mul: rows must be 16-byte aligned");
+    return sgl_mi355_internal_tiled_gemm_silu_mul(x, x_stride_elems, w_interleaved, w_stride_elems, act, act_stride_elems, scales_x,
+                                                  scales_w_interleaved, M, N, K, (hipStream_t)stream);
+  }
   SkinnyParams p;
   p.x = (const char*)x; p.x_stride = x_stride_elems; p.w = (const char*)w_interleaved; p.w_stride = w_stride_elems;
   p.y = act; p.y_stride = act_stride_elems; p.sx = scales_x; p.sw = scales_w_interleaved; p.bias = nullptr;

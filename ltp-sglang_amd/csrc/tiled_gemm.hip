@@ -9,6 +9,7 @@
 // swizzle so the ds_read_b128 fragment reads are bank-conflict free, XCD-aware bijective block remap so the
 // workgroups that share an X row panel run on the same XCD (one L2).
 #include "common.h"
+#include "silu_lut.h"
 #include <type_traits>
 
 namespace {
@@ -29,6 +30,7 @@ struct GemmParams {
   float* slabs;  // split-K (128x128 kernel, blockIdx.y = K range of `kt_per` slices): raw f32 sums [splits][M][N], else NULL
   int kt_per;
   int* counters = nullptr;  // streaming tile, in-launch split-K combine: two words per output tile (arrivals, departures), zero between launches
+  const uint16_t* silu_lut = nullptr;  // SiluAndMul epilogue of the 256x256 kernel: the table of silu_lut.h in global memory
   int stagger_q, stagger_cus;  // 256x256 kernel: start stagger of each CU's first workgroup (quantum in 1024-cycle units; CU count)
 #ifdef SGL_GEMM_TIMELINE
   long long* tl;  // tools/microbench/gemm256_timeline.hip: s_memtime stamps of workgroup 0, slices 8..11
@@ -357,9 +359,102 @@ __device__ __forceinline__ void epilogue_scaled_lds(const GemmParams& p, const f
   }
 }
 
+// gate_up_proj + SiluAndMul (models/llama.py:94-96, activation.py:60-63) as the epilogue of the 256x256 kernel (round 3): W's rows
+// are interleaved in 16-row tiles (8 gate rows, 8 up rows: the packing of the decode path's fused kernel, sgl_kernel.fused.
+// interleave_gate_up_rows), so an MFMA column block holds gate columns on lanes g = 0, 1 and the up columns of the same indices on
+// lanes g = 2, 3.  Per value exactly the unfused sequence: y = bf16(acc * sx[m] * sw[n]) (fp8_scaled_mm's epilogue), s = bf16(silu(
+// y_gate)) through the table of silu_lut.h (exact expression outside it), act = bf16(s * y_up).  The rounded y travel as bf16 pairs
+// through ONE v_permlane32_swap per two column blocks (lower half-wave: its own gate + the upper half's up of the even block; upper
+// half-wave: the lower half's gate of the odd block + its own up), the 256 x 128 act tile is staged in LDS (256-byte rows, 16-byte
+// chunks XOR-swizzled by the row) and leaves as whole rows with non-temporal stores.  With the exact silu in this place the
+// epilogue cost more than the separate kernel it replaces (round 1: -4 %); the table is what makes it pay.  Needs N % 256 == 0.
+constexpr int kSiluLdsOff = 2 * 2 * 256 * 128;   // the table sits above the two 64 KiB operand buffers for the whole launch
+template <typename OutT>
+__device__ __forceinline__ void epilogue_silu_lds(const GemmParams& p, const f32x4_t (&acc)[4][8], int m0, int wm, int n0, int wn, char* smem,
+                                                  int tid, int lane) {
+  static_assert(sizeof(OutT) == 2 && !__is_same(OutT, _Float16), "the table is over bf16 bits");
+  const int a = lane & 15, g = lane >> 4;
+  const uint16_t* lut = (const uint16_t*)(smem + kSiluLdsOff);   // copied there at kernel entry, under the first slice's flight
+  float sxv[8], swv[4][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) sxv[i] = p.sx ? p.sx[min(m0 + wm + a + 16 * i, p.M - 1)] : 1.0f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) swv[j][r] = p.sw ? p.sw[n0 + wn + 16 * j + 4 * g + r] : 1.0f;
+  // y = OutT(acc * sx * sw + 0): the arithmetic of epilogue_scaled, packed as bf16 pairs (r = 0, 1 | r = 2, 3)
+  uint32_t yp[4][8][2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float v0 = acc[j][i][2 * h] * sxv[i], v1 = acc[j][i][2 * h + 1] * sxv[i];
+        v0 = v0 * swv[j][2 * h] + 0.0f;
+        v1 = v1 * swv[j][2 * h + 1] + 0.0f;
+        struct P2 { OutT lo, hi; };
+        yp[j][i][h] = __builtin_bit_cast(uint32_t, P2{(OutT)v0, (OutT)v1});
+      }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int row = wm + 16 * i + a;
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+      uint32_t gt[2], up[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        // x = even block, y = odd block: afterwards lanes 0-31 hold (gate, up) of the even block, lanes 32-63 of the odd block
+        const auto sw2 = __builtin_amdgcn_permlane32_swap(yp[2 * jp][i][h], yp[2 * jp + 1][i][h], false, false);
+        gt[h] = sw2[0];
+        up[h] = sw2[1];
+      }
+      uint32_t idx[4];
+      bool outside = false;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        idx[r] = silu_lut_index((r & 1) ? gt[r >> 1] >> 16 : gt[r >> 1] & 0xFFFFu);
+        outside = outside || idx[r] >= (uint32_t)kSiluLut;
+      }
+      float sI[4];
+      if (__any(outside)) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sI[r] = silu_exact_bf16(__uint_as_float((r & 1) ? gt[r >> 1] & 0xFFFF0000u : gt[r >> 1] << 16));
+      } else {
+        uint16_t e[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) e[r] = lut[idx[r]];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sI[r] = __uint_as_float((uint32_t)e[r] << 16);
+      }
+      uint32_t o[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float m0v = sI[2 * h] * __uint_as_float(up[h] << 16), m1v = sI[2 * h + 1] * __uint_as_float(up[h] & 0xFFFF0000u);
+        asm volatile("" : "+v"(m0v), "+v"(m1v));   // f32 products first: no mixed-precision fma shortcut (the reference rounds twice)
+        struct P2 { OutT lo, hi; };
+        o[h] = __builtin_bit_cast(uint32_t, P2{(OutT)m0v, (OutT)m1v});
+      }
+      // act column (within the tile's 128) = wn / 2 + 16 jp + 4 g + r  ->  byte wn + 32 jp + 8 g of the 256-byte row
+      const int c = (wn >> 4) + 2 * jp + (g >> 1);
+      *(u32x2_t*)(smem + row * 256 + ((c ^ (row & 15)) << 4) + ((g & 1) << 3)) = u32x2_t{o[0], o[1]};
+    }
+  }
+  __syncthreads();
+  const int pos = tid & 15, r0 = tid >> 4;   // 16 lanes per row, 32 rows per pass
+  OutT* ybase = (OutT*)p.y + (n0 >> 1);
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int row = 32 * it + r0;
+    const u32x4_t v = *(const u32x4_t*)(smem + row * 256 + (pos << 4));
+    const int m = m0 + row;
+    if (m < p.M) __builtin_nontemporal_store(v, (u32x4_t*)(ybase + (int64_t)m * p.y_stride + 8 * (pos ^ (row & 15))));
+  }
+}
+
 // ES: TG_FP8 (block-scaled MFMA over the whole 128-byte slice) or TG_BF16 / TG_F16 (two 16x16x32 k-steps per slice: the
 // same LDS reads, chunk 4 h + g being exactly k-step h's fragment)
-template <typename OutT, int NWV, bool DMA = true, int ES = TG_FP8>  // NWV = 8: waves 2 (M) x 4 (N), 128 x 64 outputs each; 4: 2 x 2
+template <typename OutT, int NWV, bool DMA = true, int ES = TG_FP8, bool SILU = false>  // NWV = 8: waves 2 (M) x 4 (N), 128 x 64 outputs each; 4: 2 x 2
 __global__ __launch_bounds__(NWV * 64, 1) void fp8_gemm256_kernel(const GemmParams p) {
   constexpr int WCOLS = NWV == 8 ? 4 : 2;     // waves along N
   constexpr int JN = 256 / WCOLS / 16;        // 16-column W fragments per wave
@@ -478,6 +573,9 @@ __global__ __launch_bounds__(NWV * 64, 1) void fp8_gemm256_kernel(const GemmPara
   };
   if constexpr (DMA) {
     stage(0, 0);
+    if constexpr (SILU) {   // the silu table -> LDS once per workgroup, behind the first slice's DMA
+      for (int i = tid; i < kSiluLut / 8; i += NWV * 64) *(u32x4_t*)(smem + kSiluLdsOff + 16 * i) = *(const u32x4_t*)(p.silu_lut + 8 * i);
+    }
     __syncthreads();
     stage(min(1, nk - 1), 1);
     load_w(0, 0);
@@ -535,6 +633,11 @@ __global__ __launch_bounds__(NWV * 64, 1) void fp8_gemm256_kernel(const GemmPara
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may be in flight when the workgroup ends
 
   // ---- epilogue: acc[j][i][r] -> row m0+wm+16i+a, col n0+wn+16j+4g+r ----
+  if constexpr (SILU) {
+    __syncthreads();  // every wave is past its last fragment read and every staged slice has landed: the LDS is free
+    epilogue_silu_lds<OutT>(p, acc, m0, wm, n0, wn, smem, tid, lane);
+    return;
+  }
   if constexpr (NWV == 8) {
     if (p.N % 8 == 0 && p.y_stride % 8 == 0 && ((uintptr_t)p.y & 15) == 0) {
       __syncthreads();  // every wave is past its last fragment read and every staged slice has landed: the LDS is free
@@ -708,12 +811,12 @@ int g_tiled_group_m = 4;
 int g_tiled_stagger = 1;  // x 1024 cycles per step, 16 steps: CUs spread over ~6.5 us
 int g_tiled_force = 0;  // test hook: 1 = always the 128x128 kernel, 2 = the 256x256 kernel whenever its shape rules allow
 
-template <typename OutT, int NWV, bool DMA = true, int ES = TG_FP8>
+template <typename OutT, int NWV, bool DMA = true, int ES = TG_FP8, bool SILU = false>
 int launch256(GemmParams& p, hipStream_t st) {
-  constexpr int smem = 2 * 2 * OPB;  // 128 KiB
+  constexpr int smem = 2 * 2 * OPB + (SILU ? kSiluLut * 2 : 0);  // 128 KiB (+ 18.5 KiB: the silu table)
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)fp8_gemm256_kernel<OutT, NWV, DMA, ES>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)fp8_gemm256_kernel<OutT, NWV, DMA, ES, SILU>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
   p.tiles_m = (p.M + T2 - 1) / T2;
@@ -721,7 +824,7 @@ int launch256(GemmParams& p, hipStream_t st) {
   p.group_m = g_tiled_group_m;
   p.stagger_cus = tg_cus();
   p.stagger_q = (p.tiles_m * p.tiles_n >= 2 * p.stagger_cus) ? g_tiled_stagger : 0;  // needs a second round to pay off
-  hipLaunchKernelGGL((fp8_gemm256_kernel<OutT, NWV, DMA, ES>), dim3(p.tiles_m * p.tiles_n), dim3(NWV * 64), smem, st, p);
+  hipLaunchKernelGGL((fp8_gemm256_kernel<OutT, NWV, DMA, ES, SILU>), dim3(p.tiles_m * p.tiles_n), dim3(NWV * 64), smem, st, p);
   SGL_HIP_LAUNCH_CHECK();
   return SGL_MI355_OK;
 }
@@ -922,7 +1025,39 @@ int run(const void* x, int64_t xs, const void* w, int64_t ws, void* y, int64_t y
                                : launch<TG_F16, _Float16>(p, st, workspace, workspace_floats);
 }
 
+// the table of silu_lut.h in global memory, filled on the launch stream before every use (one 256-thread workgroup, ~2 us: no
+// state to keep per device or per graph)
+__device__ uint16_t g_silu_lut[kSiluLut];
+__global__ __launch_bounds__(256) void silu_lut_fill_kernel() {
+  for (int i = threadIdx.x + 256 * blockIdx.x; i < kSiluLut; i += 256 * gridDim.x) g_silu_lut[i] = silu_lut_entry(i);
+}
+
 }  // namespace
+
+// gate_up_proj + SiluAndMul for M > 64 (called by sgl_mi355_gemm_silu_mul, skinny_gemm.hip): fp8 operands, bf16 out, 16-row
+// interleaving, N % 256 == 0, whole 128-byte K slices.  Returns SGL_MI355_EINVAL with a message otherwise.
+int sgl_mi355_internal_tiled_gemm_silu_mul(const void* x, int64_t x_stride_b, const void* w, int64_t w_stride_b, void* act,
+                                           int64_t act_stride, const float* sx, const float* sw, int M, int N, int K, hipStream_t st) {
+  SGL_CHECK(M > 0 && N > 0 && N % 256 == 0 && K % BKB == 0 && K >= BKB, "gemm_silu_mul: the prefill form needs N %% 256 == 0 and K %% 128 == 0 (N=%d K=%d)", N, K);
+  SGL_CHECK((int64_t)N * w_stride_b < 0xFFFFFFF0ll && (int64_t)M * x_stride_b < 0xFFFFFFF0ll, "gemm_silu_mul: operands above 4 GiB");
+  SGL_CHECK(act_stride % 8 == 0 && ((uintptr_t)act & 15) == 0, "gemm_silu_mul: act rows must be 16-byte aligned");
+  GemmParams p;
+  p.x = (const char*)x; p.x_stride = x_stride_b;
+  p.w = (const char*)w; p.w_stride = w_stride_b;
+  p.y = act; p.y_stride = act_stride;
+  p.sx = sx; p.sw = sw; p.bias = nullptr;
+  p.M = M; p.N = N; p.kbytes = K;
+  p.slabs = nullptr; p.kt_per = 0;
+  void* lut = nullptr;
+  if (hipGetSymbolAddress(&lut, HIP_SYMBOL(g_silu_lut)) != hipSuccess || lut == nullptr) {
+    snprintf(g_sgl_mi355_err, sizeof(g_sgl_mi355_err), "gemm_silu_mul: cannot resolve the silu table");
+    return SGL_MI355_EINVAL;
+  }
+  p.silu_lut = (const uint16_t*)lut;
+  hipLaunchKernelGGL(silu_lut_fill_kernel, dim3(4), dim3(256), 0, st);
+  SGL_HIP_LAUNCH_CHECK();
+  return launch256<__bf16, 8, true, TG_FP8, true>(p, st);
+}
 
 extern "C" int sgl_mi355_fp8_gemm_force_tile(int mode) {
   if (mode >= 2000) {  // measurement hook: 2000 = split-K combined by a separate reduce launch (default), 2001 = inside the GEMM launch

@@ -163,6 +163,7 @@ class LlamaForCausalLM(nn.Module):
         # (csrc/mlp_block.hip) instead of four.  Measured 2.5 % slower than the four launches at the headline shape, so
         # off unless SGL_MI355_MLP_BLOCK=1
         self.fused_mlp_block = os.environ.get("SGL_MI355_MLP_BLOCK", "0") != "0"
+        self.prefill_silu_epilogue = os.environ.get("SGL_MI355_PREFILL_SILU", "1") != "0"   # gate_up + SiluAndMul in the prefill GEMM's epilogue
         self._mlp_scratch = {}
         # decode, M <= 64: o_proj in this many k-ranges, summed by the add + RMSNorm that follows (1 = one launch with the plain epilogue)
         self.o_proj_kranges = int(os.environ.get("SGL_MI355_OPROJ_KRANGES", "1"))
@@ -545,8 +546,19 @@ class LlamaForCausalLM(nn.Module):
             if tp > 1:
                 hidden = tensor_model_parallel_all_reduce(hidden)
             _, hq2, hs2 = K.fused_add_rmsnorm_quant_fp8(hidden, residual, ln2.weight.data, ln2.variance_epsilon)
-            gate_up = K.fp8_scaled_mm(hq2, mlp.gate_up_proj.weight, hs2.view(-1), mlp.gate_up_proj.weight_scale.view(-1), self.dtype)
-            aq, asc = K.silu_and_mul_quant_fp8(gate_up)
+            fw = self._fused_weights(layer) if self.prefill_silu_epilogue else None
+            if (fw is not None and fw["gu_tile"] == 16 and self.dtype == torch.bfloat16 and fw["gu_w"].shape[0] % 256 == 0
+                    and fw["gu_w"].shape[1] % 128 == 0 and hq2.shape[0] > 64
+                    and K.fp8_gemm_num_slabs(hq2.shape[0], fw["gu_w"].shape[0], fw["gu_w"].shape[1], hq2.device) == 1):
+                # (one k-range: fp8_scaled_mm then sums the K slices in the same order as the 256x256 tile, so the fused form stays
+                # bit-identical to the per-op path whichever kernel that path picks)
+                # gate_up with the SiluAndMul epilogue on the decode path's interleaved weight copy: the [T, 2 I] intermediate is never
+                # written; the per-token quant reads the [T, I] activation once (bit-identical to the two-kernel sequence)
+                act = K.fp8_gemm_silu_mul(hq2, hs2.view(-1), fw["gu_w"], fw["gu_s"], self.dtype, 16)
+                aq, asc = K.sglang_per_token_quant_fp8(act)
+            else:
+                gate_up = K.fp8_scaled_mm(hq2, mlp.gate_up_proj.weight, hs2.view(-1), mlp.gate_up_proj.weight_scale.view(-1), self.dtype)
+                aq, asc = K.silu_and_mul_quant_fp8(gate_up)
             hidden = K.fp8_scaled_mm(aq, mlp.down_proj.weight, asc.view(-1), mlp.down_proj.weight_scale.view(-1), self.dtype)
             if tp > 1:
                 hidden = tensor_model_parallel_all_reduce(hidden)

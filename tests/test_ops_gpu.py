@@ -707,6 +707,29 @@ def test_fp8_gemm_silu_mul_bit_exact(tile_rows, sk):
     assert torch.equal(got, ref)
 
 
+@pytest.mark.parametrize("m,n,k", [(65, 512, 1024), (256, 2816, 4096), (300, 1024, 512), (1031, 768, 2048)])
+def test_fp8_gemm_silu_mul_prefill_form_bit_exact(m, n, k, sk):
+    """M > 64: gate_up + SiluAndMul as the epilogue of the 256x256 tile (csrc/tiled_gemm.hip epilogue_silu_lds: bf16 pairs through
+    v_permlane32_swap, silu through the 16-bit table, act tile staged in LDS) == fp8_scaled_mm (the same tile) -> silu_and_mul, bit for
+    bit: ragged M, several N tiles, gate values outside the table (zero weight rows -> exact zeros; scales that push |y| past 128)."""
+    from ltp_sglang_amd import _cabi
+    c = _cases.build_gemm_case(dict(m=m, n=n, k=k, bias=False, out="bf16"), seed=m + n)
+    a, wt, sa, sb = c["a"].to(DEV), c["w"].to(DEV).clone(), c["sa"].to(DEV) * 3, c["sb"].to(DEV).clone() * 3
+    wt.view(torch.uint8)[5] = 0            # a gate column of exact zeros
+    wt.view(torch.uint8)[n // 2 + 7] = 0   # an up column of exact zeros
+    sb[11] = sb[11] * 4000.0               # |gate| far beyond the table
+    _cabi.check(_cabi.lib.sgl_mi355_fp8_gemm_force_tile(2))
+    try:
+        ref = sk.silu_and_mul(sk.fp8_scaled_mm(a, wt.t(), sa, sb, torch.bfloat16))
+    finally:
+        _cabi.lib.sgl_mi355_fp8_gemm_force_tile(0)
+    wi = sk.interleave_gate_up_rows(wt.view(torch.uint8), 16).view(torch.float8_e4m3fn)
+    got = sk.fp8_gemm_silu_mul(a, sa, wi, sk.interleave_gate_up_rows(sb, 16), torch.bfloat16, 16)
+    assert torch.equal(got, ref)
+    with pytest.raises(RuntimeError, match="N %"):
+        sk.fp8_gemm_silu_mul(a, sa, wi[: n - 32], sk.interleave_gate_up_rows(sb, 16)[: n - 32], torch.bfloat16, 16)
+
+
 @pytest.mark.parametrize("tile_rows", [16, 8])
 @pytest.mark.parametrize("m,hq,hkv,bias", [(32, 8, 2, False), (5, 4, 4, True), (17, 28, 4, True), (48, 32, 8, False)])
 def test_fp8_qkv_rope_set_kv_bit_exact(m, hq, hkv, bias, tile_rows, sk):
