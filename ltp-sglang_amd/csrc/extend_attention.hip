@@ -499,6 +499,283 @@ __global__ __launch_bounds__(256, 2) void extend_attn_kernel(const ExtendParams 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// LDS-DMA form (round 3) of the unmasked 16-bit D = 128 kernel: extend_attn_kernel's workgroup shape, LDS images, fragment maps,
+// 64-key tiles and arithmetic ORDER (the output is bit-identical, which the tests check), with two changes that only move data:
+//   * K / V tiles travel HBM -> LDS by LDS-DMA (global_load_lds, 16 B per lane; the swizzle is applied on the source side: the lane
+//     that writes position `pos` of row r fetches the chunk the image keeps there), one tile ahead into the other half of the
+//     double buffer: no staging registers and no LDS-store pass (600 of the 4 600 cycles a lone wave spent per tile);
+//   * the 36 registers this frees hold a whole phase's fragments: all 16 K fragments of a tile are requested before the first
+//     S^T MFMA and all 16 V^T fragments before the first PV MFMA, so an LDS round trip is paid once per phase instead of once per
+//     pair of key groups (QK^T took 1 700 cycles for 512 cycles of MFMA).
+// The loop's global traffic is issued from asm statements and waited for by hand: seen by the compiler, an LDS-DMA makes
+// SIInsertWaitcnts put vmcnt(0) in front of every ds_read_b64_tr_b16 (it cannot tell the two buffers apart), i.e. the next tile's
+// flight would be waited for before this tile's PV.  Rows past the end of a phase are fetched from the phase's last row (finite
+// data; their probabilities are exactly 0).
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void ext_dma16(const char* src, unsigned lds_addr) {   // 64 lanes x 16 B -> LDS [lds_addr, + 1 KiB)
+  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ int ext_load_i32(const int32_t* src) {
+  int v;
+  asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(src) : "memory");
+  return v;
+}
+
+int g_extend_dma = 1;  // measurement hook (sgl_mi355_extend_attention_set_mode): 0 = always the register-staged kernel
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void extend_attn_dma_kernel(const ExtendParams p) {
+  using Tr = ElemTraits<T>;
+  using vec8 = typename Tr::vec8;
+  constexpr int D = 128, QT = 2, ROWB = 256, KS = 4, NT = 8;
+  constexpr int TILE_B = kKT * ROWB;  // 16 KiB
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][K 16 KiB | V 16 KiB]
+
+  const int bid = blockIdx.x;
+  const int lo = bid & 7, rest = bid >> 3;
+  const int qb = p.nqb - 1 - rest % p.nqb;
+  const int pair = (rest / p.nqb) * 8 + lo;
+  const int npairs = p.bs * p.hkv * p.hchunks;
+  if (pair >= npairs) return;
+  const int b = pair / (p.hkv * p.hchunks);
+  const int khc = pair - b * (p.hkv * p.hchunks);
+  const int kh = khc / p.hchunks, hc = khc - kh * p.hchunks;
+
+  const int bq = 1 << p.bq_log2;
+  const int gslots = (64 * QT) >> p.bq_log2;
+  const int q0 = p.qo_indptr ? p.qo_indptr[b] : p.extend_start_loc[b];
+  const int ext_len = p.qo_indptr ? p.qo_indptr[b + 1] - q0 : p.extend_seq_lens[b];
+  const int qpos0 = qb * bq;
+  if (qpos0 >= ext_len) return;
+  int pre_len;
+  const int32_t* idx_row;
+  if (p.kv_indptr) {
+    const int s0 = p.kv_indptr[b];
+    pre_len = p.kv_indptr[b + 1] - s0;
+    idx_row = p.kv_indices + s0;
+  } else {
+    pre_len = (int)p.seq_lens[b] - ext_len;
+    idx_row = p.req_to_token + p.req_pool_indices[b] * p.req_to_token_stride;
+  }
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int a = lane & 15, g = lane >> 4;
+
+  vec8 qf[QT][KS];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    const int t16 = (QT * w + qt) * 16;
+    const int hslot = t16 >> p.bq_log2;
+    const int hl = hc * (4 * QT) + hslot;
+    const int qp = qpos0 + (t16 & (bq - 1)) + a;
+    const bool row_ok = hl < p.group && hslot < gslots && qp < ext_len;
+    const T* qrow = (const T*)p.q + (int64_t)(q0 + min(qp, ext_len - 1)) * p.q_stride_t + (int64_t)(kh * p.group + min(hl, p.group - 1)) * D;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (row_ok) {
+        qf[qt][ks] = *(const vec8*)(qrow + 32 * ks + 8 * g);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[qt][ks][j] = (T)0.0f;
+      }
+    }
+  }
+
+  const int npre_tiles = (pre_len + kKT - 1) / kKT;
+  const int ext_end = p.is_causal ? min(ext_len, qpos0 + bq) : ext_len;
+  const int ntiles = npre_tiles + (ext_end + kKT - 1) / kKT;   // >= 1: the block has at least one extend key
+
+  // ---- LDS-DMA staging: wave w fills rows 16 w .. 16 w + 15 of a tile, 4 rows (1 KiB) per instruction; lane = (row l >> 4, position l & 15) ----
+  const int srow = lane >> 4, spos = lane & 15;
+  const char* kpool = (const char*)p.k_buf + ((int64_t)kh * p.k_stride_h) * 2;
+  const char* vpool = (const char*)p.v_buf + ((int64_t)kh * p.v_stride_h) * 2;
+  const char* kext = (const char*)p.ke + ((int64_t)q0 * p.ke_stride_t + (int64_t)kh * D) * 2;
+  const char* vext = (const char*)p.ve + ((int64_t)q0 * p.ve_stride_t + (int64_t)kh * D) * 2;
+  const int64_t kpst = p.k_stride_t * 2, vpst = p.v_stride_t * 2, kest = p.ke_stride_t * 2, vest = p.ve_stride_t * 2;
+  const int32_t* idx_dummy = p.qo_indptr ? p.qo_indptr : p.extend_start_loc;   // any readable int32 when there is no prefix row
+  typedef __attribute__((address_space(3))) void* lptr_t;
+
+  auto load_idx = [&](int t, int (&idn)[4]) {   // pool slots of tile t's rows (valid only after the caller's wait)
+    const bool pre = t < npre_tiles;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = t * kKT + 16 * w + 4 * i + srow;
+      idn[i] = ext_load_i32(pre ? idx_row + min(r, pre_len - 1) : idx_dummy);
+    }
+  };
+  auto stage = [&](int t, const int (&idn)[4]) {   // tile t -> buffer t & 1 (8 LDS-DMA instructions per wave)
+    const bool pre = t < npre_tiles;
+    const int base = (t - npre_tiles) * kKT + 16 * w + srow;
+    const unsigned kdst = (unsigned)(uintptr_t)(lptr_t)(smem + (t & 1) * 2 * TILE_B + (16 * w) * ROWB);   // LDS byte address
+    const unsigned vdst = kdst + TILE_B;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rr = min(base + 4 * i, ext_len - 1);
+      const int r = 4 * i + srow;   // row & 15 (16 w is a multiple of 16): the chunk the image keeps at this lane's position
+      const char* ks = (pre ? kpool + (int64_t)idn[i] * kpst : kext + (int64_t)rr * kest) + ((spos ^ r) << 4);
+      const char* vs = (pre ? vpool + (int64_t)idn[i] * vpst : vext + (int64_t)rr * vest) + (((((spos >> 1) ^ (r & 7)) << 1) | (spos & 1)) << 4);
+      ext_dma16(ks, kdst + i * 4 * ROWB);
+      ext_dma16(vs, vdst + i * 4 * ROWB);
+    }
+  };
+
+  float m_i[QT], l_i[QT];
+  f32x4_t acc[QT][NT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    m_i[qt] = -INFINITY;
+    l_i[qt] = 0.f;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[qt][n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+  const float cs = p.sm_scale * kLog2e;
+
+  // ---- prologue: tile 0 landed, slots of tile 1 known ----
+  int idn[4];
+  {
+    int i0[4];
+    load_idx(0, i0);
+    load_idx(1, idn);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(i0[0]), "+v"(i0[1]), "+v"(i0[2]), "+v"(i0[3]), "+v"(idn[0]), "+v"(idn[1]), "+v"(idn[2]), "+v"(idn[3])::"memory");
+    stage(0, i0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    // slots of tile t + 2 first, then tile t + 1's DMA (buffer (t + 1) & 1 held tile t - 1: its last readers passed the barrier)
+    int idn2[4];
+    load_idx(t + 2, idn2);
+    if (t + 1 < ntiles) stage(t + 1, idn);
+    const char* kl = smem + (t & 1) * 2 * TILE_B;
+    const char* vl = kl + TILE_B;
+    const bool in_prefix = t < npre_tiles;
+    const int kbase = in_prefix ? t * kKT : (t - npre_tiles) * kKT;
+    const int klimit = in_prefix ? pre_len : ext_len;
+
+    // ---- S^T = K Q^T: every K fragment of the tile in flight before the first MFMA; per (tt, qt) the k-steps in the order 0..3 ----
+    f32x4_t s[QT][4];
+    {
+      vec8 kf[16];
+#pragma unroll
+      for (int f = 0; f < 16; ++f) {
+        const int row = 16 * (f >> 2) + a;
+        kf[f] = *(const vec8*)(kl + row * ROWB + (((4 * (f & 3) + g) ^ (row & 15)) << 4));
+      }
+      __builtin_amdgcn_sched_barrier(0);   // (left free, the scheduler sinks each read to just before its MFMA: a round trip per pair)
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+          f32x4_t c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) c = Tr::mfma16(kf[4 * tt + ks], qf[qt][ks], c);
+          s[qt][tt] = c;
+        }
+    }
+    // ragged last tile of a phase / causal diagonal: ONE wave-uniform branch, branch-free inside
+    const int wave_qmin = qpos0 + (bq >= 16 * QT ? ((16 * QT * w) & (bq - 1)) : 0);
+    if ((kbase + kKT > klimit) || (!in_prefix && p.is_causal && kbase + kKT - 1 > wave_qmin)) {
+      const bool causal = !in_prefix && p.is_causal;
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        const int qp = qpos0 + (((QT * w + qt) * 16) & (bq - 1)) + a;
+        const int lim = min(klimit - 1, causal ? qp : 0x7fffffff) - kbase - 4 * g;   // key index relative to 16 tt + r
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[qt][tt][r] = (16 * tt + r <= lim) ? s[qt][tt][r] : -INFINITY;
+      }
+    }
+    // ---- online softmax per query tile (extend_attn_kernel's arithmetic) ----
+    vec8 pf[QT][2];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      float m = -INFINITY;
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m = fmaxf(m, s[qt][tt][r]);
+      m = fmaxf(m, __shfl_xor(m, 16, WAVE));
+      m = fmaxf(m, __shfl_xor(m, 32, WAVE));
+      const float m_new = fmaxf(m_i[qt], m * cs);
+      const float m_safe = fmaxf(m_new, -1e30f);
+      const float alpha = __builtin_amdgcn_exp2f(m_i[qt] - m_safe);
+      float lsum = 0.f;
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qt][tt][r], cs, -m_safe));
+          lsum += pv;
+          pf[qt][tt >> 1][4 * (tt & 1) + r] = Tr::from_f32(pv);
+        }
+      }
+      l_i[qt] = l_i[qt] * alpha + lsum;
+      m_i[qt] = m_new;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[qt][n] *= alpha;
+    }
+    // ---- O^T += V^T P^T: every V^T fragment of the tile in flight before the first MFMA; per (qt, n) u = 0, 1 in order ----
+    {
+      vec8 vf[16];   // fragment 2 n + u
+#pragma unroll
+      for (int f = 0; f < 16; ++f) {
+        const int n = f >> 1, u = f & 1;
+        s16x4_t t0, t1;
+        {
+          const int row = 32 * u + 4 * g + (a >> 2);
+          t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (s16x4_t __attribute__((address_space(3)))*)(vl + row * ROWB + ((n ^ (row & 7)) << 5) + ((a & 3) << 3)));
+        }
+        {
+          const int row = 32 * u + 16 + 4 * g + (a >> 2);
+          t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (s16x4_t __attribute__((address_space(3)))*)(vl + row * ROWB + ((n ^ (row & 7)) << 5) + ((a & 3) << 3)));
+        }
+        vf[f] = __builtin_bit_cast(vec8, __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int qt = 0; qt < QT; ++qt) acc[qt][n] = Tr::mfma16(vf[2 * n + u], pf[qt][u], acc[qt][n]);
+    }
+    // tile t + 1 has landed and the slots of tile t + 2 are known (handed on THROUGH the wait so that nothing reads them above it)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(idn2[0]), "+v"(idn2[1]), "+v"(idn2[2]), "+v"(idn2[3])::"memory");
+#pragma unroll
+    for (int i = 0; i < 4; ++i) idn[i] = idn2[i];
+    __syncthreads();
+  }
+
+  // ---- o = acc / l ----
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    float l = l_i[qt];
+    l += __shfl_xor(l, 16, WAVE);
+    l += __shfl_xor(l, 32, WAVE);
+    const int t16 = (QT * w + qt) * 16;
+    const int hslot = t16 >> p.bq_log2;
+    const int hl = hc * (4 * QT) + hslot;
+    const int qp = qpos0 + (t16 & (bq - 1)) + a;
+    if (hl < p.group && hslot < gslots && qp < ext_len) {
+      const float inv = l > 0.f ? 1.0f / l : 0.f;
+      T* orow = (T*)p.o + (int64_t)(q0 + qp) * p.o_stride_t + (int64_t)(kh * p.group + hl) * D;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        typename Tr::vec4 ov;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ov[r] = Tr::from_f32(acc[qt][n][r] * inv);
+        *(typename Tr::vec4*)(orow + 16 * n + 4 * g) = ov;
+      }
+    }
+  }
+}
+
 // Any-head-dim fallback: one wave per (query token, q head); correctness path for odd head sizes.
 template <typename T>
 __global__ __launch_bounds__(64) void extend_attn_generic(const ExtendParams p, int d_qk, int dv, int total_q) {
@@ -596,9 +873,12 @@ int launch_mfma(ExtendParams& p, int max_len_extend, hipStream_t st) {
     if (p.logit_cap > 0.0f) return launch_mfma<T, D, KV8, true>(p, max_len_extend, st);
   }
   constexpr int smem = 2 * 2 * kKT * D * 2;
+  constexpr bool kDma = !KV8 && !CAP && !MASKED && QT == 2 && D == 128;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)extend_attn_kernel<T, D, KV8, CAP, MASKED, QT>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if constexpr (kDma)
+      (void)hipFuncSetAttribute((const void*)extend_attn_dma_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
   // head slots per workgroup: smallest power of two >= min(group, 4 QT); positions per workgroup = 64 QT / slots (>= 16)
@@ -615,6 +895,13 @@ int launch_mfma(ExtendParams& p, int max_len_extend, hipStream_t st) {
   if (nblocks >= (1ll << 31)) {
     snprintf(g_sgl_mi355_err, sizeof(g_sgl_mi355_err), "extend_attention: grid too large");
     return SGL_MI355_EINVAL;
+  }
+  if constexpr (kDma) {
+    if (g_extend_dma && p.casc_bs == 0 && !p.kv_fp8) {
+      hipLaunchKernelGGL((extend_attn_dma_kernel<T>), dim3((unsigned)nblocks), dim3(256), smem, st, p);
+      SGL_HIP_LAUNCH_CHECK();
+      return SGL_MI355_OK;
+    }
   }
   hipLaunchKernelGGL((extend_attn_kernel<T, D, KV8, CAP, MASKED, QT>), dim3((unsigned)nblocks), dim3(256), smem, st, p);
   SGL_HIP_LAUNCH_CHECK();
@@ -653,6 +940,12 @@ int sgl_mi355_internal_cascade_prefix(const void* q, int64_t q_stride_t, const v
   p.casc_bs = batch; p.casc_prefix_len = prefix_len; p.casc_chunk = chunk; p.casc_slot0 = slot0; p.max_kv_splits = max_kv_splits;
   p.part_o = attn_logits; p.part_lse = attn_lse;
   return dtype == SGL_BF16 ? launch_all<__bf16>(p, head_dim, head_dim, batch, batch, st) : launch_all<_Float16>(p, head_dim, head_dim, batch, batch, st);
+}
+
+// measurement / test hook: 1 (default) = the LDS-DMA kernel where it applies, 0 = always the register-staged kernel
+extern "C" int sgl_mi355_extend_attention_set_mode(int lds_dma) {
+  g_extend_dma = lds_dma ? 1 : 0;
+  return SGL_MI355_OK;
 }
 
 extern "C" int sgl_mi355_extend_attention(

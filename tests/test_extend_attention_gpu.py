@@ -90,6 +90,27 @@ def test_extend_head_group_shapes(hq, hkv, pkg):
     assert (o.double() - _f64(c)).abs().max().item() <= TOL_F64[c["dtype"]]
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("hq,hkv,pre,ext", [(32, 8, [0, 0], [300, 77]), (8, 2, [130, 64, 0], [45, 200, 513]), (12, 12, [5], [260]),
+                                            (32, 2, [70, 0], [129, 33]), (6, 2, [257, 31], [64, 1])])
+def test_extend_lds_dma_kernel_equals_register_staged_kernel(dtype, hq, hkv, pre, ext, pkg):
+    """16-bit K/V, D = 128, no mask / cap: the default is the LDS-DMA kernel (csrc/extend_attention.hip extend_attn_dma_kernel: same
+    tiles, fragment maps and arithmetic order, only the way the tiles reach LDS and the fragments reach registers differs) -- bit
+    for bit the register-staged kernel, over prefix + extend phases, ragged tiles, every head-group shape, causal and not."""
+    from ltp_sglang_amd import _cabi
+    case = dict(name="dma", kind="extend", dtype=dtype, hq=hq, hkv=hkv, d=128, pre=pre, ext=ext)
+    c = _cases.build_attn_case(case, seed=hq + len(pre))
+    for causal in (True, False):
+        got = _run(pkg, c, causal=causal)
+        try:
+            _cabi.check(_cabi.lib.sgl_mi355_extend_attention_set_mode(0))
+            ref = _run(pkg, c, causal=causal)
+        finally:
+            _cabi.lib.sgl_mi355_extend_attention_set_mode(1)
+        assert torch.equal(got, ref)
+        assert (got.double() - _f64(c, causal=causal)).abs().max().item() <= TOL_F64[c["dtype"]]
+
+
 def test_extend_long_sequence_properties(pkg):
     """seq 2048 without prefix at Llama-3-8B heads (BASELINE shape per request): compare 2 requests fully against
     the f64 oracle and check the causal first-row property o[0] == v[0]."""
