@@ -142,7 +142,8 @@ def _traffic_profile():
     files = glob.glob(os.path.join(ROOT, "profiles", "round*_pmc_traffic.json"))
     if not files:
         return None, None
-    path = max(files, key=lambda f: int(re.search(r"round(\d+)", os.path.basename(f)).group(1)))
+    # (round number, then name: a re-profile later in a round is "round3b_..." and sorts after "round3_...")
+    path = max(files, key=lambda f: (int(re.search(r"round(\d+)", os.path.basename(f)).group(1)), os.path.basename(f)))
     with open(path) as f:
         return os.path.relpath(path, ROOT), json.load(f)
 
