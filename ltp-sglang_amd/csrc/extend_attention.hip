@@ -524,8 +524,10 @@ __device__ __forceinline__ int ext_load_i32(const int32_t* src) {
 
 int g_extend_dma = 1;  // measurement hook (sgl_mi355_extend_attention_set_mode): 0 = always the register-staged kernel
 
-template <typename T>
-__global__ __launch_bounds__(256, 2) void extend_attn_dma_kernel(const ExtendParams p) {
+// NW: waves per workgroup -- 4 (128 rows, two workgroups per CU) or 8 (256 rows = twice the query positions per K / V tile, one
+// workgroup per CU: half the tile traffic)
+template <typename T, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void extend_attn_dma_kernel(const ExtendParams p) {
   using Tr = ElemTraits<T>;
   using vec8 = typename Tr::vec8;
   constexpr int D = 128, QT = 2, ROWB = 256, KS = 4, NT = 8;
@@ -543,7 +545,7 @@ __global__ __launch_bounds__(256, 2) void extend_attn_dma_kernel(const ExtendPar
   const int kh = khc / p.hchunks, hc = khc - kh * p.hchunks;
 
   const int bq = 1 << p.bq_log2;
-  const int gslots = (64 * QT) >> p.bq_log2;
+  const int gslots = (16 * NW * QT) >> p.bq_log2;
   const int q0 = p.qo_indptr ? p.qo_indptr[b] : p.extend_start_loc[b];
   const int ext_len = p.qo_indptr ? p.qo_indptr[b + 1] - q0 : p.extend_seq_lens[b];
   const int qpos0 = qb * bq;
@@ -568,7 +570,7 @@ __global__ __launch_bounds__(256, 2) void extend_attn_dma_kernel(const ExtendPar
   for (int qt = 0; qt < QT; ++qt) {
     const int t16 = (QT * w + qt) * 16;
     const int hslot = t16 >> p.bq_log2;
-    const int hl = hc * (4 * QT) + hslot;
+    const int hl = hc * (4 * QT) + hslot;   // (hchunks > 1 only when group > 8: NW = 4 there)
     const int qp = qpos0 + (t16 & (bq - 1)) + a;
     const bool row_ok = hl < p.group && hslot < gslots && qp < ext_len;
     const T* qrow = (const T*)p.q + (int64_t)(q0 + min(qp, ext_len - 1)) * p.q_stride_t + (int64_t)(kh * p.group + min(hl, p.group - 1)) * D;
@@ -587,7 +589,8 @@ __global__ __launch_bounds__(256, 2) void extend_attn_dma_kernel(const ExtendPar
   const int ext_end = p.is_causal ? min(ext_len, qpos0 + bq) : ext_len;
   const int ntiles = npre_tiles + (ext_end + kKT - 1) / kKT;   // >= 1: the block has at least one extend key
 
-  // ---- LDS-DMA staging: wave w fills rows 16 w .. 16 w + 15 of a tile, 4 rows (1 KiB) per instruction; lane = (row l >> 4, position l & 15) ----
+  // ---- LDS-DMA staging: wave w fills rows RPWV w .. of a tile (64 / NW rows), 4 rows (1 KiB) per instruction; lane = (row l >> 4, position l & 15) ----
+  constexpr int RPWV = kKT / NW, NIW = RPWV / 4;
   const int srow = lane >> 4, spos = lane & 15;
   const char* kpool = (const char*)p.k_buf + ((int64_t)kh * p.k_stride_h) * 2;
   const char* vpool = (const char*)p.v_buf + ((int64_t)kh * p.v_stride_h) * 2;
@@ -597,23 +600,23 @@ __global__ __launch_bounds__(256, 2) void extend_attn_dma_kernel(const ExtendPar
   const int32_t* idx_dummy = p.qo_indptr ? p.qo_indptr : p.extend_start_loc;   // any readable int32 when there is no prefix row
   typedef __attribute__((address_space(3))) void* lptr_t;
 
-  auto load_idx = [&](int t, int (&idn)[4]) {   // pool slots of tile t's rows (valid only after the caller's wait)
+  auto load_idx = [&](int t, int (&idn)[NIW]) {   // pool slots of tile t's rows (valid only after the caller's wait)
     const bool pre = t < npre_tiles;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = t * kKT + 16 * w + 4 * i + srow;
+    for (int i = 0; i < NIW; ++i) {
+      const int r = t * kKT + RPWV * w + 4 * i + srow;
       idn[i] = ext_load_i32(pre ? idx_row + min(r, pre_len - 1) : idx_dummy);
     }
   };
-  auto stage = [&](int t, const int (&idn)[4]) {   // tile t -> buffer t & 1 (8 LDS-DMA instructions per wave)
+  auto stage = [&](int t, const int (&idn)[NIW]) {   // tile t -> buffer t & 1 (2 NIW LDS-DMA instructions per wave)
     const bool pre = t < npre_tiles;
-    const int base = (t - npre_tiles) * kKT + 16 * w + srow;
-    const unsigned kdst = (unsigned)(uintptr_t)(lptr_t)(smem + (t & 1) * 2 * TILE_B + (16 * w) * ROWB);   // LDS byte address
+    const int base = (t - npre_tiles) * kKT + RPWV * w + srow;
+    const unsigned kdst = (unsigned)(uintptr_t)(lptr_t)(smem + (t & 1) * 2 * TILE_B + (RPWV * w) * ROWB);   // LDS byte address
     const unsigned vdst = kdst + TILE_B;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NIW; ++i) {
       const int rr = min(base + 4 * i, ext_len - 1);
-      const int r = 4 * i + srow;   // row & 15 (16 w is a multiple of 16): the chunk the image keeps at this lane's position
+      const int r = (RPWV * w + 4 * i + srow) & 15;   // the chunk the image keeps at this lane's position depends on row & 15 (K), row & 7 (V)
       const char* ks = (pre ? kpool + (int64_t)idn[i] * kpst : kext + (int64_t)rr * kest) + ((spos ^ r) << 4);
       const char* vs = (pre ? vpool + (int64_t)idn[i] * vpst : vext + (int64_t)rr * vest) + (((((spos >> 1) ^ (r & 7)) << 1) | (spos & 1)) << 4);
       ext_dma16(ks, kdst + i * 4 * ROWB);
@@ -633,12 +636,13 @@ __global__ __launch_bounds__(256, 2) void extend_attn_dma_kernel(const ExtendPar
   const float cs = p.sm_scale * kLog2e;
 
   // ---- prologue: tile 0 landed, slots of tile 1 known ----
-  int idn[4];
+  int idn[NIW];
   {
-    int i0[4];
+    int i0[NIW];
     load_idx(0, i0);
     load_idx(1, idn);
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(i0[0]), "+v"(i0[1]), "+v"(i0[2]), "+v"(i0[3]), "+v"(idn[0]), "+v"(idn[1]), "+v"(idn[2]), "+v"(idn[3])::"memory");
+#pragma unroll
+    for (int i = 0; i < NIW; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+v"(i0[i]), "+v"(idn[i])::"memory");
     stage(0, i0);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -646,7 +650,7 @@ __global__ __launch_bounds__(256, 2) void extend_attn_dma_kernel(const ExtendPar
 
   for (int t = 0; t < ntiles; ++t) {
     // slots of tile t + 2 first, then tile t + 1's DMA (buffer (t + 1) & 1 held tile t - 1: its last readers passed the barrier)
-    int idn2[4];
+    int idn2[NIW];
     load_idx(t + 2, idn2);
     if (t + 1 < ntiles) stage(t + 1, idn);
     const char* kl = smem + (t & 1) * 2 * TILE_B;
@@ -746,9 +750,10 @@ __global__ __launch_bounds__(256, 2) void extend_attn_dma_kernel(const ExtendPar
           for (int qt = 0; qt < QT; ++qt) acc[qt][n] = Tr::mfma16(vf[2 * n + u], pf[qt][u], acc[qt][n]);
     }
     // tile t + 1 has landed and the slots of tile t + 2 are known (handed on THROUGH the wait so that nothing reads them above it)
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(idn2[0]), "+v"(idn2[1]), "+v"(idn2[2]), "+v"(idn2[3])::"memory");
 #pragma unroll
-    for (int i = 0; i < 4; ++i) idn[i] = idn2[i];
+    for (int i = 0; i < NIW; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+v"(idn2[i])::"memory");
+#pragma unroll
+    for (int i = 0; i < NIW; ++i) idn[i] = idn2[i];
     __syncthreads();
   }
 
@@ -877,8 +882,10 @@ int launch_mfma(ExtendParams& p, int max_len_extend, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)extend_attn_kernel<T, D, KV8, CAP, MASKED, QT>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if constexpr (kDma)
-      (void)hipFuncSetAttribute((const void*)extend_attn_dma_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if constexpr (kDma) {
+      (void)hipFuncSetAttribute((const void*)extend_attn_dma_kernel<T, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+      (void)hipFuncSetAttribute((const void*)extend_attn_dma_kernel<T, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    }
     attr_set = true;
   }
   // head slots per workgroup: smallest power of two >= min(group, 4 QT); positions per workgroup = 64 QT / slots (>= 16)
@@ -898,7 +905,14 @@ int launch_mfma(ExtendParams& p, int max_len_extend, hipStream_t st) {
   }
   if constexpr (kDma) {
     if (g_extend_dma && p.casc_bs == 0 && !p.kv_fp8) {
-      hipLaunchKernelGGL((extend_attn_dma_kernel<T>), dim3((unsigned)nblocks), dim3(256), smem, st, p);
+      if (g_extend_dma == 2 && p.group <= 8 && max_len_extend > 2 * bq) {   // 8 waves: twice the positions per workgroup
+        p.bq_log2 = lg + 1;
+        p.nqb = (max_len_extend + 2 * bq - 1) / (2 * bq);
+        const int64_t nb8 = (int64_t)((npairs + 7) / 8) * p.nqb * 8;
+        hipLaunchKernelGGL((extend_attn_dma_kernel<T, 8>), dim3((unsigned)nb8), dim3(512), smem, st, p);
+      } else {
+        hipLaunchKernelGGL((extend_attn_dma_kernel<T, 4>), dim3((unsigned)nblocks), dim3(256), smem, st, p);
+      }
       SGL_HIP_LAUNCH_CHECK();
       return SGL_MI355_OK;
     }
@@ -944,7 +958,7 @@ int sgl_mi355_internal_cascade_prefix(const void* q, int64_t q_stride_t, const v
 
 // measurement / test hook: 1 (default) = the LDS-DMA kernel where it applies, 0 = always the register-staged kernel
 extern "C" int sgl_mi355_extend_attention_set_mode(int lds_dma) {
-  g_extend_dma = lds_dma ? 1 : 0;
+  g_extend_dma = lds_dma < 0 ? 0 : (lds_dma > 2 ? 2 : lds_dma);   // (2: the 8-wave form of the LDS-DMA kernel, a measurement variant)
   return SGL_MI355_OK;
 }
 
