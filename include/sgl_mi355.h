@@ -98,10 +98,13 @@ int sgl_mi355_decode_attention_cascade(const void* q, int64_t q_stride_t, const 
  * 4-wave workgroup sharing one split with an LDS merge. */
 int sgl_mi355_decode_attention_set_mode(int mode);
 
-/* Measurement / test hook for sgl_mi355_extend_attention: 1 (default) = the LDS-DMA kernel (K / V tiles HBM -> LDS without staging
- * registers, a whole phase's fragments in flight) where it applies (16-bit K/V, D = 128, no mask / cap / cascade), 0 = always the
- * register-staged kernel.  Both implement extend_attention_fwd (extend_attention.py:41-438) with the same arithmetic order. */
-int sgl_mi355_extend_attention_set_mode(int lds_dma);
+/* Kernel choice of sgl_mi355_extend_attention for 16-bit K/V, D = 128, no mask / cap / cascade (all forms implement
+ * extend_attention_fwd, extend_attention.py:41-438, with the same arithmetic order and bit-identical outputs): set_mode 0 = always
+ * the register-staged kernel, 1 (default) = the LDS-DMA kernel with 4 or 8 waves per workgroup by the mean number of keys a query
+ * block attends to (8 from 1536 on), 2 / 3 = always 8 / 4 waves.  set_kv_hint: that mean for the next calls, from host-side lengths
+ * (per request prefix + extend / 2); 0 = unknown (no prefix assumed). */
+int sgl_mi355_extend_attention_set_mode(int mode);
+int sgl_mi355_extend_attention_set_kv_hint(int mean_keys_per_query_block);
 /* Extend (prefill / chunked prefill / prefix-cache hit) attention: cached prefix from the paged pool + causal
  * triangle over the contiguous new K/V.  Replaces extend_attention_fwd
  * (python/sglang/srt/layers/attention/triton_ops/extend_attention.py:306-438) with (qo_indptr, kv_indptr,

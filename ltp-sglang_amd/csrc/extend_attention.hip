@@ -522,7 +522,8 @@ __device__ __forceinline__ int ext_load_i32(const int32_t* src) {
   return v;
 }
 
-int g_extend_dma = 1;  // measurement hook (sgl_mi355_extend_attention_set_mode): 0 = always the register-staged kernel
+int g_extend_dma = 1;  // sgl_mi355_extend_attention_set_mode: 0 = always the register-staged kernel, 1 = LDS-DMA kernel, 4 or 8 waves by the rule in launch_mfma, 2 / 3 = always 8 / 4 waves
+int g_extend_kv_hint = 0;  // sgl_mi355_extend_attention_set_kv_hint: mean keys a query block attends to (0: unknown)
 
 // NW: waves per workgroup -- 4 (128 rows, two workgroups per CU) or 8 (256 rows = twice the query positions per K / V tile, one
 // workgroup per CU: half the tile traffic)
@@ -905,7 +906,12 @@ int launch_mfma(ExtendParams& p, int max_len_extend, hipStream_t st) {
   }
   if constexpr (kDma) {
     if (g_extend_dma && p.casc_bs == 0 && !p.kv_fp8) {
-      if (g_extend_dma == 2 && p.group <= 8 && max_len_extend > 2 * bq) {   // 8 waves: twice the positions per workgroup
+      // 8 waves (twice the query positions per K / V tile, half the tile traffic) pay where a query block walks many keys: same
+      // box, 4 -> 8 waves: radix hit 16 x (1536 + 512) 367 -> 334 us, 2 x 8192 1 333 -> 1 238 us, 32 x 2048 without prefix
+      // 1 600 -> 1 614 us.  Mean keys per query block: the caller's hint (prefix + extend / 2 per request), else extend / 2.
+      const int mean_keys = g_extend_kv_hint > 0 ? g_extend_kv_hint : max_len_extend / 2;
+      const bool wide = g_extend_dma == 2 || (g_extend_dma == 1 && mean_keys >= 1536);
+      if (wide && p.group <= 8 && max_len_extend > 2 * bq) {
         p.bq_log2 = lg + 1;
         p.nqb = (max_len_extend + 2 * bq - 1) / (2 * bq);
         const int64_t nb8 = (int64_t)((npairs + 7) / 8) * p.nqb * 8;
@@ -956,9 +962,16 @@ int sgl_mi355_internal_cascade_prefix(const void* q, int64_t q_stride_t, const v
   return dtype == SGL_BF16 ? launch_all<__bf16>(p, head_dim, head_dim, batch, batch, st) : launch_all<_Float16>(p, head_dim, head_dim, batch, batch, st);
 }
 
-// measurement / test hook: 1 (default) = the LDS-DMA kernel where it applies, 0 = always the register-staged kernel
-extern "C" int sgl_mi355_extend_attention_set_mode(int lds_dma) {
-  g_extend_dma = lds_dma < 0 ? 0 : (lds_dma > 2 ? 2 : lds_dma);   // (2: the 8-wave form of the LDS-DMA kernel, a measurement variant)
+// measurement / test hook: 0 = always the register-staged kernel, 1 (default) = the LDS-DMA kernel where it applies with 4 or 8 waves
+// per workgroup by the mean-keys rule, 2 = always 8 waves, 3 = always 4 waves
+extern "C" int sgl_mi355_extend_attention_set_mode(int mode) {
+  g_extend_dma = mode < 0 ? 0 : (mode > 3 ? 3 : mode);
+  return SGL_MI355_OK;
+}
+// host-side knowledge the kernel arguments do not carry: the mean number of keys a query block of the NEXT calls attends to
+// (per request: prefix + extend / 2 when causal); 0 = unknown (the launcher then assumes no prefix)
+extern "C" int sgl_mi355_extend_attention_set_kv_hint(int mean_keys_per_query_block) {
+  g_extend_kv_hint = mean_keys_per_query_block > 0 ? mean_keys_per_query_block : 0;
   return SGL_MI355_OK;
 }
 

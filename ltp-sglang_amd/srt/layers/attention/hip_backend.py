@@ -228,6 +228,10 @@ class HipAttnBackend(AttentionBackend):
         ext_cpu = forward_batch.extend_seq_lens_cpu
         max_extend_len = int(max(ext_cpu)) if ext_cpu is not None else int(forward_batch.extend_seq_lens.max().item())
         self.forward_metadata = ForwardMetadata(None, None, max_extend_len, None, kv_indptr, kv_indices, qo_indptr)
+        if pre_cpu is not None and ext_cpu is not None and bs > 0:
+            # what the extend kernel's launcher cannot see in its arguments: how many keys a query block walks on average
+            # (prefix + half the causal triangle) -- it picks 4 or 8 waves per workgroup by it
+            lib.sgl_mi355_extend_attention_set_kv_hint(int(sum(p + e // 2 for p, e in zip(pre_cpu, ext_cpu)) // bs))
         if self._has_window():
             md = self.forward_metadata
             md.window_kv_indptr, md.window_kv_indices, _ = self._window_metadata(

@@ -92,7 +92,7 @@ def test_extend_head_group_shapes(hq, hkv, pkg):
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
 @pytest.mark.parametrize("hq,hkv,pre,ext", [(32, 8, [0, 0], [300, 77]), (8, 2, [130, 64, 0], [45, 200, 513]), (12, 12, [5], [260]),
-                                            (32, 2, [70, 0], [129, 33]), (6, 2, [257, 31], [64, 1])])
+                                            (32, 2, [70, 0], [129, 33]), (6, 2, [257, 31], [64, 1]), (8, 2, [1700], [300])])
 def test_extend_lds_dma_kernel_equals_register_staged_kernel(dtype, hq, hkv, pre, ext, pkg):
     """16-bit K/V, D = 128, no mask / cap: the default is the LDS-DMA kernel (csrc/extend_attention.hip extend_attn_dma_kernel: same
     tiles, fragment maps and arithmetic order, only the way the tiles reach LDS and the fragments reach registers differs) -- bit
@@ -101,14 +101,26 @@ def test_extend_lds_dma_kernel_equals_register_staged_kernel(dtype, hq, hkv, pre
     case = dict(name="dma", kind="extend", dtype=dtype, hq=hq, hkv=hkv, d=128, pre=pre, ext=ext)
     c = _cases.build_attn_case(case, seed=hq + len(pre))
     for causal in (True, False):
-        got = _run(pkg, c, causal=causal)
+        outs = {}
         try:
-            _cabi.check(_cabi.lib.sgl_mi355_extend_attention_set_mode(0))
-            ref = _run(pkg, c, causal=causal)
+            for mode in (0, 2, 3):   # register-staged; LDS-DMA with 8 and with 4 waves per workgroup
+                _cabi.check(_cabi.lib.sgl_mi355_extend_attention_set_mode(mode))
+                outs[mode] = _run(pkg, c, causal=causal)
         finally:
             _cabi.lib.sgl_mi355_extend_attention_set_mode(1)
-        assert torch.equal(got, ref)
-        assert (got.double() - _f64(c, causal=causal)).abs().max().item() <= TOL_F64[c["dtype"]]
+        assert torch.equal(outs[2], outs[0]) and torch.equal(outs[3], outs[0])
+        assert (outs[0].double() - _f64(c, causal=causal)).abs().max().item() <= TOL_F64[c["dtype"]]
+    # the default rule (4 or 8 waves by the mean number of keys per query block: the caller's hint, else extend / 2)
+    try:
+        for hint in (0, 100, 5000):
+            _cabi.check(_cabi.lib.sgl_mi355_extend_attention_set_kv_hint(hint))
+            got = _run(pkg, c, causal=True)
+            _cabi.lib.sgl_mi355_extend_attention_set_mode(0)
+            ref = _run(pkg, c, causal=True)
+            _cabi.lib.sgl_mi355_extend_attention_set_mode(1)
+            assert torch.equal(got, ref)
+    finally:
+        _cabi.lib.sgl_mi355_extend_attention_set_kv_hint(0)
 
 
 def test_extend_long_sequence_properties(pkg):
