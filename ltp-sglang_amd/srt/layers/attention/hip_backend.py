@@ -180,6 +180,12 @@ class HipAttnBackend(AttentionBackend):
         bs = forward_batch.batch_size
         if not forward_batch.forward_mode.is_decode() or not self._cascade_ok(bs, shared_prefix_len):
             return self.init_forward_metadata(forward_batch)
+        lens_cpu = getattr(forward_batch, "seq_lens_cpu", None)
+        if lens_cpu is not None and len(lens_cpu) and min(int(x) for x in lens_cpu) <= shared_prefix_len:
+            # a request that ends inside the "shared" prefix would hand the suffix pass a negative length (checked on host-side
+            # lengths only: no device sync; that the slots really are shared is the caller's contract -- match_prefix)
+            raise ValueError(f"cascade decode: every request must be longer than the shared prefix ({shared_prefix_len}); "
+                             f"shortest is {min(int(x) for x in lens_cpu)}")
         if prefix_splits is None:
             prefix_splits = self._cascade_prefix_splits(bs, shared_prefix_len)
         self.forward_metadata = self._cascade_metadata(bs, forward_batch.req_pool_indices, forward_batch.seq_lens,

@@ -486,3 +486,7 @@ def test_backend_cascade_metadata_and_forward(pkg):
     _, oq_, os_ = backend.forward_decode_merged_quant(q, layer, fb)
     deq = oq_.float().cpu() * os_.cpu()
     assert (deq - casc).abs().max().item() <= 0.07 * casc.abs().max().item()
+    # a request that ends inside the "shared" prefix is refused on the host-side lengths (no device sync)
+    fb.seq_lens_cpu = P["seq"].clone()
+    with pytest.raises(ValueError, match="longer than the shared prefix"):
+        backend.init_forward_metadata_cascade(fb, int(P["seq"].min()))
