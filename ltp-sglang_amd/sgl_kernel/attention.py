@@ -103,8 +103,9 @@ def extend_attention_fwd(
     assert q_extend.stride(2) == 1 and q_extend.stride(1) == d and o_extend.stride(1) == dv
     assert k_extend.stride(1) == d and v_extend.stride(1) == dv and k_extend.stride(2) == 1 and v_extend.stride(2) == 1
     assert qo_indptr.dtype == torch.int32 and kv_indptr.dtype == torch.int32 and kv_indices.dtype == torch.int32
-    kst, ksh = _row_strides(k_buffer)
-    vst, vsh = _row_strides(v_buffer)
+    # (k_buffer / v_buffer None: no request of the batch has a cached prefix -- nothing is read from the pool, whatever its dtype)
+    kst, ksh = _row_strides(k_buffer) if k_buffer is not None else (0, 0)
+    vst, vsh = _row_strides(v_buffer) if v_buffer is not None else (0, 0)
     sm_scale = sm_scale or 1.0 / (d ** 0.5)
     check(
         lib.sgl_mi355_extend_attention(

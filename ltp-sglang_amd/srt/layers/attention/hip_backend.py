@@ -309,11 +309,14 @@ class HipAttnBackend(AttentionBackend):
             forward_batch.token_to_kv_pool.set_kv_buffer(layer, forward_batch.out_cache_loc, k, v, layer.k_scale, layer.v_scale)
         md = self.forward_metadata
         causal = not (layer.is_cross_attention or getattr(layer.attn_type, "value", "decoder") == "encoder_only")
+        # no cached prefix anywhere in the batch (the size of kv_indices is host knowledge): nothing is read from the pool, so the
+        # kernel need not know its dtype -- an fp8 pool would otherwise select the fp8-prefix instantiation for rows that do not exist
+        no_prefix = kv_indices.numel() == 0
         K.extend_attention_fwd(
             q.view(-1, layer.tp_q_head_num, layer.qk_head_dim), _rows(k), _rows(v),
             o.view(-1, layer.tp_q_head_num, layer.v_head_dim),
-            forward_batch.token_to_kv_pool.get_key_buffer(layer.layer_id),
-            forward_batch.token_to_kv_pool.get_value_buffer(layer.layer_id),
+            None if no_prefix else forward_batch.token_to_kv_pool.get_key_buffer(layer.layer_id),
+            None if no_prefix else forward_batch.token_to_kv_pool.get_value_buffer(layer.layer_id),
             md.qo_indptr, kv_indptr, kv_indices, md.custom_mask, causal, md.mask_indptr, md.max_extend_len, layer.scaling,
             layer.logit_cap, sliding_window_size=window, k_scale=layer.k_scale_float or 1.0, v_scale=layer.v_scale_float or 1.0,
         )
