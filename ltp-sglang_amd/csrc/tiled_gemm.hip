@@ -807,7 +807,7 @@ int tg_cus() {
   }
   return cus;
 }
-int g_tiled_group_m = 4;
+int g_tiled_group_m = 8;   // r3 sweep (tools/debug/gm_sweep.py, M = 8192 / 16 384 / 65 536 x the four Llama-3-8B shapes): 8 is as fast as 4 or up to 5 % faster (4 until round 3)
 int g_tiled_stagger = 1;  // x 1024 cycles per step, 16 steps: CUs spread over ~6.5 us
 int g_tiled_force = 0;  // test hook: 1 = always the 128x128 kernel, 2 = the 256x256 kernel whenever its shape rules allow
 
