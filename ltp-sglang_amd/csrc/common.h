@@ -80,6 +80,31 @@ struct ElemTraits<_Float16> {
   static __device__ __forceinline__ _Float16 from_f32(float x) { return (_Float16)x; }
 };
 
+// Combine a value over the lane pairs (i, i ^ 16) / (i, i ^ 32) with two VALU lane swaps instead of an LDS round trip
+// (ds_bpermute, what __shfl_xor compiles to for these distances): v_permlane16_swap(x, x) leaves the even 16-lane rows in one result
+// and the odd rows in the other, v_permlane32_swap the two 32-lane halves -- op(first, second) is then op(own, partner) for a
+// commutative op, bit for bit (round 3: these sit in the middle of the attention kernels' softmax chains).
+__device__ __forceinline__ float pair16_max(float v) {
+  const uint32_t b = __builtin_bit_cast(uint32_t, v);
+  const auto r = __builtin_amdgcn_permlane16_swap(b, b, false, false);
+  return fmaxf(__builtin_bit_cast(float, (uint32_t)r[0]), __builtin_bit_cast(float, (uint32_t)r[1]));
+}
+__device__ __forceinline__ float pair32_max(float v) {
+  const uint32_t b = __builtin_bit_cast(uint32_t, v);
+  const auto r = __builtin_amdgcn_permlane32_swap(b, b, false, false);
+  return fmaxf(__builtin_bit_cast(float, (uint32_t)r[0]), __builtin_bit_cast(float, (uint32_t)r[1]));
+}
+__device__ __forceinline__ float pair16_sum(float v) {
+  const uint32_t b = __builtin_bit_cast(uint32_t, v);
+  const auto r = __builtin_amdgcn_permlane16_swap(b, b, false, false);
+  return __builtin_bit_cast(float, (uint32_t)r[0]) + __builtin_bit_cast(float, (uint32_t)r[1]);
+}
+__device__ __forceinline__ float pair32_sum(float v) {
+  const uint32_t b = __builtin_bit_cast(uint32_t, v);
+  const auto r = __builtin_amdgcn_permlane32_swap(b, b, false, false);
+  return __builtin_bit_cast(float, (uint32_t)r[0]) + __builtin_bit_cast(float, (uint32_t)r[1]);
+}
+
 // wave-wide xor shuffle (ds_bpermute / DPP chosen by the compiler)
 __device__ __forceinline__ float wave_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, WAVE); }
 

@@ -377,8 +377,7 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attn_stage1(const DecodePar
         mt = fmaxf(mt, x[tt][r]);
       }
     }
-    mt = fmaxf(mt, __shfl_xor(mt, 16, WAVE));
-    mt = fmaxf(mt, __shfl_xor(mt, 32, WAVE));
+    mt = pair32_max(pair16_max(mt));   // over the four lane groups of a head (VALU lane swaps, no LDS round trip)
     const float m_new = fmaxf(m_i, mt * cs);  // finite: every tile holds >= 1 valid token
     const float alpha = __builtin_amdgcn_exp2f(m_i - m_new);
     float lsum = 0.0f;
@@ -417,8 +416,7 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attn_stage1(const DecodePar
   }
 
   // ---- merge the NW wave-private states, write the split partial ----
-  l_i += __shfl_xor(l_i, 16, WAVE);
-  l_i += __shfl_xor(l_i, 32, WAVE);
+  l_i = pair32_sum(pair16_sum(l_i));
   if constexpr (MODE == 1) {
     // the wave IS the split: write acc / l and m + log(l) straight from the accumulator layout
     if (a < nh) {

@@ -61,6 +61,7 @@ struct ExtendParams {
   int casc_bs = 0, casc_prefix_len = 0, casc_chunk = 0, casc_slot0 = 0, max_kv_splits = 0;
   float* part_o = nullptr;
   float* part_lse = nullptr;
+  long long* tl = nullptr;   // SGL_EXT_TIMELINE builds only
 };
 
 constexpr int kKT = 64;  // kv tokens per tile
@@ -396,8 +397,7 @@ __global__ __launch_bounds__(256, 2) void extend_attn_kernel(const ExtendParams 
         for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) m = fmaxf(m, s[qt][tt][r]);
-        m = fmaxf(m, __shfl_xor(m, 16, WAVE));
-        m = fmaxf(m, __shfl_xor(m, 32, WAVE));
+        m = pair32_max(pair16_max(m));
         const float m_new = fmaxf(m_i[qt], m * cs);
         const float m_safe = fmaxf(m_new, -1e30f);
         const float alpha = __builtin_amdgcn_exp2f(m_i[qt] - m_safe);
@@ -468,8 +468,7 @@ __global__ __launch_bounds__(256, 2) void extend_attn_kernel(const ExtendParams 
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
     float l = l_i[qt];
-    l += __shfl_xor(l, 16, WAVE);
-    l += __shfl_xor(l, 32, WAVE);
+    l = pair32_sum(pair16_sum(l));
     if (cascade) {   // split partial of (request qpos, head hq_idx): O = acc / l in f32 and LSE = m ln 2 + ln l, the decode kernel's slot layout
       if (head_ok[qt] && qpos[qt] < ext_len) {
         const int64_t slot = ((int64_t)qpos[qt] * p.hq + hq_idx[qt]) * p.max_kv_splits + p.casc_slot0 + b;
@@ -522,6 +521,13 @@ __device__ __forceinline__ int ext_load_i32(const int32_t* src) {
   return v;
 }
 
+#ifdef SGL_EXT_TIMELINE
+// tools/debug/ext_timeline.py: s_memtime stamps of workgroup SGL_EXT_TIMELINE's four waves, first 24 tiles, 6 stamps per tile
+long long* g_ext_tl = nullptr;
+#define EXT_STAMP(k) do { if (tl && t < 24) tl[((w * 24 + t) * 6) + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define EXT_STAMP(k) do { } while (0)
+#endif
 int g_extend_dma = 1;  // sgl_mi355_extend_attention_set_mode: 0 = always the register-staged kernel, 1 = LDS-DMA kernel, 4 or 8 waves by the rule in launch_mfma, 2 / 3 = always 8 / 4 waves
 int g_extend_kv_hint = 0;  // sgl_mi355_extend_attention_set_kv_hint: mean keys a query block attends to (0: unknown)
 
@@ -565,6 +571,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void extend_attn_dma_kern
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int a = lane & 15, g = lane >> 4;
+#ifdef SGL_EXT_TIMELINE
+  long long* tl = (blockIdx.x == SGL_EXT_TIMELINE && lane == 0) ? p.tl : nullptr;
+#endif
 
   vec8 qf[QT][KS];
 #pragma unroll
@@ -625,6 +634,19 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void extend_attn_dma_kern
     }
   };
 
+  auto stage_ext = [&](int t) {   // the same for a tile of new tokens only (npre_tiles == 0)
+    const int base = t * kKT + RPWV * w + srow;
+    const unsigned kdst = (unsigned)(uintptr_t)(lptr_t)(smem + (t & 1) * 2 * TILE_B + (RPWV * w) * ROWB);
+    const unsigned vdst = kdst + TILE_B;
+#pragma unroll
+    for (int i = 0; i < NIW; ++i) {
+      const int rr = min(base + 4 * i, ext_len - 1);
+      const int r = (RPWV * w + 4 * i + srow) & 15;
+      ext_dma16(kext + (int64_t)rr * kest + ((spos ^ r) << 4), kdst + i * 4 * ROWB);
+      ext_dma16(vext + (int64_t)rr * vest + (((((spos >> 1) ^ (r & 7)) << 1) | (spos & 1)) << 4), vdst + i * 4 * ROWB);
+    }
+  };
+
   float m_i[QT], l_i[QT];
   f32x4_t acc[QT][NT];
 #pragma unroll
@@ -651,9 +673,17 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void extend_attn_dma_kern
 
   for (int t = 0; t < ntiles; ++t) {
     // slots of tile t + 2 first, then tile t + 1's DMA (buffer (t + 1) & 1 held tile t - 1: its last readers passed the barrier)
+    EXT_STAMP(0);
     int idn2[NIW];
-    load_idx(t + 2, idn2);
-    if (t + 1 < ntiles) stage(t + 1, idn);
+    if (npre_tiles > 0) {   // (kernel-uniform: a batch without cached prefix needs neither pool slots nor address selects)
+      load_idx(t + 2, idn2);
+      if (t + 1 < ntiles) stage(t + 1, idn);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NIW; ++i) idn2[i] = 0;
+      if (t + 1 < ntiles) stage_ext(t + 1);
+    }
+    EXT_STAMP(1);
     const char* kl = smem + (t & 1) * 2 * TILE_B;
     const char* vl = kl + TILE_B;
     const bool in_prefix = t < npre_tiles;
@@ -670,16 +700,16 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void extend_attn_dma_kern
         kf[f] = *(const vec8*)(kl + row * ROWB + (((4 * (f & 3) + g) ^ (row & 15)) << 4));
       }
       __builtin_amdgcn_sched_barrier(0);   // (left free, the scheduler sinks each read to just before its MFMA: a round trip per pair)
+      // k-steps outermost: eight independent accumulators between two MFMAs on the same one (per accumulator still ks = 0..3 in order)
 #pragma unroll
-      for (int tt = 0; tt < 4; ++tt)
+      for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-          f32x4_t c = {0.f, 0.f, 0.f, 0.f};
+        for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
-          for (int ks = 0; ks < KS; ++ks) c = Tr::mfma16(kf[4 * tt + ks], qf[qt][ks], c);
-          s[qt][tt] = c;
-        }
+          for (int qt = 0; qt < QT; ++qt)
+            s[qt][tt] = Tr::mfma16(kf[4 * tt + ks], qf[qt][ks], ks == 0 ? f32x4_t{0.f, 0.f, 0.f, 0.f} : s[qt][tt]);
     }
+    EXT_STAMP(2);
     // ragged last tile of a phase / causal diagonal: ONE wave-uniform branch, branch-free inside
     const int wave_qmin = qpos0 + (bq >= 16 * QT ? ((16 * QT * w) & (bq - 1)) : 0);
     if ((kbase + kKT > klimit) || (!in_prefix && p.is_causal && kbase + kKT - 1 > wave_qmin)) {
@@ -703,8 +733,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void extend_attn_dma_kern
       for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) m = fmaxf(m, s[qt][tt][r]);
-      m = fmaxf(m, __shfl_xor(m, 16, WAVE));
-      m = fmaxf(m, __shfl_xor(m, 32, WAVE));
+      m = pair32_max(pair16_max(m));   // two VALU lane swaps instead of two LDS round trips in the middle of the softmax's chain
       const float m_new = fmaxf(m_i[qt], m * cs);
       const float m_safe = fmaxf(m_new, -1e30f);
       const float alpha = __builtin_amdgcn_exp2f(m_i[qt] - m_safe);
@@ -723,6 +752,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void extend_attn_dma_kern
 #pragma unroll
       for (int n = 0; n < NT; ++n) acc[qt][n] *= alpha;
     }
+    EXT_STAMP(3);
     // ---- O^T += V^T P^T: every V^T fragment of the tile in flight before the first MFMA; per (qt, n) u = 0, 1 in order ----
     {
       vec8 vf[16];   // fragment 2 n + u
@@ -743,27 +773,29 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void extend_attn_dma_kern
         vf[f] = __builtin_bit_cast(vec8, __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7));
       }
       __builtin_amdgcn_sched_barrier(0);
+      // k-steps outermost: sixteen independent accumulators between the two MFMAs of one (per accumulator still u = 0, 1 in order)
 #pragma unroll
-      for (int n = 0; n < NT; ++n)
+      for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int n = 0; n < NT; ++n)
 #pragma unroll
           for (int qt = 0; qt < QT; ++qt) acc[qt][n] = Tr::mfma16(vf[2 * n + u], pf[qt][u], acc[qt][n]);
     }
+    EXT_STAMP(4);
     // tile t + 1 has landed and the slots of tile t + 2 are known (handed on THROUGH the wait so that nothing reads them above it)
 #pragma unroll
     for (int i = 0; i < NIW; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+v"(idn2[i])::"memory");
 #pragma unroll
     for (int i = 0; i < NIW; ++i) idn[i] = idn2[i];
     __syncthreads();
+    EXT_STAMP(5);
   }
 
   // ---- o = acc / l ----
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
     float l = l_i[qt];
-    l += __shfl_xor(l, 16, WAVE);
-    l += __shfl_xor(l, 32, WAVE);
+    l = pair32_sum(pair16_sum(l));
     const int t16 = (QT * w + qt) * 16;
     const int hslot = t16 >> p.bq_log2;
     const int hl = hc * (4 * QT) + hslot;
@@ -975,6 +1007,13 @@ extern "C" int sgl_mi355_extend_attention_set_kv_hint(int mean_keys_per_query_bl
   return SGL_MI355_OK;
 }
 
+#ifdef SGL_EXT_TIMELINE
+extern "C" int sgl_mi355_extend_attention_debug_timeline(long long* buf) {
+  g_ext_tl = buf;
+  return SGL_MI355_OK;
+}
+#endif
+
 extern "C" int sgl_mi355_extend_attention(
     const void* q_extend, const void* k_extend, const void* v_extend, void* o_extend, int64_t q_stride_t,
     int64_t k_stride_t_ext, int64_t v_stride_t_ext, int64_t o_stride_t, const void* k_buffer, const void* v_buffer,
@@ -1025,6 +1064,9 @@ extern "C" int sgl_mi355_extend_attention(
   p.nqb = 0; p.bq_log2 = 0; p.hchunks = 1;
   p.custom_mask = custom_mask; p.mask_indptr = mask_indptr; p.skip_prefix_mask = skip_prefix_custom_mask ? 1 : 0;
   p.sliding_window = sliding_window_size > 0 ? sliding_window_size : 0;
+#ifdef SGL_EXT_TIMELINE
+  p.tl = g_ext_tl;
+#endif
   hipStream_t st = (hipStream_t)stream;
   return dtype == SGL_BF16 ? launch_all<__bf16>(p, head_dim, v_head_dim, total_q_tokens, max_len_extend, st)
                            : launch_all<_Float16>(p, head_dim, v_head_dim, total_q_tokens, max_len_extend, st);
