@@ -108,14 +108,28 @@ __device__ __forceinline__ float pair32_sum(float v) {
 // wave-wide xor shuffle (ds_bpermute / DPP chosen by the compiler)
 __device__ __forceinline__ float wave_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, WAVE); }
 
+// Wave-wide reductions without LDS round trips (round 3): hipcc compiles every __shfl_xor step to a ds_bpermute, six dependent LDS
+// round trips per reduction -- a tenth of a decode-sized row kernel's lifetime.  Distances 32 and 16 by lane swaps (above), 8, 4, 2, 1
+// by DPP row rotations (within a 16-lane row the partial sums have period 2 x distance, so rotating by the distance reaches the same
+// partner values as the xor butterfly): the same pairs are combined in the same order, so max and sum give the same bits as before.
+template <int CTRL>
+__device__ __forceinline__ float dpp_row(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float wave_reduce_max(float v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, WAVE));
+  v = pair16_max(pair32_max(v));
+  v = fmaxf(v, dpp_row<0x128>(v));   // row_ror:8
+  v = fmaxf(v, dpp_row<0x124>(v));   // row_ror:4
+  v = fmaxf(v, dpp_row<0x122>(v));   // row_ror:2
+  v = fmaxf(v, dpp_row<0x121>(v));   // row_ror:1
   return v;
 }
 __device__ __forceinline__ float wave_reduce_sum(float v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, WAVE);
+  v = pair16_sum(pair32_sum(v));
+  v += dpp_row<0x128>(v);
+  v += dpp_row<0x124>(v);
+  v += dpp_row<0x122>(v);
+  v += dpp_row<0x121>(v);
   return v;
 }
 
