@@ -116,6 +116,11 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_row(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
+// value of lane i ^ 8 / i ^ 4 by DPP (one / two VALU moves) instead of a ds_bpermute round trip: within a 16-lane row, i ^ 8 is a
+// rotation by 8; i ^ 4 is the half-row mirror (i -> 7 - i within 8 lanes) followed by the quad mirror (j -> 3 - j within 4 lanes)
+__device__ __forceinline__ float lane_xor8(float v) { return dpp_row<0x128>(v); }
+__device__ __forceinline__ float lane_xor4(float v) { return dpp_row<0x1B>(dpp_row<0x141>(v)); }   // quad_perm [3,2,1,0] after row_half_mirror
+
 __device__ __forceinline__ float wave_reduce_max(float v) {
   v = pair16_max(pair32_max(v));
   v = fmaxf(v, dpp_row<0x128>(v));   // row_ror:8

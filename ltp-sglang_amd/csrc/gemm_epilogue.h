@@ -48,7 +48,7 @@ __device__ __forceinline__ void epi_store(float v, bool live, int em, int en, in
   static_assert(EPI == EPI_SILU || EPI == EPI_ROPE, "fused epilogues only");
   const float vr = rnd_to<OutT>(v);             // the GEMM's own output rounding
   const int H = rpt >> 1;                       // rows of each half of an interleaved tile (8, or 4 for 8-row tiles)
-  const float pr = __shfl_xor(vr, H, WAVE);     // the partner column of the same row m
+  const float pr = H == 8 ? lane_xor8(vr) : lane_xor4(vr);   // the partner column of the same row m (DPP: no LDS round trip)
   const bool lo = (en & H) == 0;                // first half of the tile (gate / rotation-pair index i)
   if constexpr (EPI == EPI_SILU) {
     if (live && lo) {
