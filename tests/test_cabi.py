@@ -90,3 +90,21 @@ def test_forward_mode_and_backend_dispatch(pkg):
     assert calls == ["decode", "extend", "extend"]
     assert b.forward(q, None, None, layer, SimpleNamespace(forward_mode=ForwardMode.IDLE)).shape == (3, 32)
     assert b.support_triton() is True
+
+
+def test_fp8_gemm_kernel_choice_and_k_partition_are_host_logic(pkg):
+    """Which tile fp8_scaled_mm takes above M = 64 and into how many k-ranges it splits is decided on the host (csrc/tiled_gemm.hip
+    takes128s / splits128s: two measured cost lines); sgl_mi355_fp8_gemm_num_slabs reports it without touching a GPU (256 CUs assumed
+    when no device is present).  Pinned here: the Llama-3-70B TP-8 shard shapes at M = 128, the 256 < M <= 1024 band, prefill."""
+    from ltp_sglang_amd import _cabi
+
+    f = _cabi.lib.sgl_mi355_fp8_gemm_num_slabs
+    ws = 1 << 24
+    want = {(128, 1280, 8192): 8, (128, 8192, 1024): 1, (128, 7168, 8192): 4, (128, 8192, 3584): 3,   # streaming tile, split-K by tiles < CUs
+            (512, 1024, 4096): 4, (320, 4096, 2048): 2,                                             # the band where the 256x256 tile would idle CUs
+            (1024, 4096, 2048): 1, (512, 28672, 4096): 1, (1024, 4096, 14336): 1,                   # one k-range (either tile)
+            (65536, 28672, 4096): 1, (16384, 6144, 4096): 1}                                        # prefill: the 256x256 tile
+    got = {k: int(f(k[0], k[1], k[2], ws)) for k in want}
+    assert got == want
+    assert int(f(128, 1280, 8192, 0)) == 1          # no workspace: no split
+    assert int(f(0, 128, 128, ws)) == 1 and int(f(128, 128, 100, ws)) == 1   # degenerate / K not whole 128-byte slices
