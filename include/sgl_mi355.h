@@ -228,7 +228,8 @@ int sgl_mi355_skinny_gemm_slabs_min(const void* x, int64_t x_stride_elems, const
 int sgl_mi355_skinny_gemm_force_generic(int on);
 /* Test hook for sgl_mi355_fp8_gemm's tile choice: 0 = by shape, 1 = always 128x128 tiles, 2 = 256x256 tiles whenever K is
   * a multiple of 128 (8 waves), 3 = the same tile with 4 waves of 128x128 outputs (accumulators in AGPRs), 4 = register-staged 256x256, 5 = the 4-stage
-  * streaming 128x128 tile (default for M <= 256); 100 + g = scheduling group height g of the 256x256 kernel. */
+  * streaming 128x128 tile (default for M <= 256), 7 = the 256x128 tile (eight waves of 64x64 outputs; default where 256x256 tiles are
+  * fewer than the CUs and half-size tiles fill them); 100 + g = scheduling group height g of the 256x256 kernel. */
 int sgl_mi355_fp8_gemm_force_tile(int mode);
 /* Tiled MFMA GEMM for M > 64 with the same contract as sgl_mi355_skinny_gemm's fp8 case:
  * fp8_scaled_mm, sgl-kernel/csrc/gemm/fp8_gemm_kernel.cu:1071-1146 (CUTLASS tile dispatch :303-440,739-796). */
@@ -240,6 +241,9 @@ int sgl_mi355_fp8_gemm(const void* x, int64_t x_stride_elems, const void* w, int
  * partial sums it forms for this shape and scratch size (1: none); fp8_gemm_slabs writes them raw (no scales) for
  * sgl_mi355_fused_add_rmsnorm_quant_fp8 (slabs + sx + sw), with fp8_gemm's own k-range partition. */
 int sgl_mi355_fp8_gemm_num_slabs(int M, int N, int K, int64_t workspace_floats);
+/* Which kernel sgl_mi355_fp8_gemm picks for this shape (contiguous rows; host logic only): 0 = 256x256 tile, 1 = streaming 128x128
+ * tile, 2 = 256x128 tile.  The counterpart of the reference's shape-keyed CUTLASS tile dispatch (fp8_gemm_kernel.cu:303-440). */
+int sgl_mi355_fp8_gemm_tile_choice(int M, int N, int K, int64_t workspace_floats);
 int sgl_mi355_fp8_gemm_slabs(const void* x, int64_t x_stride_elems, const void* w, int64_t w_stride_elems, float* slabs, int M,
                              int N, int K, int64_t workspace_floats, void* stream);
 /* (workspace: optional f32 scratch for split-K when a launch has fewer 128x128 output tiles than half the CUs -- decode at

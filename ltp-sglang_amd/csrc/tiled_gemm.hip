@@ -303,7 +303,7 @@ constexpr int kEpiRowB = 128;  // bytes per staged row: 64 outputs of 2 bytes (8
 template <typename OutT, int NI, int NJ>
 __device__ __forceinline__ void epilogue_scaled_lds(const GemmParams& p, const f32x4_t (&acc)[NJ][NI], int mrow_base, int ncol_base,
                                                     char* wave_lds, int lane) {
-  static_assert(NJ == 4 && NI == 8, "one wave = 128 rows x 64 columns");
+  static_assert(NJ == 4 && (NI == 8 || NI == 4), "one wave = 128 (or 64) rows x 64 columns");
   const int a = lane & 15, g = lane >> 4;
   float sxv[NI], swv[NJ][4], bv[NJ][4];
 #pragma unroll
@@ -349,7 +349,7 @@ __device__ __forceinline__ void epilogue_scaled_lds(const GemmParams& p, const f
   const int rsub = lane >> 3, c16 = lane & 7;  // 8 lanes cover one 128-byte row
   const bool col_ok = ncol_base + 8 * c16 + 7 < p.N;
 #pragma unroll
-  for (int it = 0; it < 16; ++it) {
+  for (int it = 0; it < 2 * NI; ++it) {
     const int row = 8 * it + rsub;
     const u32x4_t v = *(const u32x4_t*)(wave_lds + row * kEpiRowB + ((c16 ^ (row & 7)) << 4));
     const int m = mrow_base + row;
@@ -454,12 +454,24 @@ __device__ __forceinline__ void epilogue_silu_lds(const GemmParams& p, const f32
 
 // ES: TG_FP8 (block-scaled MFMA over the whole 128-byte slice) or TG_BF16 / TG_F16 (two 16x16x32 k-steps per slice: the
 // same LDS reads, chunk 4 h + g being exactly k-step h's fragment)
-template <typename OutT, int NWV, bool DMA = true, int ES = TG_FP8, bool SILU = false>  // NWV = 8: waves 2 (M) x 4 (N), 128 x 64 outputs each; 4: 2 x 2
+// WN: W rows (output columns) per tile.  256, or 128 with four waves -- the same 128 x 64 wave tile and slice pipeline over a
+// 256 x 128 output tile, for launches whose 256 x 256 tiles are fewer than the CUs (chunked prefill, M ~ 1024-4096)
+template <typename OutT, int NWV, bool DMA = true, int ES = TG_FP8, bool SILU = false, int WN = 256>  // NWV = 8: waves 2 (M) x 4 (N), 128 x 64 outputs each; 4: 2 x 2
 __global__ __launch_bounds__(NWV * 64, 1) void fp8_gemm256_kernel(const GemmParams p) {
-  constexpr int WCOLS = NWV == 8 ? 4 : 2;     // waves along N
-  constexpr int JN = 256 / WCOLS / 16;        // 16-column W fragments per wave
-  constexpr int RPW = 256 / NWV;              // staging rows per wave and operand
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][W 32 KiB | X 32 KiB]
+  constexpr int WCOLS = (NWV == 8 && WN == 256) ? 4 : 2;  // waves along N
+  constexpr int JN = WN / WCOLS / 16;         // 16-column W fragments per wave
+  constexpr int MR = 256 / (NWV / WCOLS);     // X rows (output rows) per wave: 128, or 64 for eight waves over a 256 x 128 tile
+  constexpr int NI = MR / 16;                 // 16-row X fragments per wave
+  constexpr int IG = NI / 4;                  // ... per MFMA group (four groups per slice)
+  static_assert(!SILU || (WN == 256 && NWV == 8), "the SiLU epilogue is written for the 256 x 256 tile");
+  constexpr int RPW = 256 / NWV;              // X staging rows per wave
+  constexpr int WRPW = WN / NWV;              // W staging rows per wave
+  constexpr int WOPB = WN * BKB;              // W bytes per buffer
+  constexpr int BUFB = WOPB + OPB;            // one buffer: [W | X 32 KiB]
+  constexpr int NBUF = WN == 128 ? 3 : 2;     // slice buffers: a ring of three 48 KiB buffers for the narrow tile (a slice is half the MFMA time: one slice of prefetch distance does not cover the fetch)
+  constexpr int DMA_PER_SLICE = (RPW + WRPW) / 8;  // LDS-DMA instructions per wave and slice
+  static_assert(WRPW % 16 == 0 && RPW % 16 == 0, "the staging swizzle below assumes 16-row aligned wave bases");
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][W | X]
   const int nwg = p.tiles_m * p.tiles_n;
   const int bid = blockIdx.x;
   const int q = nwg / 8, r8 = nwg % 8, xcd = bid % 8;
@@ -472,11 +484,11 @@ __global__ __launch_bounds__(NWV * 64, 1) void fp8_gemm256_kernel(const GemmPara
   const int grp = wgid / per_group, in_grp = wgid - grp * per_group;
   const int gsz = min(p.tiles_m - grp * GM, GM);
   const int tm = grp * GM + in_grp % gsz, tn = in_grp / gsz;
-  const int m0 = tm * T2, n0 = tn * T2;
+  const int m0 = tm * T2, n0 = tn * WN;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = (w / WCOLS) * 128, wn = (w % WCOLS) * (16 * JN);
+  const int wm = (w / WCOLS) * MR, wn = (w % WCOLS) * (16 * JN);
   // Phase stagger: tiles of one launch take the same time on every CU, so without it all 256 CUs reach their epilogues together
   // and the burst of 256 x 128 KiB of output is write-bandwidth bound (5-6 us per tile with the MFMA pipes idle).  The first
   // workgroup of every CU starts up to p.stagger_us late; the workgroups that follow on that CU inherit its phase.
@@ -496,21 +508,23 @@ __global__ __launch_bounds__(NWV * 64, 1) void fp8_gemm256_kernel(const GemmPara
   unsigned wvo[2], xvo[2];
 #pragma unroll
   for (int par = 0; par < 2; ++par) {
-    const int rl = RPW * w + (lane >> 3);                          // row of 8-row group 0 (parity `par` adds 8 par rows)
-    const int chunk = (lane & 7) ^ (((lane >> 4) + 4 * par) & 7);  // ((row >> 1) & 7) for row = rl + 8 t, t & 1 == par
-    wvo[par] = (unsigned)((int64_t)(n0 + rl) * p.w_stride) + chunk * 16;
-    xvo[par] = (unsigned)((int64_t)(m0 + rl) * p.x_stride) + chunk * 16;
+    const int rl = lane >> 3;                                      // row of 8-row group 0 within the wave's rows (parity `par` adds 8 par rows)
+    const int chunk = (lane & 7) ^ (((lane >> 4) + 4 * par) & 7);  // ((row >> 1) & 7) for row = base + rl + 8 t, t & 1 == par, base % 16 == 0
+    wvo[par] = (unsigned)((int64_t)(n0 + WRPW * w + rl) * p.w_stride) + chunk * 16;
+    xvo[par] = (unsigned)((int64_t)(m0 + RPW * w + rl) * p.x_stride) + chunk * 16;
   }
   const int nk = p.kbytes / BKB;
+  static_assert(DMA || WN == 256, "register staging is only kept for the 256 x 256 tile");
   u32x4_t sreg[DMA ? 1 : RPW / 8][2];  // register staging (DMA == false): one 16-byte piece per 8-row group and operand
   auto stage = [&](int kt, int buf) {
     const int off = kt * BKB;
     if constexpr (DMA) {
-      auto* wb = (__attribute__((address_space(3))) char*)(smem + buf * 2 * OPB + (RPW * w) * BKB);
+      auto* wb = (__attribute__((address_space(3))) char*)(smem + buf * BUFB + (WRPW * w) * BKB);
+      auto* xb = (__attribute__((address_space(3))) char*)(smem + buf * BUFB + WOPB + (RPW * w) * BKB);
 #pragma unroll
       for (int t = 0; t < RPW / 8; ++t) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, wb + t * 8 * BKB, 16, wvo[t & 1], (int)(t * 8 * p.w_stride) + off, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, wb + OPB + t * 8 * BKB, 16, xvo[t & 1], (int)(t * 8 * p.x_stride) + off, 0, 0);
+        if (t < WRPW / 8) __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, wb + t * 8 * BKB, 16, wvo[t & 1], (int)(t * 8 * p.w_stride) + off, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, xb + t * 8 * BKB, 16, xvo[t & 1], (int)(t * 8 * p.x_stride) + off, 0, 0);
       }
     } else {
 #pragma unroll
@@ -522,51 +536,51 @@ __global__ __launch_bounds__(NWV * 64, 1) void fp8_gemm256_kernel(const GemmPara
   };
   auto commit = [&](int buf) {  // register staging: the pieces land where the LDS-DMA would have put them
     if constexpr (!DMA) {
-      char* wb = smem + buf * 2 * OPB + (RPW * w) * BKB + lane * 16;
+      char* wb = smem + buf * BUFB + (RPW * w) * BKB + lane * 16;
 #pragma unroll
       for (int t = 0; t < RPW / 8; ++t) {
         *(u32x4_t*)(wb + t * 8 * BKB) = sreg[t][0];
-        *(u32x4_t*)(wb + OPB + t * 8 * BKB) = sreg[t][1];
+        *(u32x4_t*)(wb + WOPB + t * 8 * BKB) = sreg[t][1];
       }
     }
   };
 
-  f32x4_t acc[JN][8];
+  f32x4_t acc[JN][NI];
 #pragma unroll
   for (int j = 0; j < JN; ++j)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < NI; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   // Software pipeline: every LDS read of slice kt is issued before the slice's single barrier, the fragments of the next
   // MFMA group are fetched while the current group runs, and the barrier sits before the LAST group, so that its wait,
   // the re-staging of the buffer just drained and the first fragment reads of slice kt + 1 all hide behind 8-16 MFMAs.
   constexpr int NG = 4;                 // MFMA groups per slice: 2 X row-tiles (32 rows) x JN column tiles each
-  u32x4_t wf[DMA ? 1 : 2][JN][2], xf[3][2][2];  // X fragments in a 3-slot rotation (LDS-DMA path: one W fragment set)
+  u32x4_t wf[DMA ? 1 : 2][JN][2], xf[3][IG][2];  // X fragments in a 3-slot rotation (LDS-DMA path: one W fragment set)
   auto load_w = [&](int buf, int ws) {
-    const char* wa = smem + buf * 2 * OPB;
+    const char* wa = smem + buf * BUFB;
 #pragma unroll
     for (int j = 0; j < JN; ++j)
 #pragma unroll
       for (int h = 0; h < 2; ++h) wf[ws][j][h] = *(const u32x4_t*)(wa + lds_off(wn + 16 * j + a, 4 * h + g));
   };
   auto load_x = [&](int buf, int grp, int slot) {
-    const char* xa = smem + buf * 2 * OPB + OPB;
+    const char* xa = smem + buf * BUFB + WOPB;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < IG; ++i)
 #pragma unroll
-      for (int h = 0; h < 2; ++h) xf[slot][i][h] = *(const u32x4_t*)(xa + lds_off(wm + 32 * grp + 16 * i + a, 4 * h + g));
+      for (int h = 0; h < 2; ++h) xf[slot][i][h] = *(const u32x4_t*)(xa + lds_off(wm + 16 * IG * grp + 16 * i + a, 4 * h + g));
   };
   auto mma = [&](int grp, int slot, int ws) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < IG; ++i)
 #pragma unroll
       for (int j = 0; j < JN; ++j) {
         if constexpr (ES == TG_FP8) {
-          mfma_mx(wf[ws][j][0], wf[ws][j][1], xf[slot][i][0], xf[slot][i][1], acc[j][2 * grp + i]);
+          mfma_mx(wf[ws][j][0], wf[ws][j][1], xf[slot][i][0], xf[slot][i][1], acc[j][IG * grp + i]);
         } else {
-          mfma_chunk<ES>(wf[ws][j][0], xf[slot][i][0], acc[j][2 * grp + i]);
-          mfma_chunk<ES>(wf[ws][j][1], xf[slot][i][1], acc[j][2 * grp + i]);
+          mfma_chunk<ES>(wf[ws][j][0], xf[slot][i][0], acc[j][IG * grp + i]);
+          mfma_chunk<ES>(wf[ws][j][1], xf[slot][i][1], acc[j][IG * grp + i]);
         }
       }
     __builtin_amdgcn_s_setprio(0);
@@ -576,8 +590,14 @@ __global__ __launch_bounds__(NWV * 64, 1) void fp8_gemm256_kernel(const GemmPara
     if constexpr (SILU) {   // the silu table -> LDS once per workgroup, behind the first slice's DMA
       for (int i = tid; i < kSiluLut / 8; i += NWV * 64) *(u32x4_t*)(smem + kSiluLdsOff + 16 * i) = *(const u32x4_t*)(p.silu_lut + 8 * i);
     }
-    __syncthreads();
-    stage(min(1, nk - 1), 1);
+    if constexpr (NBUF == 3) {   // ring of three: two slices stay in flight behind the one being multiplied
+      stage(min(1, nk - 1), 1);
+      stage(min(2, nk - 1), 2);
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * DMA_PER_SLICE) : "memory");
+    } else {
+      __syncthreads();
+      stage(min(1, nk - 1), 1);
+    }
     load_w(0, 0);
     load_x(0, 0, 0);
     // One slice = 4 MFMA groups g0..g3 (2 X row tiles x JN column tiles each).  X fragments rotate through three slots so
@@ -587,31 +607,34 @@ __global__ __launch_bounds__(NWV * 64, 1) void fp8_gemm256_kernel(const GemmPara
     auto slice = [&](int kt, int buf, auto r_) {
       constexpr int R = decltype(r_)::value;
       constexpr int S0 = R, S1 = (R + 1) % 3, S2 = (R + 2) % 3;  // g0 in S0 on entry; g1 -> S1, g2 -> S2, g3 -> S0
+      const int nb = NBUF == 3 ? (buf + 1) % 3 : buf ^ 1;        // the next slice's buffer
       load_x(buf, 1, S1);
       mma(0, S0, 0);
       load_x(buf, 2, S2);
       mma(1, S1, 0);
       load_x(buf, 3, S0);
       TL_STAMP(0);  // (stamps only where the wave drains lgkmcnt anyway: an s_memtime elsewhere serialises the LDS reads)
-      __syncthreads();  // slice kt + 1 has landed for every wave (vmcnt) and nobody reads buf any more (lgkmcnt)
+      // slice kt + 1 has landed for every wave (vmcnt) and nobody reads buf any more (lgkmcnt)
+      if constexpr (NBUF == 3) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(DMA_PER_SLICE) : "memory");   // (slice kt + 2 may still be in flight)
+      else __syncthreads();
       TL_STAMP(1);
-      load_x(buf ^ 1, 0, S1);           // next slice's g0 -> S1 = its S0 (after the last slice: a re-staged copy, never used)
-      stage(min(kt + 2, nk - 1), buf);  // branch free: the last two iterations re-stage the final slice into drained buffers
+      load_x(nb, 0, S1);                       // next slice's g0 -> S1 = its S0 (after the last slice: a re-staged copy, never used)
+      stage(min(kt + NBUF, nk - 1), buf);      // branch free: the last iterations re-stage the final slice into drained buffers
       mma(2, S2, 0);
       mma(3, S0, 0);
-      load_w(buf ^ 1, 0);               // the W fragments are free once the slice's last MFMA has issued
+      load_w(nb, 0);                           // the W fragments are free once the slice's last MFMA has issued
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>;
     int kt = 0;
     for (; kt + 2 < nk; kt += 3) {
-      slice(kt, kt & 1, I0{});
-      slice(kt + 1, (kt + 1) & 1, I1{});
-      slice(kt + 2, kt & 1, I2{});
+      slice(kt, NBUF == 3 ? 0 : kt & 1, I0{});
+      slice(kt + 1, NBUF == 3 ? 1 : (kt + 1) & 1, I1{});
+      slice(kt + 2, NBUF == 3 ? 2 : kt & 1, I2{});
     }
-    if (kt < nk) slice(kt, kt & 1, I0{});
-    if (kt + 1 < nk) slice(kt + 1, (kt + 1) & 1, I1{});
+    if (kt < nk) slice(kt, NBUF == 3 ? 0 : kt & 1, I0{});
+    if (kt + 1 < nk) slice(kt + 1, NBUF == 3 ? 1 : (kt + 1) & 1, I1{});
   } else {
     stage(0, 0);
     commit(0);
@@ -638,14 +661,14 @@ __global__ __launch_bounds__(NWV * 64, 1) void fp8_gemm256_kernel(const GemmPara
     epilogue_silu_lds<OutT>(p, acc, m0, wm, n0, wn, smem, tid, lane);
     return;
   }
-  if constexpr (NWV == 8) {
+  if constexpr (JN == 4) {   // 128 x 64 wave tiles: rows staged through the wave's own 16 KiB of LDS, written as whole 128-byte rows
     if (p.N % 8 == 0 && p.y_stride % 8 == 0 && ((uintptr_t)p.y & 15) == 0) {
       __syncthreads();  // every wave is past its last fragment read and every staged slice has landed: the LDS is free
-      epilogue_scaled_lds<OutT, 8, JN>(p, acc, m0 + wm, n0 + wn, smem + w * (128 * kEpiRowB), lane);
+      epilogue_scaled_lds<OutT, NI, JN>(p, acc, m0 + wm, n0 + wn, smem + w * (MR * kEpiRowB), lane);
       return;
     }
   }
-  epilogue_scaled<OutT, 8, JN>(p, acc, m0 + wm + a, n0 + wn + 4 * g);
+  epilogue_scaled<OutT, NI, JN>(p, acc, m0 + wm + a, n0 + wn + 4 * g);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -811,20 +834,20 @@ int g_tiled_group_m = 8;   // r3 sweep (tools/debug/gm_sweep.py, M = 8192 / 16 3
 int g_tiled_stagger = 1;  // x 1024 cycles per step, 16 steps: CUs spread over ~6.5 us
 int g_tiled_force = 0;  // test hook: 1 = always the 128x128 kernel, 2 = the 256x256 kernel whenever its shape rules allow
 
-template <typename OutT, int NWV, bool DMA = true, int ES = TG_FP8, bool SILU = false>
+template <typename OutT, int NWV, bool DMA = true, int ES = TG_FP8, bool SILU = false, int WN = 256>
 int launch256(GemmParams& p, hipStream_t st) {
-  constexpr int smem = 2 * 2 * OPB + (SILU ? kSiluLut * 2 : 0);  // 128 KiB (+ 18.5 KiB: the silu table)
+  constexpr int smem = (WN == 128 ? 3 : 2) * (WN * BKB + OPB) + (SILU ? kSiluLut * 2 : 0);  // 128 KiB (+ 18.5 KiB: the silu table); 3 x 48 KiB for 256 x 128 tiles
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)fp8_gemm256_kernel<OutT, NWV, DMA, ES, SILU>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)fp8_gemm256_kernel<OutT, NWV, DMA, ES, SILU, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
   p.tiles_m = (p.M + T2 - 1) / T2;
-  p.tiles_n = (p.N + T2 - 1) / T2;
+  p.tiles_n = (p.N + WN - 1) / WN;
   p.group_m = g_tiled_group_m;
   p.stagger_cus = tg_cus();
   p.stagger_q = (p.tiles_m * p.tiles_n >= 2 * p.stagger_cus) ? g_tiled_stagger : 0;  // needs a second round to pay off
-  hipLaunchKernelGGL((fp8_gemm256_kernel<OutT, NWV, DMA, ES, SILU>), dim3(p.tiles_m * p.tiles_n), dim3(NWV * 64), smem, st, p);
+  hipLaunchKernelGGL((fp8_gemm256_kernel<OutT, NWV, DMA, ES, SILU, WN>), dim3(p.tiles_m * p.tiles_n), dim3(NWV * 64), smem, st, p);
   SGL_HIP_LAUNCH_CHECK();
   return SGL_MI355_OK;
 }
@@ -949,28 +972,62 @@ int launch128s(GemmParams& p, hipStream_t st, float* workspace, int64_t workspac
   return SGL_MI355_OK;
 }
 
-// Does sgl_mi355_fp8_gemm send this fp8 problem to the streaming 128x128 tile?  Always at decode-sized M (<= 256: the weights are
-// read once and bytes in flight decide).  Above that the 256x256 tile wins whenever it fills the chip, but between the two lies a
-// band (256 < M <= ~1024 with few 256-wide tiles) where it leaves CUs idle and the streaming tile, with split-K when even its
-// tiles are fewer than CUs, is up to 2x faster (tools/debug/mid_m.py, round 3: M = 1024, N = 4096, K = 14336: 79 us against 167 us
-// for 256x256 and 156 us for the old 128x128 kernel; M = 512, N = 28672, K = 4096: 100 us against 62 us for 256x256).  The choice
-// is the smaller of two measured cost lines: one round of 256x256 tiles takes 46-50 us per 4096 bytes of K, one round of streaming
-// tiles 24 us; a partly filled last round costs about half its share (fewer CUs contend for L2 / HBM).
-inline bool takes128s(int M, int N, int kbytes, int64_t x_stride_b, int64_t w_stride_b, bool have_workspace = true,
-                      int64_t workspace_floats = (1ll << 40)) {
+// Which tile does sgl_mi355_fp8_gemm give this fp8 problem?  The streaming 128x128 tile always at decode-sized M (<= 256: the weights
+// are read once and bytes in flight decide).  Above that the 256x256 tile wins whenever it fills the chip, but below that lies a band
+// where it leaves CUs idle: 256 < M <= ~1024 with few 256-wide tiles, where the streaming tile (with split-K when even its tiles are
+// fewer than CUs) is up to 2x faster (tools/debug/mid_m.py, round 3: M = 1024, N = 4096, K = 14336: 79 us against 167 us), and the
+// chunked-prefill band M ~ 1024-4096 with N <= 8192, where the 256x128 tile (eight waves of 64x64 outputs, the same slice pipeline
+// over a ring of three 48 KiB buffers) fills the chip with half-size tiles (tools/debug/tile_256x128.py, round 3: M = 2048, N = 4096,
+// K = 4096: 33 us against 46 us for 256x256 and 51 us for streaming; K = 14336: 109 us against 168 / 150 us).  The choice is the
+// smallest of three measured cost lines per 4096 bytes of K: one round of 256x256 tiles takes 46-50 us, one round of 256x128 tiles
+// 29-32 us, one round of streaming tiles 24 us (a partly filled last round of those costs about half its share: fewer CUs contend for
+// L2 / HBM).  Launches of many rounds never reach the comparison: the larger tile has the higher arithmetic intensity.
+enum TileChoice { kTile256 = 0, kTile128s = 1, kTile256x128 = 2, kTileOld = 3 };
+inline TileChoice choose_tile(int M, int N, int kbytes, int64_t x_stride_b, int64_t w_stride_b, bool have_workspace = true,
+                              int64_t workspace_floats = (1ll << 40)) {
   const bool can256 = kbytes % BKB == 0 && kbytes >= BKB && (int64_t)N * w_stride_b < 0xFFFFFFF0ll && (int64_t)M * x_stride_b < 0xFFFFFFF0ll;
-  if (!can256 || g_tiled_force == 5) return can256;
-  if (g_tiled_force != 0) return false;
-  if (M <= 256) return true;
+  if (!can256) return kTile256;   // (run() sends these to the old 128x128 kernel)
+  if (g_tiled_force == 5) return kTile128s;
+  if (g_tiled_force == 7) return kTile256x128;
+  if (g_tiled_force != 0) return kTile256;
+  if (M <= 256) return kTile128s;
   const double cus = tg_cus(), k4 = kbytes / 4096.0;
-  const int64_t t256 = (int64_t)((M + T2 - 1) / T2) * ((N + T2 - 1) / T2), t128 = (int64_t)((M + S_BM - 1) / S_BM) * ((N + S_BN - 1) / S_BN);
-  if (t128 > 8 * (int64_t)cus) return false;   // many rounds either way: the larger tile has the higher arithmetic intensity
+  const int64_t tm256 = (M + T2 - 1) / T2;
+  const int64_t t256 = tm256 * ((N + T2 - 1) / T2), tnar = tm256 * ((N + 127) / 128), t128 = (int64_t)((M + S_BM - 1) / S_BM) * ((N + S_BN - 1) / S_BN);
+  if (t128 > 8 * (int64_t)cus) return kTile256;   // many rounds either way
   int kt_per = 0;
   const int splits = splits128s(M, N, kbytes, have_workspace, workspace_floats > kCounterFloats ? workspace_floats - kCounterFloats : 0, &kt_per);
   const double r = (double)t128 * splits / cus, rounds = r <= 1.0 ? 1.0 : 0.5 * (ceil(r) + r);
   const double cost128 = rounds * 24.0 * k4 / splits + (splits > 1 ? 7.0 : 0.0);
   const double cost256 = ceil((double)t256 / cus) * 49.0 * k4;
-  return cost128 < cost256;
+  const double costnar = ceil((double)tnar / cus) * 31.0 * k4;
+  if (cost128 < cost256 && cost128 <= costnar) return kTile128s;
+  return costnar < cost256 ? kTile256x128 : kTile256;
+}
+// The same for 16-bit operands (dense_gemm), per 8192 bytes of K (tools/debug/tile_256x128_dense.py, round 3): one round of 256x256
+// tiles takes 85-92 us, one round of 256x128 tiles 53-57 us, the 128x128 kernel (kTileOld: split-K when its tiles are fewer than half
+// the CUs, where it stays) about 20 + 47 r us for r = tiles / CUs >= 0.5.  Until round 3 the 256x256 kernel ran only with at least one
+// tile per CU: M = 2048, N = 6144, K = 4096 took 150 us on the 128x128 kernel against 92 us.
+inline TileChoice choose_tile16(int M, int N, int kbytes, int64_t x_stride_b, int64_t w_stride_b) {
+  const bool can256 = kbytes % BKB == 0 && kbytes >= BKB && (int64_t)N * w_stride_b < 0xFFFFFFF0ll && (int64_t)M * x_stride_b < 0xFFFFFFF0ll;
+  if (!can256 || g_tiled_force == 1) return kTileOld;
+  if (g_tiled_force == 2) return kTile256;
+  if (g_tiled_force == 7) return kTile256x128;
+  const double cus = tg_cus(), k8 = kbytes / 8192.0;
+  const int64_t tm256 = (M + T2 - 1) / T2;
+  const int64_t t256 = tm256 * ((N + T2 - 1) / T2), tnar = tm256 * ((N + 127) / 128), t128 = (int64_t)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  const double r = (double)t128 / cus;
+  if (M <= 256 || r < 0.5) return kTileOld;
+  if (t128 > 8 * (int64_t)cus) return kTile256;
+  const double cost_old = (20.0 + 47.0 * r) * k8;
+  const double cost256 = ceil((double)t256 / cus) * 88.0 * k8;
+  const double costnar = ceil((double)tnar / cus) * 55.0 * k8;
+  if (cost_old < cost256 && cost_old <= costnar) return kTileOld;
+  return costnar < cost256 ? kTile256x128 : kTile256;
+}
+inline bool takes128s(int M, int N, int kbytes, int64_t x_stride_b, int64_t w_stride_b, bool have_workspace = true,
+                      int64_t workspace_floats = (1ll << 40)) {
+  return choose_tile(M, N, kbytes, x_stride_b, w_stride_b, have_workspace, workspace_floats) == kTile128s;
 }
 
 int run(const void* x, int64_t xs, const void* w, int64_t ws, void* y, int64_t ys, const float* sx, const float* sw,
@@ -996,10 +1053,13 @@ int run(const void* x, int64_t xs, const void* w, int64_t ws, void* y, int64_t y
     // both LDS-DMA kernels want whole 128-byte K slices
     const bool can256 = p.kbytes % BKB == 0 && p.kbytes >= BKB && (int64_t)N * p.w_stride < 0xFFFFFFF0ll &&
                         (int64_t)M * p.x_stride < 0xFFFFFFF0ll;  // 32-bit buffer offsets
+    const TileChoice tile = choose_tile(M, N, p.kbytes, p.x_stride, p.w_stride, workspace != nullptr, workspace_floats);
     // decode-sized M: the streaming tile (weights read once; bytes in flight decide)
-    if (takes128s(M, N, p.kbytes, p.x_stride, p.w_stride, workspace != nullptr, workspace_floats))
+    if (tile == kTile128s)
       return out_dtype == SGL_BF16 ? launch128s<__bf16>(p, st, workspace, workspace_floats)
                                    : launch128s<_Float16>(p, st, workspace, workspace_floats);
+    if (tile == kTile256x128)
+      return out_dtype == SGL_BF16 ? launch256<__bf16, 8, true, TG_FP8, false, 128>(p, st) : launch256<_Float16, 8, true, TG_FP8, false, 128>(p, st);
     if (can256 && g_tiled_force == 4) return out_dtype == SGL_BF16 ? launch256<__bf16, 8, false>(p, st) : launch256<_Float16, 8, false>(p, st);
     if (can256 && g_tiled_force == 3) return out_dtype == SGL_BF16 ? launch256<__bf16, 4>(p, st) : launch256<_Float16, 4>(p, st);
     // (the old 128x128 kernel is left with the shapes neither LDS-DMA kernel accepts: K not whole 128-byte slices, > 4 GiB operands)
@@ -1008,11 +1068,14 @@ int run(const void* x, int64_t xs, const void* w, int64_t ws, void* y, int64_t y
     return out_dtype == SGL_BF16 ? launch<TG_FP8, __bf16>(p, st, workspace, workspace_floats)
                                  : launch<TG_FP8, _Float16>(p, st, workspace, workspace_floats);
   }
-  {  // 16-bit inputs: the 256x256 LDS-DMA kernel when there is at least one tile per CU and K is whole 128-byte slices
-    const int64_t tiles256 = (int64_t)((M + T2 - 1) / T2) * ((N + T2 - 1) / T2);
-    const bool can256 = p.kbytes % BKB == 0 && p.kbytes >= BKB && (int64_t)N * p.w_stride < 0xFFFFFFF0ll &&
-                        (int64_t)M * p.x_stride < 0xFFFFFFF0ll;
-    if (can256 && g_tiled_force != 1 && (g_tiled_force == 2 || tiles256 >= tg_cus())) {
+  {  // 16-bit inputs: the LDS-DMA kernels (256x256 / 256x128 tiles) for whole 128-byte K slices, by measured cost lines
+    const TileChoice tile = choose_tile16(M, N, p.kbytes, p.x_stride, p.w_stride);
+    if (tile == kTile256x128) {
+      if (in_dtype == SGL_BF16)
+        return out_dtype == SGL_BF16 ? launch256<__bf16, 8, true, TG_BF16, false, 128>(p, st) : launch256<_Float16, 8, true, TG_BF16, false, 128>(p, st);
+      return out_dtype == SGL_BF16 ? launch256<__bf16, 8, true, TG_F16, false, 128>(p, st) : launch256<_Float16, 8, true, TG_F16, false, 128>(p, st);
+    }
+    if (tile == kTile256) {
       if (in_dtype == SGL_BF16)
         return out_dtype == SGL_BF16 ? launch256<__bf16, 8, true, TG_BF16>(p, st) : launch256<_Float16, 8, true, TG_BF16>(p, st);
       return out_dtype == SGL_BF16 ? launch256<__bf16, 8, true, TG_F16>(p, st) : launch256<_Float16, 8, true, TG_F16>(p, st);
@@ -1082,6 +1145,13 @@ extern "C" int sgl_mi355_fp8_gemm(const void* x, int64_t x_stride_elems, const v
                                   void* stream) {
   return run(x, x_stride_elems, w, w_stride_elems, y, y_stride_elems, scales_x, scales_w, bias, M, N, K, SGL_FP8_E4M3,
              out_dtype, stream, "fp8_gemm", workspace, workspace_floats);
+}
+
+// Which kernel sgl_mi355_fp8_gemm picks for contiguous rows (host logic, no GPU work): 0 = 256x256 tile (or, for K that is not whole
+// 128-byte slices, the old 128x128 kernel), 1 = streaming 128x128 tile, 2 = 256x128 tile.
+extern "C" int sgl_mi355_fp8_gemm_tile_choice(int M, int N, int K, int64_t workspace_floats) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  return (int)choose_tile(M, N, K, K, K, true, workspace_floats);
 }
 
 // How many f32 [M, N] slabs sgl_mi355_fp8_gemm sums for this shape when given `workspace_floats` of scratch (1: it runs as one

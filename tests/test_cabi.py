@@ -108,3 +108,12 @@ def test_fp8_gemm_kernel_choice_and_k_partition_are_host_logic(pkg):
     assert got == want
     assert int(f(128, 1280, 8192, 0)) == 1          # no workspace: no split
     assert int(f(0, 128, 128, ws)) == 1 and int(f(128, 128, 100, ws)) == 1   # degenerate / K not whole 128-byte slices
+    # the tile itself: 0 = 256x256, 1 = streaming 128x128, 2 = 256x128 (chunked-prefill band: 256x256 tiles fewer than CUs, half-size tiles fill them)
+    t = _cabi.lib.sgl_mi355_fp8_gemm_tile_choice
+    want_t = {(64 + 1, 4096, 4096): 1, (256, 28672, 4096): 1, (1024, 4096, 14336): 1, (1024, 4096, 4096): 1,
+              (2048, 4096, 4096): 2, (2048, 4096, 14336): 2, (1536, 4096, 4096): 2, (1024, 6144, 4096): 2, (8192, 1024, 8192): 2,
+              (4096, 6144, 4096): 2, (520, 8192, 8192): 2,
+              (2048, 6144, 4096): 0, (2048, 28672, 4096): 0, (4096, 4096, 4096): 0, (8192, 6144, 4096): 0,
+              (65536, 28672, 4096): 0, (65536, 4096, 14336): 0, (2048, 4096, 4000): 0}
+    got_t = {k: int(t(k[0], k[1], k[2], ws)) for k in want_t}
+    assert got_t == want_t

@@ -526,6 +526,33 @@ def test_streaming_tile_in_launch_splitk_combine_bit_exact(m, n, k, sk):
                                rtol=1.6e-2, atol=0.3)
 
 
+@pytest.mark.parametrize("m,n,k,picked", [(2048, 4096, 4096, True), (1536, 4096, 1024, True), (1030, 6144, 384, True), (777, 1000, 128, False),
+                                          (300, 136, 256, False), (2048, 4104, 512, False), (257, 8192, 640, False)])
+@pytest.mark.parametrize("out", ["bf16", "f16"])
+def test_fp8_scaled_mm_256x128_tile_vs_oracle_and_256x256_bits(m, n, k, picked, out, sk):
+    """The 256x128 tile of the chunked-prefill band (csrc/tiled_gemm.hip: eight waves of 64x64 outputs over a ring of three slice
+    buffers; default where 256x256 tiles are fewer than CUs and half-size tiles fill them): the same k order per output as the 256x256
+    kernel, so the same bits, and the oracle's tolerance -- at a default-dispatch shape, ragged M / N (rows past the end arrive as
+    zeros; the last column tile partly past N), and K of 1-5 slices (the ring's prologue and the re-staged tail)."""
+    from ltp_sglang_amd import _cabi
+    c = _cases.build_gemm_case(dict(m=m, n=n, k=k, bias=True, out=out), seed=m + n + k)
+    a, wt, sa, sb, bias = (c[x].to(DEV) for x in ("a", "w", "sa", "sb", "bias"))
+    ws_n = 1 << 24
+    assert (int(_cabi.lib.sgl_mi355_fp8_gemm_tile_choice(m, n, k, ws_n)) == 2) == picked
+    outs = {}
+    for mode in (2, 7):
+        _cabi.check(_cabi.lib.sgl_mi355_fp8_gemm_force_tile(mode))
+        try:
+            outs[mode] = sk.fp8_scaled_mm(a, wt.t(), sa, sb, c["out_dtype"], bias)
+        finally:
+            _cabi.lib.sgl_mi355_fp8_gemm_force_tile(0)
+    assert torch.equal(outs[2], outs[7])
+    if picked:
+        assert torch.equal(sk.fp8_scaled_mm(a, wt.t(), sa, sb, c["out_dtype"], bias), outs[7])
+    ref = oq.scaled_mm(c["a"], c["w"].t(), c["sa"], c["sb"], c["out_dtype"], c["bias"])
+    torch.testing.assert_close(outs[7].cpu().float(), ref.float(), rtol=1.6e-2, atol=0.3)
+
+
 def test_fp8_gemm_tile_kernels_agree(sk):
     # exact small-integer operands: every product and partial sum is exact in f32, so both kernels must match bit for bit
     from ltp_sglang_amd import _cabi
@@ -535,7 +562,7 @@ def test_fp8_gemm_tile_kernels_agree(sk):
     w = torch.randint(-2, 3, (n, k), generator=g).float().to(torch.float8_e4m3fn).to(DEV)
     sa, sb = torch.ones(m, device=DEV), torch.ones(n, device=DEV)
     outs = []
-    for mode in (1, 2, 3, 4, 5):
+    for mode in (1, 2, 3, 4, 5, 7):
         _cabi.check(_cabi.lib.sgl_mi355_fp8_gemm_force_tile(mode))
         try:
             outs.append(sk.fp8_scaled_mm(a, w.t(), sa, sb, torch.float16))
@@ -556,6 +583,30 @@ def test_dense_gemm_large_m(dtype, shape, sk):
     ref = x.float() @ w.float().t()
     tol = 3e-2 if dtype == torch.bfloat16 else 4e-3
     assert (o.cpu().float() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("shape", [(2048, 4096, 512), (1030, 776, 192), (3000, 4096, 64)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_dense_gemm_256x128_tile_bits_equal_256x256(dtype, shape, sk):
+    """16-bit operands through the 256x128 tile (default in the chunked-prefill band, csrc/tiled_gemm.hip choose_tile16): the same k
+    order per output as the 256x256 kernel, so the same bits; both within the 16-bit tolerance of an f32 matmul."""
+    from ltp_sglang_amd import _cabi
+    g = torch.Generator().manual_seed(19)
+    m, n, k = shape
+    x = torch.randn(m, k, generator=g).to(dtype)
+    w = (torch.randn(n, k, generator=g) * 0.05).to(dtype)
+    outs = {}
+    for mode in (2, 7, 0):
+        _cabi.check(_cabi.lib.sgl_mi355_fp8_gemm_force_tile(mode))
+        try:
+            outs[mode] = sk.dense_linear(x.to(DEV), w.to(DEV))
+        finally:
+            _cabi.lib.sgl_mi355_fp8_gemm_force_tile(0)
+    assert torch.equal(outs[2], outs[7])
+    ref = x.float() @ w.float().t()
+    tol = 3e-2 if dtype == torch.bfloat16 else 4e-3
+    for o in outs.values():
+        assert (o.cpu().float() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
 
 
 # ---------------------------------------------------------------- fused decode kernels == their unfused op sequences
