@@ -300,10 +300,13 @@ __device__ __forceinline__ void epilogue_scaled(const GemmParams& p, const f32x4
 // its epilogue at the same moment those partial-line writes took 6-9 us per tile (measured by compiling the epilogue out),
 // as much as 4-6 K slices of MFMA work.  Needs N % 8 == 0 and 16-byte aligned output rows; otherwise epilogue_scaled.
 constexpr int kEpiRowB = 128;  // bytes per staged row: 64 outputs of 2 bytes (8 waves x 16 KiB = the kernel's 128 KiB of LDS)
-template <typename OutT, int NI, int NJ>
+// PASSES > 1: the wave's rows go through a private image of NI / PASSES row tiles, one pass after the other (same-wave LDS operations
+// are ordered) -- the persistent kernel has one 64 KiB slice buffer free for the epilogue, not both.
+template <typename OutT, int NI, int NJ, int PASSES = 1>
 __device__ __forceinline__ void epilogue_scaled_lds(const GemmParams& p, const f32x4_t (&acc)[NJ][NI], int mrow_base, int ncol_base,
                                                     char* wave_lds, int lane) {
-  static_assert(NJ == 4 && (NI == 8 || NI == 4), "one wave = 128 (or 64) rows x 64 columns");
+  static_assert(NJ == 4 && (NI == 8 || NI == 4) && NI % PASSES == 0, "one wave = 128 (or 64) rows x 64 columns");
+  constexpr int NIP = NI / PASSES;
   const int a = lane & 15, g = lane >> 4;
   float sxv[NI], swv[NJ][4], bv[NJ][4];
 #pragma unroll
@@ -331,31 +334,35 @@ __device__ __forceinline__ void epilogue_scaled_lds(const GemmParams& p, const f
 #pragma unroll
       for (int r = 0; r < 4; ++r) bv[j][r] = (float)((const OutT*)p.bias)[min(ncol_base + 4 * g + 16 * j + r, p.N - 1)];
   }
-#pragma unroll
-  for (int i = 0; i < NI; ++i)
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      typedef OutT o4_t __attribute__((ext_vector_type(4)));
-      o4_t o;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v = acc[j][i][r] * sxv[i];
-        v = v * swv[j][r] + bv[j][r];
-        o[r] = (OutT)v;
-      }
-      *(o4_t*)(wave_lds + (16 * i + a) * kEpiRowB + (((2 * j + (g >> 1)) ^ (a & 7)) << 4) + ((g & 1) << 3)) = o;
-    }
-  // (same-wave LDS operations are ordered: no barrier between the image's writes and reads)
   const int rsub = lane >> 3, c16 = lane & 7;  // 8 lanes cover one 128-byte row
   const bool col_ok = ncol_base + 8 * c16 + 7 < p.N;
 #pragma unroll
-  for (int it = 0; it < 2 * NI; ++it) {
-    const int row = 8 * it + rsub;
-    const u32x4_t v = *(const u32x4_t*)(wave_lds + row * kEpiRowB + ((c16 ^ (row & 7)) << 4));
-    const int m = mrow_base + row;
-    // NON-TEMPORAL stores: the output (hundreds of MB per prefill GEMM) is not read again by this launch and would otherwise
-    // displace the X / W panels that the other tiles of the XCD re-read from L2.  Same-box A/B (round 2): prefill 1 946 -> 2 000 TFLOP/s.
-    if (m < p.M && col_ok) __builtin_nontemporal_store(v, (u32x4_t*)((OutT*)p.y + (int64_t)m * p.y_stride + ncol_base + 8 * c16));
+  for (int ps = 0; ps < PASSES; ++ps) {
+#pragma unroll
+    for (int ii = 0; ii < NIP; ++ii)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int i = ps * NIP + ii;
+        typedef OutT o4_t __attribute__((ext_vector_type(4)));
+        o4_t o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[j][i][r] * sxv[i];
+          v = v * swv[j][r] + bv[j][r];
+          o[r] = (OutT)v;
+        }
+        *(o4_t*)(wave_lds + (16 * ii + a) * kEpiRowB + (((2 * j + (g >> 1)) ^ (a & 7)) << 4) + ((g & 1) << 3)) = o;
+      }
+    // (same-wave LDS operations are ordered: no barrier between the image's writes and reads)
+#pragma unroll
+    for (int it = 0; it < 2 * NIP; ++it) {
+      const int row = 8 * it + rsub;
+      const u32x4_t v = *(const u32x4_t*)(wave_lds + row * kEpiRowB + ((c16 ^ (row & 7)) << 4));
+      const int m = mrow_base + 16 * NIP * ps + row;
+      // NON-TEMPORAL stores: the output (hundreds of MB per prefill GEMM) is not read again by this launch and would otherwise
+      // displace the X / W panels that the other tiles of the XCD re-read from L2.  Same-box A/B (round 2): prefill 1 946 -> 2 000 TFLOP/s.
+      if (m < p.M && col_ok) __builtin_nontemporal_store(v, (u32x4_t*)((OutT*)p.y + (int64_t)m * p.y_stride + ncol_base + 8 * c16));
+    }
   }
 }
 
@@ -371,41 +378,53 @@ __device__ __forceinline__ void epilogue_scaled_lds(const GemmParams& p, const f
 constexpr int kSiluLdsOff = 2 * 2 * 256 * 128;   // the table sits above the two 64 KiB operand buffers for the whole launch
 template <typename OutT>
 __device__ __forceinline__ void epilogue_silu_lds(const GemmParams& p, const f32x4_t (&acc)[4][8], int m0, int wm, int n0, int wn, char* smem,
-                                                  int tid, int lane) {
+                                                  int tid, int lane, char* stg = nullptr) {
+  if (stg == nullptr) stg = smem;   // the 64 KiB the act tile is staged in (the persistent kernel passes the slice buffer that is free)
   static_assert(sizeof(OutT) == 2 && !__is_same(OutT, _Float16), "the table is over bf16 bits");
   const int a = lane & 15, g = lane >> 4;
   const uint16_t* lut = (const uint16_t*)(smem + kSiluLdsOff);   // copied there at kernel entry, under the first slice's flight
-  float sxv[8], swv[4][4];
+  float sxv[8], swv[4][4];   // (one wave-uniform branch per optional pointer, as in epilogue_scaled: tested per value, every load is a basic block)
 #pragma unroll
-  for (int i = 0; i < 8; ++i) sxv[i] = p.sx ? p.sx[min(m0 + wm + a + 16 * i, p.M - 1)] : 1.0f;
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) swv[j][r] = p.sw ? p.sw[n0 + wn + 16 * j + 4 * g + r] : 1.0f;
-  // y = OutT(acc * sx * sw + 0): the arithmetic of epilogue_scaled, packed as bf16 pairs (r = 0, 1 | r = 2, 3)
-  uint32_t yp[4][8][2];
+  for (int i = 0; i < 8; ++i) sxv[i] = 1.0f;
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int r = 0; r < 4; ++r) swv[j][r] = 1.0f;
+  if (p.sx) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sxv[i] = p.sx[min(m0 + wm + a + 16 * i, p.M - 1)];
+  }
+  if (p.sw) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x4_t v = *(const f32x4_t*)(p.sw + n0 + wn + 16 * j + 4 * g);   // (N % 256 == 0: whole, 16-byte aligned groups of four)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) swv[j][r] = v[r];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int row = wm + 16 * i + a;
+    // y = OutT(acc * sx * sw + 0): the arithmetic of epilogue_scaled, packed as bf16 pairs (r = 0, 1 | r = 2, 3); one row tile at a
+    // time, so that the accumulators die as they are consumed (all 64 pairs up front cost the persistent kernel 250 spills)
+    uint32_t ypi[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         float v0 = acc[j][i][2 * h] * sxv[i], v1 = acc[j][i][2 * h + 1] * sxv[i];
         v0 = v0 * swv[j][2 * h] + 0.0f;
         v1 = v1 * swv[j][2 * h + 1] + 0.0f;
         struct P2 { OutT lo, hi; };
-        yp[j][i][h] = __builtin_bit_cast(uint32_t, P2{(OutT)v0, (OutT)v1});
+        ypi[j][h] = __builtin_bit_cast(uint32_t, P2{(OutT)v0, (OutT)v1});
       }
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int row = wm + 16 * i + a;
 #pragma unroll
     for (int jp = 0; jp < 2; ++jp) {
       uint32_t gt[2], up[2];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         // x = even block, y = odd block: afterwards lanes 0-31 hold (gate, up) of the even block, lanes 32-63 of the odd block
-        const auto sw2 = __builtin_amdgcn_permlane32_swap(yp[2 * jp][i][h], yp[2 * jp + 1][i][h], false, false);
+        const auto sw2 = __builtin_amdgcn_permlane32_swap(ypi[2 * jp][h], ypi[2 * jp + 1][h], false, false);
         gt[h] = sw2[0];
         up[h] = sw2[1];
       }
@@ -437,7 +456,7 @@ __device__ __forceinline__ void epilogue_silu_lds(const GemmParams& p, const f32
       }
       // act column (within the tile's 128) = wn / 2 + 16 jp + 4 g + r  ->  byte wn + 32 jp + 8 g of the 256-byte row
       const int c = (wn >> 4) + 2 * jp + (g >> 1);
-      *(u32x2_t*)(smem + row * 256 + ((c ^ (row & 15)) << 4) + ((g & 1) << 3)) = u32x2_t{o[0], o[1]};
+      *(u32x2_t*)(stg + row * 256 + ((c ^ (row & 15)) << 4) + ((g & 1) << 3)) = u32x2_t{o[0], o[1]};
     }
   }
   __syncthreads();
@@ -446,7 +465,7 @@ __device__ __forceinline__ void epilogue_silu_lds(const GemmParams& p, const f32
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
     const int row = 32 * it + r0;
-    const u32x4_t v = *(const u32x4_t*)(smem + row * 256 + (pos << 4));
+    const u32x4_t v = *(const u32x4_t*)(stg + row * 256 + (pos << 4));
     const int m = m0 + row;
     if (m < p.M) __builtin_nontemporal_store(v, (u32x4_t*)(ybase + (int64_t)m * p.y_stride + 8 * (pos ^ (row & 15))));
   }
@@ -672,6 +691,214 @@ __global__ __launch_bounds__(NWV * 64, 1) void fp8_gemm256_kernel(const GemmPara
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// PERSISTENT form of the 256x256 kernel for launches of many tiles per CU (prefill): one workgroup per CU walks its XCD's tile list
+// (tile j, j + W, j + 2 W, ... for the W workgroups of an XCD: the order the dispatcher produces for equal tile times, so the
+// grouped L2 reuse is the same), and the NEXT tile's first K slice is staged while the current tile's last slice is multiplied:
+// slice nk - 2's drained buffer takes it, the last slice stages nothing, the epilogue goes through the buffer the last slice
+// leaves (64 KiB: the SiLU act tile as is, the plain output in two passes of 64 rows per wave).  What it removes per tile: the
+// workgroup hand-over on the CU, the first slice's full fetch latency with nothing to overlap, the table copy of the SiLU form.
+// Same k order and epilogue arithmetic per output: the same bits as the one-tile-per-workgroup kernel.
+// ---------------------------------------------------------------------------------------------------------
+template <typename OutT, int ES = TG_FP8, bool SILU = false>
+__global__ __launch_bounds__(512, 1) void fp8_gemm256p_kernel(const GemmParams p) {
+  constexpr int NWV = 8, WCOLS = 4, JN = 4, RPW = 32, BUFB = 2 * OPB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][W 32 KiB | X 32 KiB] (+ the silu table)
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int bid = blockIdx.x;
+  const int q = nwg / 8, r8 = nwg % 8, xcd = bid % 8;
+  const int base = xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q;   // this XCD's tiles: base .. base + cnt - 1
+  const int cnt = q + (xcd < r8 ? 1 : 0);
+  const int per = (int)gridDim.x / 8;   // workgroups per XCD (the launcher makes the grid a multiple of 8)
+  int ti = bid / 8;
+  if (ti >= cnt) return;
+  const int GM = p.group_m;
+  const int per_group = GM * p.tiles_n;
+  auto origin = [&](int t, int& m0, int& n0) {   // grouped order, as in fp8_gemm256_kernel
+    const int wgid = base + t;
+    const int grp = wgid / per_group, in_grp = wgid - grp * per_group;
+    const int gsz = min(p.tiles_m - grp * GM, GM);
+    m0 = (grp * GM + in_grp % gsz) * T2;
+    n0 = (in_grp / gsz) * T2;
+  };
+  int m0, n0;
+  origin(ti, m0, n0);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = (w / WCOLS) * 128, wn = (w % WCOLS) * (16 * JN);
+  if (p.stagger_q > 0 && (int)blockIdx.x < p.stagger_cus) {   // phase stagger of the CUs' first tiles (see fp8_gemm256_kernel)
+    const int mask = (p.stagger_q & 64) ? 31 : 15;
+    const int steps = ((blockIdx.x >> 3) & mask) * (p.stagger_q & 63);
+    for (int t = 0; t < steps; ++t) __builtin_amdgcn_s_sleep(8);
+  }
+  const int a = lane & 15, g = lane >> 4;
+
+  const auto wrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (unsigned)((int64_t)p.N * p.w_stride), 0x00020000);
+  const auto xrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (unsigned)((int64_t)p.M * p.x_stride), 0x00020000);
+  // per-lane offsets within a tile (the same for every tile: two VGPRs per operand); the tile's origin travels in the scalar offset
+  unsigned wvo[2], xvo[2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par) {
+    const int rl = RPW * w + (lane >> 3);
+    const int chunk = (lane & 7) ^ (((lane >> 4) + 4 * par) & 7);
+    wvo[par] = (unsigned)((int64_t)rl * p.w_stride) + chunk * 16;
+    xvo[par] = (unsigned)((int64_t)rl * p.x_stride) + chunk * 16;
+  }
+  const int nk = p.kbytes / BKB;   // >= 3 (launcher)
+  auto stage_at = [&](int wo, int xo, int kt, int buf) {   // wo / xo: byte offsets of the tile's first W / X row (launcher: operands < 2 GiB)
+    const int off = kt * BKB;
+    auto* wb = (__attribute__((address_space(3))) char*)(smem + buf * BUFB + (RPW * w) * BKB);
+#pragma unroll
+    for (int t = 0; t < RPW / 8; ++t) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, wb + t * 8 * BKB, 16, wvo[t & 1], wo + (int)(t * 8 * p.w_stride) + off, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, wb + OPB + t * 8 * BKB, 16, xvo[t & 1], xo + (int)(t * 8 * p.x_stride) + off, 0, 0);
+    }
+  };
+  int wo0 = (int)((int64_t)n0 * p.w_stride), xo0 = (int)((int64_t)m0 * p.x_stride), wo1 = wo0, xo1 = xo0;   // this tile / the next one
+
+  f32x4_t acc[JN][8];
+  u32x4_t wf[JN][2], xf[3][2][2];
+  auto load_w = [&](int buf) {
+    const char* wa = smem + buf * BUFB;
+#pragma unroll
+    for (int j = 0; j < JN; ++j)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) wf[j][h] = *(const u32x4_t*)(wa + lds_off(wn + 16 * j + a, 4 * h + g));
+  };
+  auto load_x = [&](int buf, int grp, int slot) {
+    const char* xa = smem + buf * BUFB + OPB;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) xf[slot][i][h] = *(const u32x4_t*)(xa + lds_off(wm + 32 * grp + 16 * i + a, 4 * h + g));
+  };
+  auto mma = [&](int grp, int slot) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < JN; ++j) {
+        if constexpr (ES == TG_FP8) {
+          mfma_mx(wf[j][0], wf[j][1], xf[slot][i][0], xf[slot][i][1], acc[j][2 * grp + i]);
+        } else {
+          mfma_chunk<ES>(wf[j][0], xf[slot][i][0], acc[j][2 * grp + i]);
+          mfma_chunk<ES>(wf[j][1], xf[slot][i][1], acc[j][2 * grp + i]);
+        }
+      }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  // one K slice (see fp8_gemm256_kernel); TAIL 0: inside the tile, 1: slice nk - 2 (its drained buffer takes the next tile's slice
+  // 0), 2: the last slice (stages nothing and fetches no fragments: its buffer is the epilogue's)
+  auto slice = [&](int kt, int buf, auto r_, auto tail_, auto pin_) {
+    constexpr int R = decltype(r_)::value, TAIL = decltype(tail_)::value;
+    constexpr bool PIN = decltype(pin_)::value != 0;
+    constexpr int S0 = R, S1 = (R + 1) % 3, S2 = (R + 2) % 3;
+    // (outside the k loop the slices are straight-line code up to the epilogue, one scheduling region: left alone, the scheduler
+    // hoists every fragment read of the last three slices to the top and parks the fragments in scratch -- pin the order there)
+#define SGL_PIN() do { if constexpr (PIN) __builtin_amdgcn_sched_barrier(0); } while (0)
+    load_x(buf, 1, S1);
+    SGL_PIN();
+    mma(0, S0);
+    SGL_PIN();
+    load_x(buf, 2, S2);
+    SGL_PIN();
+    mma(1, S1);
+    SGL_PIN();
+    load_x(buf, 3, S0);
+    __syncthreads();
+    if constexpr (TAIL != 2) load_x(buf ^ 1, 0, S1);
+    if constexpr (TAIL == 0) stage_at(wo0, xo0, kt + 2, buf);
+    if constexpr (TAIL == 1) stage_at(wo1, xo1, 0, buf);
+    SGL_PIN();
+    mma(2, S2);
+    mma(3, S0);
+    SGL_PIN();
+    if constexpr (TAIL != 2) load_w(buf ^ 1);
+    SGL_PIN();
+#undef SGL_PIN
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+
+  int b0 = 0;   // the buffer that holds slice 0 of the current tile
+  stage_at(wo0, xo0, 0, 0);
+  if constexpr (SILU) {   // the silu table -> LDS once per workgroup, behind the first slice's DMA
+    for (int i = tid; i < kSiluLut / 8; i += NWV * 64) *(u32x4_t*)(smem + kSiluLdsOff + 16 * i) = *(const u32x4_t*)(p.silu_lut + 8 * i);
+  }
+  __syncthreads();
+  for (;;) {
+    stage_at(wo0, xo0, 1, b0 ^ 1);
+    const bool has_next = ti + per < cnt;
+    int m1 = m0, n1 = n0;
+    if (has_next) origin(ti + per, m1, n1);
+    wo1 = (int)((int64_t)n1 * p.w_stride);   // (no next tile: this tile's own slice 0 once more, into a drained buffer nobody reads)
+    xo1 = (int)((int64_t)m1 * p.x_stride);
+#pragma unroll
+    for (int j = 0; j < JN; ++j)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // nk = 3 G + r slices: the r odd ones come FIRST, at rotation phases 3 - r .. 2, so that the groups of three -- and with them the
+    // tile's last two slices, which differ (TAIL) -- sit at static phases 0, 1, 2.  (With the odd slices at the end the tail needed
+    // one copy per value of r; the three-way join cost the register allocator a thousand spills.)
+    const int r = nk % 3, G = nk / 3;   // G >= 1 (launcher)
+    load_w(b0);
+    load_x(b0, 0, 0);   // the first slice's phase is 0, 2 or 1 (r = 0, 1, 2): its X fragments go to all three slots -- eight extra LDS reads
+    load_x(b0, 0, 2);   // per tile, and every slot is defined on every path (a slot loaded on one branch only would be carried around
+    load_x(b0, 0, 1);   // the tile loop, through the epilogue, as a live value)
+    int kt = 0;
+    if (r == 2) {
+      slice(kt, (kt + b0) & 1, I1{}, I0{}, I0{});
+      ++kt;
+    }
+    if (r >= 1) {
+      slice(kt, (kt + b0) & 1, I2{}, I0{}, I0{});
+      ++kt;
+    }
+    for (int gi = 0; gi + 1 < G; ++gi, kt += 3) {
+      slice(kt, (kt + b0) & 1, I0{}, I0{}, I0{});
+      slice(kt + 1, (kt + 1 + b0) & 1, I1{}, I0{}, I0{});
+      slice(kt + 2, (kt + b0) & 1, I2{}, I0{}, I0{});
+    }
+    slice(kt, (kt + b0) & 1, I0{}, I0{}, I1{});
+    slice(kt + 1, (kt + 1 + b0) & 1, I1{}, I1{}, I1{});
+    slice(kt + 2, (kt + b0) & 1, I2{}, I2{}, I1{});
+    // ---- epilogue through the last slice's buffer; the other one holds (or is receiving) the next tile's slice 0 ----
+    char* ebuf = smem + ((nk - 1 + b0) & 1) * BUFB;
+    // The accumulators are "used" here: otherwise the IR-level sinking pass moves the last slices' MFMAs down to their first use
+    // inside the epilogue's branches (the SiLU form's table / exact-expression split), below the barrier, and the fragments they
+    // read -- loaded above it -- travel there through scratch (225 spilled dwords, the MFMA blocks of the tail slices empty).
+#pragma unroll
+    for (int j = 0; j < JN; ++j)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(acc[j][i]));
+    __syncthreads();  // every wave is past its last fragment read
+    // the epilogue's per-lane addressing is the same for every tile; derived from an opaque copy of the lane id so that it is NOT
+    // hoisted out of the tile loop (hoisted, it stayed live across the main loop and was spilled: scratch reloads between the
+    // LDS-DMA issues, each dragging a vmcnt(0) behind it)
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    if constexpr (SILU) {
+      epilogue_silu_lds<OutT>(p, acc, m0, wm, n0, wn, smem, lane_e + 64 * w, lane_e, ebuf);
+    } else {
+      if (p.N % 8 == 0 && p.y_stride % 8 == 0 && ((uintptr_t)p.y & 15) == 0)
+        epilogue_scaled_lds<OutT, 8, JN, 2>(p, acc, m0 + wm, n0 + wn, ebuf + w * (64 * kEpiRowB), lane_e);
+      else
+        epilogue_scaled<OutT, 8, JN>(p, acc, m0 + wm + (lane_e & 15), n0 + wn + 4 * (lane_e >> 4));
+    }
+    if (!has_next) break;
+    ti += per;
+    m0 = m1;
+    n0 = n1;
+    wo0 = wo1;
+    xo0 = xo1;
+    b0 = (nk + b0) & 1;   // = the buffer of slice nk - 2
+    __syncthreads();      // the epilogue's LDS reads are done: its buffer may take slice 1
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may be in flight when the workgroup ends
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // fp8 "streaming" tile for decode-sized M (64 < M <= 256, the continuous-batching regime): the weights are read once and
 // that read is the whole cost, so what matters is bytes in flight per CU, not MFMA rate.  128x128 tile, 128-byte K slices,
 // LDS-DMA into a FOUR-deep ring of 32 KiB stages (three slices in flight while one is computed: a counted s_waitcnt, never
@@ -848,6 +1075,33 @@ int launch256(GemmParams& p, hipStream_t st) {
   p.stagger_cus = tg_cus();
   p.stagger_q = (p.tiles_m * p.tiles_n >= 2 * p.stagger_cus) ? g_tiled_stagger : 0;  // needs a second round to pay off
   hipLaunchKernelGGL((fp8_gemm256_kernel<OutT, NWV, DMA, ES, SILU, WN>), dim3(p.tiles_m * p.tiles_n), dim3(NWV * 64), smem, st, p);
+  SGL_HIP_LAUNCH_CHECK();
+  return SGL_MI355_OK;
+}
+
+int g_tiled_persistent = 1;  // measurement hook (force_tile 3000 / 3001): 0 = one tile per workgroup always
+template <typename OutT, int ES = TG_FP8, bool SILU = false>
+int launch256p(GemmParams& p, hipStream_t st) {
+  const int cus = tg_cus() / 8 * 8;
+  const int64_t tiles = (int64_t)((p.M + T2 - 1) / T2) * ((p.N + T2 - 1) / T2);
+  // (measured, tools/debug/persistent_256.py / persistent_silu.py, M = 65 536: K = 4096 x N = 6144 / 4096 / 28672 -5 % / -5 % / -2.5 %, K = 384-640
+  // -10...-16 %; K = 14336 a tie (the hand-over is 4 % of a tile there and the static tile schedule gives up the dispatcher's load
+  // balancing); the SiLU form a tie as well -- both stay on one tile per workgroup)
+  if (!g_tiled_persistent || SILU || p.kbytes > 8192 || cus < 8 || tiles < 2 * (int64_t)cus || p.kbytes < 3 * BKB || (int64_t)p.N * p.w_stride >= (1ll << 31) ||
+      (int64_t)p.M * p.x_stride >= (1ll << 31))   // (the tile origin travels in a signed 32-bit scalar offset)
+    return launch256<OutT, 8, true, ES, SILU>(p, st);
+  constexpr int smem = 2 * 2 * OPB + (SILU ? kSiluLut * 2 : 0);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)fp8_gemm256p_kernel<OutT, ES, SILU>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  p.tiles_m = (p.M + T2 - 1) / T2;
+  p.tiles_n = (p.N + T2 - 1) / T2;
+  p.group_m = g_tiled_group_m;
+  p.stagger_cus = cus;
+  p.stagger_q = g_tiled_stagger;
+  hipLaunchKernelGGL((fp8_gemm256p_kernel<OutT, ES, SILU>), dim3(cus), dim3(512), smem, st, p);
   SGL_HIP_LAUNCH_CHECK();
   return SGL_MI355_OK;
 }
@@ -1064,7 +1318,7 @@ int run(const void* x, int64_t xs, const void* w, int64_t ws, void* y, int64_t y
     if (can256 && g_tiled_force == 3) return out_dtype == SGL_BF16 ? launch256<__bf16, 4>(p, st) : launch256<_Float16, 4>(p, st);
     // (the old 128x128 kernel is left with the shapes neither LDS-DMA kernel accepts: K not whole 128-byte slices, > 4 GiB operands)
     if (can256 && g_tiled_force != 1)
-      return out_dtype == SGL_BF16 ? launch256<__bf16, 8>(p, st) : launch256<_Float16, 8>(p, st);
+      return out_dtype == SGL_BF16 ? launch256p<__bf16>(p, st) : launch256p<_Float16>(p, st);
     return out_dtype == SGL_BF16 ? launch<TG_FP8, __bf16>(p, st, workspace, workspace_floats)
                                  : launch<TG_FP8, _Float16>(p, st, workspace, workspace_floats);
   }
@@ -1077,8 +1331,8 @@ int run(const void* x, int64_t xs, const void* w, int64_t ws, void* y, int64_t y
     }
     if (tile == kTile256) {
       if (in_dtype == SGL_BF16)
-        return out_dtype == SGL_BF16 ? launch256<__bf16, 8, true, TG_BF16>(p, st) : launch256<_Float16, 8, true, TG_BF16>(p, st);
-      return out_dtype == SGL_BF16 ? launch256<__bf16, 8, true, TG_F16>(p, st) : launch256<_Float16, 8, true, TG_F16>(p, st);
+        return out_dtype == SGL_BF16 ? launch256p<__bf16, TG_BF16>(p, st) : launch256p<_Float16, TG_BF16>(p, st);
+      return out_dtype == SGL_BF16 ? launch256p<__bf16, TG_F16>(p, st) : launch256p<_Float16, TG_F16>(p, st);
     }
   }
   if (in_dtype == SGL_BF16)
@@ -1119,10 +1373,14 @@ int sgl_mi355_internal_tiled_gemm_silu_mul(const void* x, int64_t x_stride_b, co
   p.silu_lut = (const uint16_t*)lut;
   hipLaunchKernelGGL(silu_lut_fill_kernel, dim3(4), dim3(256), 0, st);
   SGL_HIP_LAUNCH_CHECK();
-  return launch256<__bf16, 8, true, TG_FP8, true>(p, st);
+  return launch256p<__bf16, TG_FP8, true>(p, st);
 }
 
 extern "C" int sgl_mi355_fp8_gemm_force_tile(int mode) {
+  if (mode >= 3000) {  // measurement hook: 3001 = persistent 256x256 kernel where a launch has at least two tiles per CU (default), 3000 = never
+    g_tiled_persistent = mode - 3000;
+    return SGL_MI355_OK;
+  }
   if (mode >= 2000) {  // measurement hook: 2000 = split-K combined by a separate reduce launch (default), 2001 = inside the GEMM launch
     g_tiled_inlaunch = mode - 2000;
     return SGL_MI355_OK;

@@ -553,6 +553,41 @@ def test_fp8_scaled_mm_256x128_tile_vs_oracle_and_256x256_bits(m, n, k, picked, 
     torch.testing.assert_close(outs[7].cpu().float(), ref.float(), rtol=1.6e-2, atol=0.3)
 
 
+@pytest.mark.parametrize("m,n,k", [(8192, 4096, 384), (8190, 4104, 512), (8192, 4096, 640), (4100, 8192, 1024)])
+def test_fp8_scaled_mm_persistent_256_kernel_bits_equal_one_tile_per_workgroup(m, n, k, sk):
+    """Launches of at least two 256x256 tiles per CU run the persistent form (csrc/tiled_gemm.hip fp8_gemm256p_kernel: one workgroup
+    per CU walks its XCD's tile list, the next tile's first K slice staged under the current tile's last one, epilogue through the
+    free slice buffer): same k order and epilogue arithmetic, so the same bits as one tile per workgroup -- with K of 3 / 4 / 5 / 8
+    slices (the three rotation phases of the first slice), ragged M and N, both output types; and the oracle's tolerance."""
+    from ltp_sglang_amd import _cabi
+    for out in ("bf16", "f16"):
+        c = _cases.build_gemm_case(dict(m=m, n=n, k=k, bias=True, out=out), seed=m + n + k)
+        a, wt, sa, sb, bias = (c[x].to(DEV) for x in ("a", "w", "sa", "sb", "bias"))
+        outs = {}
+        for mode in (3000, 3001):
+            _cabi.check(_cabi.lib.sgl_mi355_fp8_gemm_force_tile(mode))
+            try:
+                outs[mode] = sk.fp8_scaled_mm(a, wt.t(), sa, sb, c["out_dtype"], bias)
+            finally:
+                _cabi.lib.sgl_mi355_fp8_gemm_force_tile(3001)
+        assert torch.equal(outs[3000], outs[3001])
+        if out == "bf16":
+            ref = oq.scaled_mm(c["a"], c["w"].t(), c["sa"], c["sb"], c["out_dtype"], c["bias"])
+            torch.testing.assert_close(outs[3001].cpu().float(), ref.float(), rtol=1.6e-2, atol=0.3)
+    # 16-bit operands through the same kernel
+    g = torch.Generator().manual_seed(23)
+    x = torch.randn(m, k // 2, generator=g).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(n, k // 2, generator=g) * 0.05).to(torch.bfloat16).to(DEV)
+    outs = {}
+    for mode in (3000, 3001):
+        _cabi.check(_cabi.lib.sgl_mi355_fp8_gemm_force_tile(mode))
+        try:
+            outs[mode] = sk.dense_linear(x, w)
+        finally:
+            _cabi.lib.sgl_mi355_fp8_gemm_force_tile(3001)
+    assert torch.equal(outs[3000], outs[3001])
+
+
 def test_fp8_gemm_tile_kernels_agree(sk):
     # exact small-integer operands: every product and partial sum is exact in f32, so both kernels must match bit for bit
     from ltp_sglang_amd import _cabi
