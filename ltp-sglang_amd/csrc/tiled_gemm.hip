@@ -1342,8 +1342,8 @@ int run(const void* x, int64_t xs, const void* w, int64_t ws, void* y, int64_t y
                                : launch<TG_F16, _Float16>(p, st, workspace, workspace_floats);
 }
 
-// the table of silu_lut.h in global memory, filled on the launch stream before every use (one 256-thread workgroup, ~2 us: no
-// state to keep per device or per graph)
+// the table of silu_lut.h in global memory (one copy per device: __device__ variables are per-device), filled by four 256-thread
+// workgroups (~5 us with the launch) once per device -- see sgl_mi355_internal_tiled_gemm_silu_mul
 __device__ uint16_t g_silu_lut[kSiluLut];
 __global__ __launch_bounds__(256) void silu_lut_fill_kernel() {
   for (int i = threadIdx.x + 256 * blockIdx.x; i < kSiluLut; i += 256 * gridDim.x) g_silu_lut[i] = silu_lut_entry(i);
@@ -1371,8 +1371,25 @@ int sgl_mi355_internal_tiled_gemm_silu_mul(const void* x, int64_t x_stride_b, co
     return SGL_MI355_EINVAL;
   }
   p.silu_lut = (const uint16_t*)lut;
-  hipLaunchKernelGGL(silu_lut_fill_kernel, dim3(4), dim3(256), 0, st);
-  SGL_HIP_LAUNCH_CHECK();
+  // The table is a constant of the device: filled once per device and process, then waited for, so that a later call on another
+  // stream finds it complete (5 us per call before: 1 % of a 2 048-token prefill chunk's layer).  Under stream capture the fill
+  // is part of every captured call instead -- nothing executes at capture time, and the graph must not depend on what ran before it.
+  static bool filled[64] = {};
+  int dev = 0;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  const bool capturing = hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
+  const bool known = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64;
+  if (capturing || !known || !filled[dev]) {
+    hipLaunchKernelGGL(silu_lut_fill_kernel, dim3(4), dim3(256), 0, st);
+    SGL_HIP_LAUNCH_CHECK();
+    if (!capturing && known) {
+      if (hipStreamSynchronize(st) != hipSuccess) {
+        snprintf(g_sgl_mi355_err, sizeof(g_sgl_mi355_err), "gemm_silu_mul: filling the silu table failed");
+        return SGL_MI355_EHIP;
+      }
+      filled[dev] = true;
+    }
+  }
   return launch256p<__bf16, TG_FP8, true>(p, st);
 }
 

@@ -810,8 +810,20 @@ def test_fp8_gemm_silu_mul_prefill_form_bit_exact(m, n, k, sk):
     finally:
         _cabi.lib.sgl_mi355_fp8_gemm_force_tile(0)
     wi = sk.interleave_gate_up_rows(wt.view(torch.uint8), 16).view(torch.float8_e4m3fn)
-    got = sk.fp8_gemm_silu_mul(a, sa, wi, sk.interleave_gate_up_rows(sb, 16), torch.bfloat16, 16)
+    sbi = sk.interleave_gate_up_rows(sb, 16)
+    got = sk.fp8_gemm_silu_mul(a, sa, wi, sbi, torch.bfloat16, 16)
     assert torch.equal(got, ref)
+    # captured: the table fill rides in the graph (outside capture it runs once per device), replays on a side stream agree
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr, stream=st):
+        got_g = sk.fp8_gemm_silu_mul(a, sa, wi, sbi, torch.bfloat16, 16)
+    for _ in range(2):
+        got_g.zero_()
+        gr.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(got_g, ref)
     with pytest.raises(RuntimeError, match="N %"):
         sk.fp8_gemm_silu_mul(a, sa, wi[: n - 32], sk.interleave_gate_up_rows(sb, 16)[: n - 32], torch.bfloat16, 16)
 
