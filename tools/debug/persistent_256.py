@@ -10,7 +10,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gemm_sweep import timed
 DEV = "cuda:0"
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
-for n, k in [(6144, 4096), (4096, 4096), (4096, 14336), (28672, 4096), (1536, 4096), (4096, 384), (4096, 512), (4096, 640)]:
+SHAPES = [(6144, 4096), (4096, 4096), (4096, 14336), (28672, 4096), (1536, 4096), (4096, 384), (4096, 512), (4096, 640)]
+if len(sys.argv) > 2:   # "N:K,N:K,..."
+    SHAPES = [tuple(int(v) for v in t.split(":")) for t in sys.argv[2].split(",")]
+for n, k in SHAPES:
     ws = [torch.randn(n, k, device=DEV).clamp(-3, 3).to(torch.float8_e4m3fn) for _ in range(2)]
     sb = torch.rand(n, device=DEV)
     x = torch.randn(M, k, device=DEV).to(torch.float8_e4m3fn)
