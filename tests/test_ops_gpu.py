@@ -588,6 +588,31 @@ def test_fp8_scaled_mm_persistent_256_kernel_bits_equal_one_tile_per_workgroup(m
     assert torch.equal(outs[3000], outs[3001])
 
 
+def test_fp8_scaled_mm_random_shapes_default_dispatch_vs_oracle(sk):
+    """Whatever kernel the host cost lines pick (skinny, streaming 128x128 with or without split-K, 256x128, 256x256 one-tile or
+    persistent, the old 128x128 kernel for K that is not whole 128-byte slices): 28 seeded shapes with ragged M / N / K against the
+    oracle, and the tile choice reported for each is one the shape rules allow."""
+    from ltp_sglang_amd import _cabi
+    rng = torch.Generator().manual_seed(2026)
+    seen = set()
+    for it in range(28):
+        m = int(torch.randint(65, 3000, (1,), generator=rng))
+        n = 8 * int(torch.randint(1, 514, (1,), generator=rng))
+        k = 16 * int(torch.randint(1, 65, (1,), generator=rng)) if it % 4 == 3 else 128 * int(torch.randint(1, 9, (1,), generator=rng))
+        if it == 0:
+            m, n, k = 16384, 8192, 384     # two 256x256 tiles per CU: the persistent form
+        tile = int(_cabi.lib.sgl_mi355_fp8_gemm_tile_choice(m, n, k, 1 << 24))
+        assert tile in (0, 1, 2) and (k % 128 == 0 or tile == 0)
+        seen.add(tile)
+        c = _cases.build_gemm_case(dict(m=m, n=n, k=k, bias=bool(it & 1), out="bf16" if it & 2 else "f16"), seed=1000 + it)
+        a, wt, sa, sb = (c[x].to(DEV) for x in ("a", "w", "sa", "sb"))
+        bias = c["bias"].to(DEV) if c["bias"] is not None else None
+        o = sk.fp8_scaled_mm(a, wt.t(), sa, sb, c["out_dtype"], bias)
+        ref = oq.scaled_mm(c["a"], c["w"].t(), c["sa"], c["sb"], c["out_dtype"], c["bias"])
+        torch.testing.assert_close(o.cpu().float(), ref.float(), rtol=1.6e-2, atol=0.3, msg=lambda s_: f"M={m} N={n} K={k} tile={tile}: {s_}")
+    assert seen == {0, 1, 2}
+
+
 def test_fp8_gemm_tile_kernels_agree(sk):
     # exact small-integer operands: every product and partial sum is exact in f32, so both kernels must match bit for bit
     from ltp_sglang_amd import _cabi
