@@ -669,6 +669,26 @@ def test_dense_gemm_256x128_tile_bits_equal_256x256(dtype, shape, sk):
         assert (o.cpu().float() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
 
 
+def test_dense_gemm_random_shapes_default_dispatch(sk):
+    """16-bit operands through whatever choose_tile16 picks (old 128x128 kernel with or without split-K, 256x128, 256x256 one-tile or
+    persistent): 16 seeded ragged shapes against an f32 matmul."""
+    rng = torch.Generator().manual_seed(77)
+    for it in range(16):
+        m = int(torch.randint(65, 4200, (1,), generator=rng))
+        n = 8 * int(torch.randint(1, 600, (1,), generator=rng))
+        k = 8 * int(torch.randint(1, 130, (1,), generator=rng)) if it % 4 == 3 else 64 * int(torch.randint(1, 17, (1,), generator=rng))
+        if it == 0:
+            m, n, k = 8192, 4096, 256      # two 256x256 tiles per CU: the persistent form
+        dtype = torch.bfloat16 if it & 1 else torch.float16
+        x = torch.randn(m, k, generator=rng).to(dtype)
+        w = (torch.randn(n, k, generator=rng) * 0.05).to(dtype)
+        o = sk.dense_linear(x.to(DEV), w.to(DEV))
+        ref = x.float() @ w.float().t()
+        tol = 3e-2 if dtype == torch.bfloat16 else 4e-3
+        err = (o.cpu().float() - ref).abs().max().item()
+        assert err <= tol * max(1.0, ref.abs().max().item()), f"M={m} N={n} K={k} {dtype}: {err}"
+
+
 # ---------------------------------------------------------------- fused decode kernels == their unfused op sequences
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("with_res", [True, False])
