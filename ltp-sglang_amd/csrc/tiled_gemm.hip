@@ -745,7 +745,11 @@ __global__ __launch_bounds__(512, 1) void fp8_gemm256p_kernel(const GemmParams p
     xvo[par] = (unsigned)((int64_t)rl * p.x_stride) + chunk * 16;
   }
   const int nk = p.kbytes / BKB;   // >= 3 (launcher)
-  auto stage_at = [&](int wo, int xo, int kt, int buf) {   // wo / xo: byte offsets of the tile's first W / X row (launcher: operands < 2 GiB)
+  // wo / xo: byte offsets of the tile's first W / X row (launcher: operands < 2 GiB), in the SCALAR offset.  The range check of gfx950
+  // covers vector + scalar offset (tools/microbench/buffer_soffset_check.hip: a load whose vector offset is inside the descriptor's
+  // range and whose sum with the scalar offset is not returns zeros, LDS-DMA form included), so a ragged last tile still gets zeros
+  // for its rows past N / M and nothing behind the operand is touched.
+  auto stage_at = [&](int wo, int xo, int kt, int buf) {
     const int off = kt * BKB;
     auto* wb = (__attribute__((address_space(3))) char*)(smem + buf * BUFB + (RPW * w) * BKB);
 #pragma unroll
