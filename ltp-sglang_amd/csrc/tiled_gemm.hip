@@ -1091,7 +1091,8 @@ int launch256p(GemmParams& p, hipStream_t st) {
   // (measured, tools/debug/persistent_256.py / persistent_silu.py, M = 65 536: K = 4096 x N = 6144 / 4096 / 28672 -5 % / -5 % / -2.5 %, K = 384-640
   // -10...-16 %; K = 14336 a tie (the hand-over is 4 % of a tile there and the static tile schedule gives up the dispatcher's load
   // balancing); the SiLU form a tie as well -- both stay on one tile per workgroup)
-  if (!g_tiled_persistent || SILU || p.kbytes > 8192 || cus < 8 || tiles < 2 * (int64_t)cus || p.kbytes < 3 * BKB || (int64_t)p.N * p.w_stride >= (1ll << 31) ||
+  static_assert(!SILU, "the SiluAndMul form stays on one tile per workgroup (a tie, see above); fp8_gemm256p_kernel supports it");
+  if (!g_tiled_persistent || p.kbytes > 8192 || cus < 8 || tiles < 2 * (int64_t)cus || p.kbytes < 3 * BKB || (int64_t)p.N * p.w_stride >= (1ll << 31) ||
       (int64_t)p.M * p.x_stride >= (1ll << 31))   // (the tile origin travels in a signed 32-bit scalar offset)
     return launch256<OutT, 8, true, ES, SILU>(p, st);
   constexpr int smem = 2 * 2 * OPB + (SILU ? kSiluLut * 2 : 0);
@@ -1394,7 +1395,7 @@ int sgl_mi355_internal_tiled_gemm_silu_mul(const void* x, int64_t x_stride_b, co
       filled[dev] = true;
     }
   }
-  return launch256p<__bf16, TG_FP8, true>(p, st);
+  return launch256<__bf16, 8, true, TG_FP8, true>(p, st);   // (the persistent form measured a tie for this epilogue: launch256p)
 }
 
 extern "C" int sgl_mi355_fp8_gemm_force_tile(int mode) {
