@@ -2,7 +2,9 @@
 batch 32 x seq 2048, synthetic random weights and token ids, every device op a hand-written HIP kernel.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1 without a launcher: this process starts the N ranks itself, one per GPU, as bench_one_batch.py:527-546 spawns one
+     process per tp_rank, and relays rank 0's JSON line; under `python -m torch.distributed.run --nproc-per-node N ... bench.py
+     --gpus N ...` the launcher's RANK / LOCAL_RANK / WORLD_SIZE are used and must agree with --gpus)
 
 A "step" is one decode step of the whole model for the whole batch (32 new tokens).  Inputs (weights, the KV pool
 filled by a real prefill of 32 x 2048 tokens, index tensors) are resident in HBM before the timed region.
@@ -44,6 +46,9 @@ def parse_args():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the measured configuration); gloo = rehearsal of the N > 1 path on fewer GPUs")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--allow-eager", action="store_true",
+                    help="if the HIP-graph capture of the decode step fails, time eager (launch-bound) steps and say so in the metric "
+                         "name instead of exiting with code 3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fused-decode", action="store_true", help="measurement hook: the per-op decode path (same logits, more launches)")
     ap.add_argument("--prefill-chunk", type=int, default=32,
@@ -148,8 +153,54 @@ def _traffic_profile():
         return os.path.relpath(path, ROOT), json.load(f)
 
 
+def spawn_ranks(args):
+    """`bench.py --gpus N` without a launcher (WORLD_SIZE unset): start the N ranks here -- one child process per GPU with RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_* set, the reference's bench_one_batch.py:527-546 (one process per tp_rank) -- relay rank 0's
+    stdout (the JSON line), and exit non-zero as soon as any rank does.  This parent never touches a GPU (no HIP call, no exec of a
+    process that has initialised one): the children are fresh interpreters."""
+    import socket
+    import subprocess
+
+    n = args.gpus
+    if args.dist_backend == "nccl" and torch.cuda.device_count() < n:   # (device_count() does not initialise the GPU on this image)
+        raise SystemExit(f"[bench] --gpus {n} over RCCL needs {n} visible GPUs, found {torch.cuda.device_count()} "
+                         f"(--dist-backend gloo rehearses the N > 1 path on fewer)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL and the P2P all-reduce both need it on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))   # only rank 0 owns stdout
+    rc = 0
+    live = list(procs)
+    while live and rc == 0:
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is not None:
+                live.remove(p)
+                if code != 0:
+                    rc = code if code > 0 else 1
+    for p in live:   # a rank failed: its peers would wait in a collective forever
+        p.terminate()
+    for p in live:
+        try:
+            p.wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            p.kill()
+    if rc:
+        print(f"[bench] a rank exited with code {rc}; the job is void", file=sys.stderr)
+    raise SystemExit(rc)
+
+
 def main():
     args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args)   # does not return
     phases, t_phase = {}, time.perf_counter()
 
     def phase(name):
@@ -161,6 +212,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"[bench] --gpus {args.gpus} but the launcher set WORLD_SIZE={world}: the two must agree "
+                         f"(plain `python bench.py --gpus N` starts its own N ranks)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
     local_rank %= max(1, torch.cuda.device_count())  # (gloo rehearsal: several ranks may share one GPU)
@@ -174,6 +228,8 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device(dev))
         else:
             dist.init_process_group("gloo")
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"[bench] process group has {dist.get_world_size()} ranks, --gpus says {args.gpus}")
 
     from __graft_entry__ import load_package
 
@@ -182,7 +238,11 @@ def main():
     from ltp_sglang_amd.srt.model_executor.synthetic_llama import LlamaShape, SyntheticModelRunner
 
     comm.init_tensor_parallel()
-    ar_kind = "none" if world == 1 else "rccl"
+    cfg = {"llama3-8b": LlamaShape.llama3_8b, "llama3-70b": LlamaShape.llama3_70b, "qwen2-7b": LlamaShape.qwen2_7b,
+           "tiny": LlamaShape.tiny}[args.model]()
+    if args.layers:
+        cfg.num_hidden_layers = args.layers
+    ar_kind = "none" if world == 1 else ("rccl" if args.dist_backend == "nccl" else "gloo through host copies (rehearsal)")
     if world > 1 and args.all_reduce != "rccl" and (args.dist_backend == "nccl" or args.all_reduce == "p2p"):
         # one-shot P2P all-reduce / all-gather (custom_all_reduce_hip.cuh:261-294 in the reference): IPC handles travel over a
         # gloo side group; before it is trusted, one all-reduce and one all-gather are compared with RCCL's results on every rank
@@ -225,8 +285,15 @@ def main():
         flag = torch.tensor([1 if ok else 0], device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)   # all ranks or none
         if int(flag.item()) == 1:
+            # The two-stage kernels (custom_all_reduce_hip.cuh:294) become part of the default dispatch only after THIS job has
+            # checked them, plain and fused, on a message above the reference's threshold (>= 1 MiB at the model's hidden size)
+            # against RCCL on every rank; otherwise every message stays on the one-shot kernel.
+            two_stage = car.validate_two_stage(comm.tensor_model_parallel_all_reduce, rows=max(128, (1 << 19) // cfg.hidden_size),
+                                               hidden=cfg.hidden_size)
             comm.set_custom_all_reduce(car)
-            ar_kind = "p2p (one-shot below the reference's size rule, two-stage above; fused with add + RMSNorm + quant)"
+            ar_kind = ("p2p (one-shot below the reference's size rule, two-stage above -- both self-checked against "
+                       + ("RCCL" if args.dist_backend == "nccl" else "the host sum") + "; fused with add + RMSNorm + quant)"
+                       if two_stage else "p2p one-shot at every size (the two-stage self-check did not pass); fused with add + RMSNorm + quant")
         elif args.all_reduce == "p2p":
             raise SystemExit(f"[bench] rank {rank}: --all-reduce p2p requested but unusable ({why or 'a peer failed'})")
         elif rank == 0:
@@ -243,10 +310,6 @@ def main():
         from ltp_sglang_amd import _cabi
 
         _cabi.check(_cabi.lib.sgl_mi355_decode_attention_set_mode(args.decode_attn_mode))
-    cfg = {"llama3-8b": LlamaShape.llama3_8b, "llama3-70b": LlamaShape.llama3_70b, "qwen2-7b": LlamaShape.qwen2_7b,
-           "tiny": LlamaShape.tiny}[args.model]()
-    if args.layers:
-        cfg.num_hidden_layers = args.layers
     quant = None if args.quant == "none" else args.quant
     bs, seq = args.batch, args.seq_len
     total_steps = args.steps + args.warmup + 4
@@ -308,6 +371,12 @@ def main():
 
     # ---- decode: W warm-up + K timed steps ----
     use_graph = not args.no_graph
+    if use_graph and world > 1 and args.dist_backend == "gloo" and comm._CUSTOM_AR is None:
+        # gloo rehearsal without the P2P communicator: the collectives are host copies, which no graph can hold -- eager by design
+        use_graph = False
+        if rank == 0:
+            print("[bench] gloo rehearsal with host-staged collectives: eager steps (not the metric)", file=sys.stderr)
+    graph_wanted = use_graph
     if use_graph:
         why = ""
         try:
@@ -326,8 +395,12 @@ def main():
         if not use_graph and rank == 0:
             # stated, not silent: config.hip_graph in the JSON line is false and the step is launch-bound (gloo rehearsal: host-staged
             # collectives cannot be captured, eager by design)
-            print(f"[bench] HIP-graph capture of the decode step not used ({why or 'a peer rank could not capture'}); timing eager steps",
+            print(f"[bench] HIP-graph capture of the decode step not used ({why or 'a peer rank could not capture'}); "
+                  + ("timing eager steps" if args.allow_eager else "exit 3 (--allow-eager times launch-bound eager steps instead)"),
                   file=sys.stderr)
+        if graph_wanted and not use_graph and not args.allow_eager:
+            # a launch-bound eager number must never be recorded as the metric by accident: every rank leaves (they all agree)
+            raise SystemExit(3)
     phase("capture")
     step_fn = runner.decode_graph if use_graph else runner.decode
     for _ in range(args.warmup):
@@ -340,10 +413,10 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1 and comm._CUSTOM_AR is not None:
         comm._CUSTOM_AR.check_error()   # a peer that missed a spin bound leaves sums unreduced: fail instead of reporting a time
-    mlp_sc = getattr(runner.model, "_mlp_scratch", {})
-    for sc in mlp_sc.values():   # persistent MLP launch (SGL_MI355_MLP_BLOCK=1): a hand-off that timed out
-        if int(sc.error_codes().abs().sum()) != 0:
-            raise SystemExit(f"[bench] rank {rank}: fp8_mlp_block hand-off timed out: {sc.error_codes().tolist()}")
+    try:
+        runner.check_errors()   # persistent MLP launch (SGL_MI355_MLP_BLOCK=1): a hand-off that timed out voids the steps
+    except RuntimeError as e:
+        raise SystemExit(f"[bench] rank {rank}: {e}")
     phase("decode")
     if world > 1:
         import torch.distributed as dist
@@ -361,13 +434,26 @@ def main():
     qd = torch.randn(bs, hq_r, d, device=dev).to(runner.dtype)
     pool = runner.token_to_kv_pool
     evs = []
+    be = runner.attn_backend
+    fp8_lin = quant in ("w8a8_fp8", "fp8")
+    in_launch_merge = d in (64, 128) and hq_r * d <= 16384 and (
+        (fp8_lin and runner.model.fused_decode and runner.model.fused_attn_merge) or (not fp8_lin and be.merge_in_launch))
+    kscale, vscale = runner.model.layers[0].self_attn.kv_scales()
+    kscale, vscale = (float(kscale) if kscale is not None else 1.0), (float(vscale) if vscale is not None else 1.0)
     for rep in range(3):
         for l in range(L):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            # o = None: stage 1 only (the split partials), which is the kernel the roofline object describes
-            K.decode_attention_fwd(qd, pool.get_key_buffer(l), pool.get_value_buffer(l), None, md.kv_indptr, md.kv_indices,
-                                   md.attn_logits, md.attn_lse, md.num_kv_splits, runner.attn_backend.max_kv_splits, d ** -0.5)
+            if in_launch_merge:
+                # the launch the captured step runs: stage 1 + the stage-2 merge + per-token fp8 quant of the merged rows by each
+                # request's last workgroup (r3's probe timed stage 1 alone, a cheaper launch than the step's)
+                K.decode_attention_merge_quant(qd, pool.get_key_buffer(l), pool.get_value_buffer(l), md.kv_indptr, md.kv_indices,
+                                               md.attn_logits, md.attn_lse, md.num_kv_splits, be.max_kv_splits, d ** -0.5,
+                                               be._merge_counter_buf(qd), 0.0, kscale, vscale, want_o=not fp8_lin, want_quant=fp8_lin)
+            else:
+                # o = None: stage 1 only (the split partials)
+                K.decode_attention_fwd(qd, pool.get_key_buffer(l), pool.get_value_buffer(l), None, md.kv_indptr, md.kv_indices,
+                                       md.attn_logits, md.attn_lse, md.num_kv_splits, be.max_kv_splits, d ** -0.5)
             e1.record()
             evs.append((e0, e1))
     torch.cuda.synchronize()
@@ -396,8 +482,9 @@ def main():
     out = {
         "metric": ("decode tokens/sec (whole job) + prefill TFLOPS, Llama-3-8B fp8 batch=32 seq=2048"
                    if (args.model, args.quant, bs, seq, args.kv_cache_dtype) == ("llama3-8b", "w8a8_fp8", 32, 2048, "auto") else
-                   f"decode tokens/sec (whole job) + prefill TFLOPS, {args.model} {args.quant} batch={bs} seq={seq} kv={args.kv_cache_dtype}"),
-        "value": tok_s, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                   f"decode tokens/sec (whole job) + prefill TFLOPS, {args.model} {args.quant} batch={bs} seq={seq} kv={args.kv_cache_dtype}")
+                  + ("" if use_graph else " [EAGER launches, no HIP graph: launch-bound, not the metric]"),
+        "value": tok_s, "unit": "tokens/s", "n_gpus": args.gpus, "world_size_observed": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "fp8_e4m3 weights+activations (f32 accumulate), bf16 KV/attention" if quant in ("w8a8_fp8", "fp8") else str(quant or "bf16"),
         "data": "synthetic",
@@ -412,7 +499,8 @@ def main():
         "step_roofline": {"algorithmic_bytes_per_step": step_bytes, "hbm_peak_GBps": 8000.0,
                           "ranks_counted": ranks_run,
                           "frac_of_hbm_roofline": step_bytes / (elapsed / args.steps) / (8e12 * ranks_run)},
-        "roofline": {"kernel": "decode_attn_stage1", "bound": "hbm", "achieved": achieved, "peak": 8000.0,
+        "roofline": {"kernel": "decode_attn_stage1" + (" (+ in-launch stage-2 merge + fp8 quant, the launch the step runs)" if in_launch_merge else " (stage 1 only)"),
+                     "bound": "hbm", "achieved": achieved, "peak": 8000.0,
                      "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                      "traffic_source": traffic_src, "traffic_profile_git_sha": traffic_sha, "launch_us": attn_ms * 1e3, "algorithmic_bytes_per_launch": kv_bytes},
     }

@@ -10,6 +10,7 @@
 // workgroups that share an X row panel run on the same XCD (one L2).
 #include "common.h"
 #include "silu_lut.h"
+#include <atomic>
 #include <type_traits>
 
 namespace {
@@ -29,7 +30,6 @@ struct GemmParams {
   int group_m;  // row tiles per scheduling group (256x256 kernel)
   float* slabs;  // split-K (128x128 kernel, blockIdx.y = K range of `kt_per` slices): raw f32 sums [splits][M][N], else NULL
   int kt_per;
-  int* counters = nullptr;  // streaming tile, in-launch split-K combine: two words per output tile (arrivals, departures), zero between launches
   const uint16_t* silu_lut = nullptr;  // SiluAndMul epilogue of the 256x256 kernel: the table of silu_lut.h in global memory
   int stagger_q, stagger_cus;  // 256x256 kernel: start stagger of each CU's first workgroup (quantum in 1024-cycle units; CU count)
 #ifdef SGL_GEMM_TIMELINE
@@ -985,7 +985,6 @@ __global__ __launch_bounds__(512, 1) void fp8_gemm128s_kernel(const GemmParams p
 
   // ---- epilogue: acc[j][i][r] -> row m0+wm+16i+a, col n0+wn+16j+4g+r ----
   if (p.slabs) {
-    // write-through (sc1) stores when the partial sums are combined inside this launch (hand-off to other workgroups)
     const auto srs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.slabs + (int64_t)blockIdx.y * p.M * p.N), 0,
                                                        (unsigned)((int64_t)p.M * p.N * 4), 0x00020000);
 #pragma unroll
@@ -995,58 +994,12 @@ __global__ __launch_bounds__(512, 1) void fp8_gemm128s_kernel(const GemmParams p
       for (int j = 0; j < 2; ++j) {
         const int n = n0 + wn + 16 * j + 4 * g;
         const unsigned off = (m < p.M && n + 3 < p.N) ? (unsigned)(((int64_t)m * p.N + n) * 4) : 0xFFFFFFF0u;  // (N % 4 == 0 in slab mode)
-        if (p.counters) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[j][i]), srs, off, 0, 16);
-        else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[j][i]), srs, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[j][i]), srs, off, 0, 0);
       }
     }
-    if (p.counters == nullptr) return;  // the consumer (a reduce launch, or a kernel that takes slabs) combines them
-    // ---- in-launch split-K combine (round 3): the S workgroups of a tile wait for each other, then each combines 1/S of the
-    // tile -- the sums of tiled_splitk_reduce_kernel in the same order, so the same bits, without the extra launch (5.6 us at the
-    // 70B TP-8 shard shapes) and without the second pass over M x N x S floats through HBM.  All S x tiles workgroups are resident
-    // (the launcher makes S x tiles <= CUs and a workgroup takes 128 KiB of LDS), every spin is bounded.  Hand-off form: sc1
-    // stores, every wave drains, barrier, one lane adds; one lane polls with sc1 loads, barrier, sc1 loads
-    // (MI355X_MICROARCH.md, visibility table, first row). ----
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    const int S = gridDim.y;
-    int* cnt = p.counters + 2 * blockIdx.x;
-    if (tid == 0) {
-      __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      for (int spin = 0; spin < (1 << 22); ++spin) {
-        if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= S) break;
-        __builtin_amdgcn_s_sleep(1);
-      }
-    }
-    __syncthreads();
-    const auto ars = __builtin_amdgcn_make_buffer_rsrc((void*)p.slabs, 0, (unsigned)min((int64_t)S * p.M * p.N * 4, (int64_t)0xFFFFFFF0ll), 0x00020000);
-    const unsigned slab_b = (unsigned)((int64_t)p.M * p.N * 4);
-    for (int f = tid + 512 * (int)blockIdx.y; f < S_BM * S_BN / 4; f += 512 * S) {
-      const int m = m0 + f / (S_BN / 4), n = n0 + (f % (S_BN / 4)) * 4;
-      if (m >= p.M || n + 3 >= p.N) continue;
-      const unsigned off = (unsigned)(((int64_t)m * p.N + n) * 4);
-      f32x4_t v = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(ars, off, 0, 16));
-      for (int sI = 1; sI < S; ++sI)
-        v += __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(ars, off + (unsigned)sI * slab_b, 0, 16));
-      OutT o[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        float r = v[c];
-        if (p.sx) r *= p.sx[m];
-        r = r * (p.sw ? p.sw[n + c] : 1.0f) + (p.bias ? (float)((const OutT*)p.bias)[n + c] : 0.0f);
-        o[c] = (OutT)r;
-      }
-      OutT* yp = (OutT*)p.y + (int64_t)m * p.y_stride + n;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) yp[c] = o[c];
-    }
-    __syncthreads();
-    if (tid == 0) {  // the last workgroup to leave puts both words back to zero (everybody has passed the wait by then)
-      const int d = __hip_atomic_fetch_add(cnt + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (d == S - 1) {
-        __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(cnt + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
+    // the consumer (the reduce launch, or a kernel that takes slabs) combines them.  (Round 3 also had an in-launch combine --
+    // the S workgroups of a tile waiting for each other on a counter; it measured slower than the reduce launch at every shape
+    // tried (DESIGN.md section 5 "Round 3" item 3a) and was removed in round 4 together with its counters.)
     return;
   }
   epilogue_scaled<OutT, 4, 2>(p, acc, m0 + wm + a, n0 + wn + 4 * g);
@@ -1173,13 +1126,6 @@ int launch(GemmParams& p, hipStream_t st, float* workspace = nullptr, int64_t wo
   return SGL_MI355_OK;
 }
 
-constexpr int64_t kCounterFloats = 1024;
-// In-launch split-K combine: OFF by default.  Same-box A/B in the model (round 3): Llama-3-70B TP-8 shard, batch 128: 10.70 ms/step
-// with it against 10.16 with the separate reduce launch; Llama-3-8B batch 128: 9.99 against 9.95 -- the workgroups of a tile wait
-// for the slowest one and then read the slabs behind their own still-draining stores, which costs more than the 1.7 us launch
-// boundary + 5.6 us reduce kernel it removes (the "splitk-seam" row of MI355X_MICROARCH.md's price list says the same).  Kept as
-// a tested option: sgl_mi355_fp8_gemm_force_tile(2001) turns it on, 2000 off.
-int g_tiled_inlaunch = 0;
 // split-K ranges of the streaming 128x128 tile for this shape (1: none) and the slices per range
 inline int splits128s(int M, int N, int kbytes, bool have_workspace, int64_t workspace_floats, int* kt_per) {
   const int tiles = ((M + S_BM - 1) / S_BM) * ((N + S_BN - 1) / S_BN), nk = kbytes / BKB, cus = tg_cus();
@@ -1211,17 +1157,12 @@ int launch128s(GemmParams& p, hipStream_t st, float* workspace, int64_t workspac
   p.tiles_m = (p.M + S_BM - 1) / S_BM;
   p.tiles_n = (p.N + S_BN - 1) / S_BN;
   const int tiles = p.tiles_m * p.tiles_n;
-  // the last kCounterFloats floats of the workspace hold the in-launch combine's counters (zero between launches)
-  const int64_t slab_floats = workspace_floats > kCounterFloats ? workspace_floats - kCounterFloats : 0;
-  const int splits = splits128s(p.M, p.N, p.kbytes, workspace != nullptr, slab_floats, &p.kt_per);
+  const int splits = splits128s(p.M, p.N, p.kbytes, workspace != nullptr, workspace_floats, &p.kt_per);
   p.slabs = splits > 1 ? workspace : nullptr;
   SGL_CHECK(!slabs_only || splits > 1, "fp8_gemm_slabs: this shape runs as one k-range (no slabs): M=%d N=%d", p.M, p.N);
-  const bool in_launch = splits > 1 && !slabs_only && g_tiled_inlaunch && 2 * tiles <= kCounterFloats && p.N % 4 == 0 &&
-                         (int64_t)splits * p.M * p.N * 4 < 0xFFFFFFF0ll && tiles * splits <= tg_cus();
-  p.counters = in_launch ? (int*)(workspace + slab_floats) : nullptr;
   hipLaunchKernelGGL((fp8_gemm128s_kernel<OutT>), dim3(tiles, splits), dim3(512), smem, st, p);
   SGL_HIP_LAUNCH_CHECK();
-  if (splits > 1 && !slabs_only && !in_launch) {
+  if (splits > 1 && !slabs_only) {
     const int64_t items = (int64_t)p.M * (p.N / 4);
     const unsigned blocks = (unsigned)((items + 255) / 256 > 4096 ? 4096 : (items + 255) / 256);
     hipLaunchKernelGGL((tiled_splitk_reduce_kernel<OutT>), dim3(blocks), dim3(256), 0, st, workspace, splits, p.sx, p.sw,
@@ -1255,7 +1196,7 @@ inline TileChoice choose_tile(int M, int N, int kbytes, int64_t x_stride_b, int6
   const int64_t t256 = tm256 * ((N + T2 - 1) / T2), tnar = tm256 * ((N + 127) / 128), t128 = (int64_t)((M + S_BM - 1) / S_BM) * ((N + S_BN - 1) / S_BN);
   if (t128 > 8 * (int64_t)cus) return kTile256;   // many rounds either way
   int kt_per = 0;
-  const int splits = splits128s(M, N, kbytes, have_workspace, workspace_floats > kCounterFloats ? workspace_floats - kCounterFloats : 0, &kt_per);
+  const int splits = splits128s(M, N, kbytes, have_workspace, workspace_floats, &kt_per);
   const double r = (double)t128 * splits / cus, rounds = r <= 1.0 ? 1.0 : 0.5 * (ceil(r) + r);
   const double cost128 = rounds * 24.0 * k4 / splits + (splits > 1 ? 7.0 : 0.0);
   const double cost256 = ceil((double)t256 / cus) * 49.0 * k4;
@@ -1353,8 +1294,26 @@ __device__ uint16_t g_silu_lut[kSiluLut];
 __global__ __launch_bounds__(256) void silu_lut_fill_kernel() {
   for (int i = threadIdx.x + 256 * blockIdx.x; i < kSiluLut; i += 256 * gridDim.x) g_silu_lut[i] = silu_lut_entry(i);
 }
+constexpr int kMaxSiluDevices = 64;
+std::atomic<bool> g_silu_table_ready[kMaxSiluDevices];   // set by sgl_mi355_silu_table_init once the fill has been ENQUEUED
 
 }  // namespace
+
+// Per-device initialisation of the SiluAndMul epilogue's table (csrc/silu_lut.h): enqueues the fill kernel on `stream` of the
+// CURRENT device and returns -- no host synchronisation.  The caller orders later work after it (the Python wrapper waits for the
+// device once).  Idempotent; refused under stream capture (a captured fill would run at replay, not now).
+extern "C" int sgl_mi355_silu_table_init(void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  int dev = -1;
+  SGL_CHECK(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < kMaxSiluDevices, "silu_table_init: cannot identify the current device");
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  SGL_CHECK(hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone,
+            "silu_table_init: must not be called while the stream is capturing");
+  hipLaunchKernelGGL(silu_lut_fill_kernel, dim3(4), dim3(256), 0, st);
+  SGL_HIP_LAUNCH_CHECK();
+  g_silu_table_ready[dev].store(true, std::memory_order_release);
+  return SGL_MI355_OK;
+}
 
 // gate_up_proj + SiluAndMul for M > 64 (called by sgl_mi355_gemm_silu_mul, skinny_gemm.hip): fp8 operands, bf16 out, 16-row
 // interleaving, N % 256 == 0, whole 128-byte K slices.  Returns SGL_MI355_EINVAL with a message otherwise.
@@ -1376,24 +1335,13 @@ int sgl_mi355_internal_tiled_gemm_silu_mul(const void* x, int64_t x_stride_b, co
     return SGL_MI355_EINVAL;
   }
   p.silu_lut = (const uint16_t*)lut;
-  // The table is a constant of the device: filled once per device and process, then waited for, so that a later call on another
-  // stream finds it complete (5 us per call before: 1 % of a 2 048-token prefill chunk's layer).  Under stream capture the fill
-  // is part of every captured call instead -- nothing executes at capture time, and the graph must not depend on what ran before it.
-  static bool filled[64] = {};
-  int dev = 0;
-  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  const bool capturing = hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
-  const bool known = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64;
-  if (capturing || !known || !filled[dev]) {
-    hipLaunchKernelGGL(silu_lut_fill_kernel, dim3(4), dim3(256), 0, st);
-    SGL_HIP_LAUNCH_CHECK();
-    if (!capturing && known) {
-      // (a refused wait -- another thread is capturing in global mode -- is not an error of this call: the fill is in the stream
-      // ahead of the GEMM either way; the table just stays "not known to be complete" and is filled again next time)
-      if (hipStreamSynchronize(st) == hipSuccess) filled[dev] = true;
-      else (void)hipGetLastError();
-    }
-  }
+  // The table is a constant of the device, filled by sgl_mi355_silu_table_init (an explicit per-device init entry point: this
+  // launcher neither synchronises nor keeps launch-time state, like every other one).
+  int dev = -1;
+  SGL_CHECK(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < kMaxSiluDevices, "gemm_silu_mul: cannot identify the current device");
+  SGL_CHECK(g_silu_table_ready[dev].load(std::memory_order_acquire),
+            "gemm_silu_mul: the silu table of device %d is not initialised -- call sgl_mi355_silu_table_init(stream) once per device "
+            "(outside stream capture) and order later work after it", dev);
   return launch256<__bf16, 8, true, TG_FP8, true>(p, st);   // (the persistent form measured a tie for this epilogue: launch256p)
 }
 
@@ -1402,10 +1350,7 @@ extern "C" int sgl_mi355_fp8_gemm_force_tile(int mode) {
     g_tiled_persistent = mode - 3000;
     return SGL_MI355_OK;
   }
-  if (mode >= 2000) {  // measurement hook: 2000 = split-K combined by a separate reduce launch (default), 2001 = inside the GEMM launch
-    g_tiled_inlaunch = mode - 2000;
-    return SGL_MI355_OK;
-  }
+  SGL_CHECK(mode < 2000 || mode >= 3000, "fp8_gemm_force_tile: the 2000 range (in-launch split-K combine) was removed in round 4");
   if (mode >= 1000) {  // measurement hook: 1000 + q sets the start-stagger quantum of the 256x256 kernel (0 = off)
     g_tiled_stagger = mode - 1000;
     return SGL_MI355_OK;
@@ -1438,7 +1383,7 @@ extern "C" int sgl_mi355_fp8_gemm_tile_choice(int M, int N, int K, int64_t works
 extern "C" int sgl_mi355_fp8_gemm_num_slabs(int M, int N, int K, int64_t workspace_floats) {
   if (M <= 0 || N <= 0 || K <= 0 || !takes128s(M, N, K, K, K, true, workspace_floats)) return 1;
   int kt_per = 0;
-  return splits128s(M, N, K, true, workspace_floats > kCounterFloats ? workspace_floats - kCounterFloats : 0, &kt_per);
+  return splits128s(M, N, K, true, workspace_floats, &kt_per);
 }
 
 // Producer half of the launch-boundary split-K reduce for 64 < M <= 256: the raw f32 partial sums [num_slabs][M][N] of

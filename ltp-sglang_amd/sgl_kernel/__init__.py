@@ -36,6 +36,7 @@ from .fused import (
     interleave_rope_rows,
     rope_set_kv,
     silu_and_mul_quant_fp8,
+    silu_table_init,
 )
 from .gemm import (
     awq_dequantize,

@@ -82,9 +82,30 @@ def interleave_rope_rows(t: torch.Tensor, num_q_heads: int, num_kv_heads: int, h
     return torch.cat([qk, t[nrope:]], dim=0).contiguous()
 
 
+_SILU_TABLE_READY = set()   # device indices whose silu table has been filled AND waited for
+
+
+def silu_table_init(device) -> None:
+    """Once per device: fills the table the M > 64 SiluAndMul epilogue reads (sgl_mi355_silu_table_init enqueues, this waits, so
+    that any stream may use it afterwards).  Must happen outside stream capture: run one eager step before capturing."""
+    idx = torch.device(device).index
+    idx = torch.cuda.current_device() if idx is None else idx
+    if idx in _SILU_TABLE_READY:
+        return
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("fp8_gemm_silu_mul: the silu table of this device is not initialised and the stream is capturing; "
+                           "run the op (or sgl_kernel.silu_table_init) once eagerly first")
+    with torch.cuda.device(idx):
+        check(lib.sgl_mi355_silu_table_init(current_stream()))
+        torch.cuda.synchronize(idx)
+    _SILU_TABLE_READY.add(idx)
+
+
 def fp8_gemm_silu_mul(x_q, x_s, w_interleaved_nk, w_s_interleaved, out_dtype, tile_rows: int = 16):
     """act [M, I] = SiluAndMul(fp8_scaled_mm(x_q, W)) with W's rows interleaved by interleave_gate_up_rows."""
     m, k = x_q.shape
+    if m > 64:
+        silu_table_init(x_q.device)
     n = w_interleaved_nk.shape[0]
     act = torch.empty((m, n // 2), dtype=out_dtype, device=x_q.device)
     check(lib.sgl_mi355_fp8_gemm_silu_mul(ptr(x_q), x_q.stride(0), ptr(w_interleaved_nk), w_interleaved_nk.stride(0), ptr(act),

@@ -10,6 +10,7 @@ flag every peer, wait for every peer, sum in rank order (see csrc/custom_all_red
 processes on ONE GPU (tests/test_custom_all_reduce_gpu.py); on a node the same code path reads over xGMI.
 """
 import ctypes
+import os
 from typing import List, Optional
 
 import torch
@@ -33,6 +34,10 @@ class CustomAllreduce:
         self.max_size = int(max_size) // 16 * 16
         self._own = ctypes.c_void_p()
         self._peers: List[Optional[int]] = []
+        # The two-stage kernels (algo 2) have run with several processes on ONE GPU only; over xGMI they are unvalidated.  Until a
+        # caller has checked them on the devices of this group (``validate_two_stage``; bench.py does at start-up) or opts in with
+        # SGL_MI355_CAR_TWO_STAGE=1, the default dispatch (algo 0) stays on the one-shot kernel at every message size.
+        self.two_stage_enabled = os.environ.get("SGL_MI355_CAR_TWO_STAGE", "0") == "1"
         if self.world_size == 1 or self.world_size not in _SUPPORTED_WORLD_SIZES:
             self.disabled_reason = f"world size {self.world_size} not in {_SUPPORTED_WORLD_SIZES}"
             return
@@ -94,12 +99,52 @@ class CustomAllreduce:
 
     should_custom_ar = should_use
 
+    def _algo(self, algo: int) -> int:
+        """The default (0 = the reference's size rule, custom_all_reduce_hip.cuh:543-549) may pick the two-stage kernels only
+        once they are enabled on every rank alike; an explicit 1 / 2 is passed through."""
+        return 1 if int(algo) == 0 and not self.two_stage_enabled else int(algo)
+
+    def validate_two_stage(self, reference_all_reduce, rows: int = 128, hidden: int = 8192) -> bool:
+        """Runs the plain and the fused two-stage kernels once on a message above the reference's 8-rank threshold (rows x hidden
+        bf16 = 2 MiB by default) and compares them with ``reference_all_reduce`` (an f32 sum over RCCL / the host) and with the
+        unfused row arithmetic.  Every rank must call it; the outcome is agreed over the CPU group, and only a pass on ALL ranks
+        sets ``two_stage_enabled`` (so the dispatch stays the same everywhere).  Returns the agreed outcome."""
+        from ...sgl_kernel import fused_add_rmsnorm_quant_fp8
+
+        ok = False
+        if not self.disabled and rows * hidden * 2 <= self.max_size:
+            try:
+                dev = self.device
+                gen = torch.Generator(device=dev).manual_seed(1000 + self.rank)
+                probe = torch.randn(rows, hidden, device=dev, generator=gen).to(torch.bfloat16)
+                want = reference_all_reduce(probe.float())
+                got = self.all_reduce(probe.clone(), algo=2)
+                self.check_error()
+                ok = bool(((got.float() - want).abs() <= 0.02 * want.abs() + 0.05).all())
+                g7 = torch.Generator(device=dev).manual_seed(7)
+                w = (1 + 0.1 * torch.randn(hidden, device=dev, generator=g7)).to(torch.bfloat16)
+                res0 = torch.randn(rows, hidden, device=dev, generator=torch.Generator(device=dev).manual_seed(11)).to(torch.bfloat16)
+                r1, r2 = res0.clone(), res0.clone()
+                n1, _, s1 = fused_add_rmsnorm_quant_fp8(want.to(torch.bfloat16), r1, w, 1e-5, want_norm=True)
+                n2, _, s2 = self.all_reduce_add_rmsnorm_quant(probe.clone(), r2, w, 1e-5, want_norm=True, algo=2)
+                self.check_error()
+                ok = (ok and bool(((n2.float() - n1.float()).abs() <= 0.03 * n1.float().abs() + 0.06).all())
+                      and bool(((r2.float() - r1.float()).abs() <= 0.03 * r1.float().abs() + 0.06).all())
+                      and bool(((s2 - s1).abs() <= 0.03 * s1.abs() + 1e-6).all()))
+            except Exception:   # a spin bound reached, a launch error: the one-shot kernel stays the default
+                ok = False
+        outcomes = [None] * self.world_size
+        dist.all_gather_object(outcomes, bool(ok), group=self.group)
+        self.two_stage_enabled = all(outcomes)
+        return self.two_stage_enabled
+
     def all_reduce(self, inp: torch.Tensor, algo: int = 0) -> torch.Tensor:
         """In-place sum over the group; returns ``inp``.  Capturable in a HIP graph (epochs live in device memory).
-        ``algo``: 0 = the reference's dispatch rule (custom_all_reduce_hip.cuh:543-549), 1 = one-shot, 2 = two-stage
-        (reduce-scatter + all-gather); the same value on every rank."""
+        ``algo``: 0 = the reference's dispatch rule (custom_all_reduce_hip.cuh:543-549) once the two-stage kernels are enabled
+        (``two_stage_enabled``; one-shot at every size before), 1 = one-shot, 2 = two-stage (reduce-scatter + all-gather); the
+        same value on every rank."""
         check(lib.sgl_mi355_car_all_reduce_algo(inp.data_ptr(), inp.numel(), dtype_code(inp.dtype), self._ptrs, self.rank,
-                                                self.world_size, self.max_size, int(algo), current_stream()))
+                                                self.world_size, self.max_size, self._algo(algo), current_stream()))
         return inp
 
     custom_all_reduce = all_reduce
@@ -129,7 +174,7 @@ class CustomAllreduce:
             partial.data_ptr(), None if residual is None else residual.data_ptr(), weight.data_ptr(), float(eps),
             None if out_norm is None else out_norm.data_ptr(), None if out_q is None else out_q.data_ptr(),
             None if out_s is None else out_s.data_ptr(), m, h, dtype_code(partial.dtype), self._ptrs, self.rank, self.world_size,
-            self.max_size, int(algo), current_stream()))
+            self.max_size, self._algo(algo), current_stream()))
         return out_norm, out_q, out_s
 
     def should_use_gather(self, inp: torch.Tensor) -> bool:

@@ -681,9 +681,23 @@ class SyntheticModelRunner:
                                      self.req_to_token_pool, self.token_to_kv_pool, self.attn_backend,
                                      seq_lens_cpu=torch.tensor(state.seq_lens_cpu, dtype=torch.int64))
 
+    def check_errors(self) -> None:
+        """Raises if a bounded spin of the persistent MLP launch (SGL_MI355_MLP_BLOCK=1, off by default) ran out during an earlier
+        step: the launch then ran on with incomplete hand-off data and the logits of that step are invalid (a captured graph
+        would replay the condition unnoticed).  Reads the per-layer sync words (a device -> host copy: synchronises).  decode() /
+        decode_graph() call it for the PREVIOUS step, whose logits the caller has consumed by then; call it after the last step.
+        The launch also needs every CU for itself: nothing else may run on the device during a step."""
+        for sc in getattr(self.model, "_mlp_scratch", {}).values():
+            codes = sc.error_codes()
+            if int(codes.abs().sum()) != 0:
+                raise RuntimeError(f"fp8_mlp_block: a hand-off timed out in an earlier step (sync words {codes.tolist()}); "
+                                   "that step's logits are invalid -- unset SGL_MI355_MLP_BLOCK (the four-launch path)")
+
     @torch.no_grad()
     def decode(self, state, next_ids: torch.Tensor, shared_prefix_len: int = 0):
         """shared_prefix_len > 0: every request of the batch shares its first slots (one radix node): cascade decode attention."""
+        if self.model.fused_mlp_block:
+            self.check_errors()
         fb = self._prepare_decode(state, next_ids)
         if shared_prefix_len > 0:
             self.attn_backend.init_forward_metadata_cascade(fb, shared_prefix_len)
@@ -730,6 +744,8 @@ class SyntheticModelRunner:
     def decode_graph(self, state, next_ids: torch.Tensor, shared_prefix_len: int = 0):
         bs = len(state.seq_lens_cpu)
         graph, buf = self._graphs[(bs, int(shared_prefix_len))]
+        if self.model.fused_mlp_block:
+            self.check_errors()
         self.attn_backend.cascade_shared_prefix_len = int(shared_prefix_len)
         if not self.fused_decode_prepare:
             fb = self._prepare_decode(state, next_ids)

@@ -30,11 +30,12 @@ def _loadable():
     return r.returncode == 0 and "ok" in r.stdout
 
 
-pytestmark = pytest.mark.skipif(not _loadable(), reason="oracle/_ref not built (or not runnable on this host)")
-
-
 @pytest.fixture(scope="module")
 def ref():
+    # checked lazily, inside the fixture: a run that deselects this module (`-m gpu` on the GPU box) must not map oracle/_ref at
+    # collection time (round 3's module-level skipif did, which is why the driver's record listed an oracle/ library as loaded)
+    if not _loadable():
+        pytest.skip("oracle/_ref not built (or not runnable on this host)")
     torch.ops.load_library(LIB)
     return torch.ops.sgl_ref
 
