@@ -55,6 +55,8 @@ def parse_args():
                     help="requests per prefill call (32 = the whole BASELINE batch in one extend, as bench_one_batch.py does; "
                          "sweep on one box: 4 / 8 / 16 / 32 requests -> 1 915 / 1 950 / 1 958 / 1 978 TFLOP/s)")
     ap.add_argument("--gemm-hook", type=int, default=0, help="measurement hook: value passed to sgl_mi355_fp8_gemm_force_tile")
+    ap.add_argument("--skinny-hook", type=int, default=0, help="measurement hook: value passed to sgl_mi355_skinny_gemm_force_generic "
+                    "(2 = 8-row tiles one tile ahead, the round-3 form; 3 = all tiles of a workgroup up front, the default)")
     ap.add_argument("--kv-split-rule", type=int, default=2, help="0 = the reference's heuristic, 1 = max splits everywhere, 2 = the MI355X balance rule")
     ap.add_argument("--max-kv-splits", type=int, default=16, help="triton_attention_num_kv_splits (16 = the reference's HIP default)")
     ap.add_argument("--all-reduce", default="auto", choices=["auto", "rccl", "p2p"],
@@ -306,6 +308,10 @@ def main():
         from ltp_sglang_amd import _cabi
 
         _cabi.check(_cabi.lib.sgl_mi355_fp8_gemm_force_tile(args.gemm_hook))
+    if args.skinny_hook:
+        from ltp_sglang_amd import _cabi
+
+        _cabi.check(_cabi.lib.sgl_mi355_skinny_gemm_force_generic(args.skinny_hook))
     if args.decode_attn_mode >= 0:
         from ltp_sglang_amd import _cabi
 
@@ -334,7 +340,9 @@ def main():
     # ---- prefill: fills the KV pool (random token ids as bench_one_batch.py:215) and measures prefill TFLOP/s ----
     import numpy as np
 
-    ids = torch.from_numpy(np.random.RandomState(0).randint(0, 10000, (bs, seq))).to(dev)
+    # (ids below 10 000 as bench_one_batch.py:215 draws them, and below the vocabulary: `--model tiny` has 2 048 rows -- round 4
+    # found its lookups reading 8 MB past the embedding table, garbage that ended in a GPU fault one step later)
+    ids = torch.from_numpy(np.random.RandomState(0).randint(0, min(10000, cfg.vocab_size), (bs, seq))).to(dev)
     # untimed warm-up prefill (one short chunk: loads every prefill kernel's code object, sets the LDS attributes), undone
     runner.extend([ids[i][: min(seq, 512)] for i in range(min(bs, args.prefill_chunk))])
     runner.clear()
@@ -367,7 +375,10 @@ def main():
     ranks_run = 1 if args.emulate_tp > 1 else world
     lin_params = ranks_run * L * ((hq_s * d + 2 * hkv_s * d) * hid + hq_s * d * hid + 3 * (inter // tp) * hid)
     prefill_flops = (2.0 * lin_params * bs * seq + ranks_run * (L * bs * (4.0 * seq * seq * hq_s * d) / 2 + 2.0 * (V // tp) * hid * bs))
-    next_ids = K_argmax(torch.cat(last_logits))
+    first_logits = torch.cat(last_logits)
+    if not bool(torch.isfinite(first_logits.float()).all()):   # outside the timed regions; a throughput over NaNs is not a measurement
+        raise SystemExit(f"[bench] rank {rank}: the prefill produced non-finite logits")
+    next_ids = K_argmax(first_logits)
 
     # ---- decode: W warm-up + K timed steps ----
     use_graph = not args.no_graph
@@ -411,6 +422,8 @@ def main():
         next_ids = K_argmax(step_fn(state, next_ids))
     barrier()
     elapsed = time.perf_counter() - t0
+    if not (int(next_ids.min()) >= 0 and int(next_ids.max()) < cfg.vocab_size):
+        raise SystemExit(f"[bench] rank {rank}: the last decode step sampled token ids outside the vocabulary (non-finite logits?)")
     if world > 1 and comm._CUSTOM_AR is not None:
         comm._CUSTOM_AR.check_error()   # a peer that missed a spin bound leaves sums unreduced: fail instead of reporting a time
     try:

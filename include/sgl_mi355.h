@@ -270,8 +270,9 @@ int sgl_mi355_silu_and_mul(void* out, const void* x, int64_t tokens, int d, int 
 int sgl_mi355_rotary_embedding(const int64_t* positions, void* query, void* key, const float* cos_sin_cache,
                                int64_t tokens, int num_q_heads, int num_k_heads, int head_size, int rot_dim,
                                int64_t q_stride, int64_t k_stride, int is_neox, int dtype, void* stream);
-/* VocabParallelEmbedding forward (F.embedding), layers/vocab_parallel_embedding.py */
-int sgl_mi355_embedding(void* out, const int64_t* ids, const void* table, int64_t tokens, int hidden, int dtype,
+/* VocabParallelEmbedding forward (F.embedding), layers/vocab_parallel_embedding.py; vocab = rows of the table: an id outside
+ * [0, vocab) yields a row of NaNs (F.embedding asserts on the device) -- never an out-of-range read */
+int sgl_mi355_embedding(void* out, const int64_t* ids, const void* table, int64_t tokens, int hidden, int64_t vocab, int dtype,
                         void* stream);
 /* greedy sampling: torch.argmax(logits, -1), layers/sampler.py */
 int sgl_mi355_argmax(int64_t* out, const void* logits, int64_t rows, int64_t vocab, int64_t row_stride, int dtype,

@@ -64,6 +64,37 @@ for _name, _res, _args in parse_header():
     SIGNATURES[_name] = (_res, _args)
 
 
+def _install_trace(path: str) -> None:
+    """SGL_MI355_TRACE=<file>: every C-ABI call is written to <file> BEFORE it runs (flushed to disk), the device is waited for
+    after it, and 'ok' is appended -- the last line without 'ok' names the launch a GPU memory fault belongs to (faults are
+    asynchronous: without the per-call wait the process dies at some later, unrelated call).  A debugging aid; never set in a
+    timed run."""
+    import functools
+
+    log = open(path.replace("{rank}", os.environ.get("RANK", "0")), "a", buffering=1)   # "{rank}": one file per rank
+
+    def wrap(name, fn):
+        @functools.wraps(fn)
+        def traced(*args):
+            log.write(f"{name}({', '.join(str(a) for a in args)})")
+            log.flush()
+            os.fsync(log.fileno())
+            rc = fn(*args)
+            if name not in ("sgl_mi355_last_error",) and torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+                torch.cuda.synchronize()
+            log.write(f" -> {rc} ok\n")
+            return rc
+
+        return traced
+
+    for name in SIGNATURES:
+        setattr(lib, name, wrap(name, getattr(lib, name)))
+
+
+if os.environ.get("SGL_MI355_TRACE"):
+    _install_trace(os.environ["SGL_MI355_TRACE"])
+
+
 def last_error() -> str:
     return lib.sgl_mi355_last_error().decode("utf-8", "replace")
 

@@ -178,3 +178,12 @@ __device__ __forceinline__ uint8_t kv_fp8_byte(float v, float scale) {
 }
 
 static inline int cdiv_i(int a, int b) { return (a + b - 1) / b; }
+
+// torch.argmax's order: NaN is the maximum and the FIRST index among equals wins, so a row of NaNs (or of -inf) has a defined
+// answer.  (Round 4: the kernels compared with `v > best` only and returned INT64_MAX for such a row -- the embedding lookup of
+// the next decode step then read ~2^63 rows past its table: a GPU memory fault.)
+__device__ __forceinline__ bool argmax_beats(float v, int64_t i, float best, int64_t bi) {
+  const bool vn = v != v, bn = best != best;
+  if (vn || bn) return vn && (!bn || i < bi);
+  return v > best || (v == best && i < bi);
+}

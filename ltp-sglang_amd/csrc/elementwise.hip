@@ -152,13 +152,19 @@ __global__ __launch_bounds__(256) void rope_kernel(T* q, T* k, const int64_t* po
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void embedding_kernel(T* out, const int64_t* ids, const T* table, int64_t tokens, int hidden) {
+__global__ __launch_bounds__(256) void embedding_kernel(T* out, const int64_t* ids, const T* table, int64_t tokens, int hidden,
+                                                        int64_t vocab) {
   const int nvec = hidden / 8;
   const int64_t total = tokens * nvec;
   for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
     const int64_t t = idx / nvec;
     const int c = (int)(idx - t * nvec);
-    *(u32x4_t*)(out + t * hidden + c * 8) = *(const u32x4_t*)(table + ids[t] * hidden + c * 8);
+    const int64_t id = ids[t];
+    // F.embedding raises a device-side assert for an id outside the table; here such a row comes out as NaNs (0x7FC0 is a NaN
+    // in bf16 and in f16) -- visible downstream, and never an out-of-range read (which is a GPU memory fault)
+    u32x4_t v = u32x4_t{0x7FC07FC0u, 0x7FC07FC0u, 0x7FC07FC0u, 0x7FC07FC0u};
+    if (id >= 0 && id < vocab) v = *(const u32x4_t*)(table + id * hidden + c * 8);
+    *(u32x4_t*)(out + t * hidden + c * 8) = v;
   }
 }
 
@@ -172,19 +178,19 @@ __global__ __launch_bounds__(256) void argmax_kernel(int64_t* out, const T* logi
   int64_t bi = 0x7fffffffffffffffLL;
   for (int64_t i = threadIdx.x; i < vocab; i += 256) {
     const float v = (float)row[i];
-    if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+    if (argmax_beats(v, i, best, bi)) { best = v; bi = i; }
   }
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) {
     const float ov = __shfl_xor(best, m, WAVE);
     const int64_t oi = __shfl_xor(bi, m, WAVE);
-    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    if (argmax_beats(ov, oi, best, bi)) { best = ov; bi = oi; }
   }
   if ((threadIdx.x & 63) == 0) { rv[threadIdx.x >> 6] = best; ri[threadIdx.x >> 6] = bi; }
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int w = 1; w < 4; ++w)
-      if (rv[w] > best || (rv[w] == best && ri[w] < bi)) { best = rv[w]; bi = ri[w]; }
+      if (argmax_beats(rv[w], ri[w], best, bi)) { best = rv[w]; bi = ri[w]; }
     out[blockIdx.x] = bi;
   }
 }
@@ -259,15 +265,16 @@ extern "C" int sgl_mi355_rotary_embedding(const int64_t* positions, void* query,
   return SGL_MI355_OK;
 }
 
-extern "C" int sgl_mi355_embedding(void* out, const int64_t* ids, const void* table, int64_t tokens, int hidden, int dtype,
-                                   void* stream) {
+extern "C" int sgl_mi355_embedding(void* out, const int64_t* ids, const void* table, int64_t tokens, int hidden, int64_t vocab,
+                                   int dtype, void* stream) {
   SGL_CHECK(tokens >= 0 && hidden > 0 && hidden % 8 == 0, "embedding: hidden=%d must be a positive multiple of 8", hidden);
+  SGL_CHECK(vocab > 0, "embedding: vocab=%lld (the table's row count) must be positive", (long long)vocab);
   if (tokens == 0) return SGL_MI355_OK;
   SGL_CHECK(out && ids && table, "embedding: null pointer");
   SGL_CHECK(dtype == SGL_BF16 || dtype == SGL_F16, "embedding: dtype must be bf16 or f16");
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL((embedding_kernel<__bf16>), dim3(grid_for(tokens * (hidden / 8))), dim3(256), 0, st, (__bf16*)out, ids,
-                     (const __bf16*)table, tokens, hidden);  // pure 16-bit copy: one instantiation serves both dtypes
+                     (const __bf16*)table, tokens, hidden, vocab);  // pure 16-bit copy: one instantiation serves both dtypes
   SGL_HIP_LAUNCH_CHECK();
   return SGL_MI355_OK;
 }

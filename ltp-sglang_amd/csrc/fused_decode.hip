@@ -322,26 +322,26 @@ __global__ __launch_bounds__(1024) void argmax_vec_kernel(int64_t* out, const T*
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float v = (float)a[q].v[j];
-          if (v > best) { best = v; bi = i * 8 + j; }  // ascending index within the thread: strict > keeps the first
+          if (argmax_beats(v, i * 8 + j, best, bi)) { best = v; bi = i * 8 + j; }
         }
       }
     }
   }
   for (int64_t i = nvec * 8 + threadIdx.x; i < vocab; i += 1024) {
     const float v = (float)row[i];
-    if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+    if (argmax_beats(v, i, best, bi)) { best = v; bi = i; }
   }
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) {
     const float ov = __shfl_xor(best, m, WAVE);
     const int64_t oi = __shfl_xor(bi, m, WAVE);
-    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    if (argmax_beats(ov, oi, best, bi)) { best = ov; bi = oi; }
   }
   if ((threadIdx.x & 63) == 0) { rv[threadIdx.x >> 6] = best; ri[threadIdx.x >> 6] = bi; }
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int w = 1; w < 16; ++w)
-      if (rv[w] > best || (rv[w] == best && ri[w] < bi)) { best = rv[w]; bi = ri[w]; }
+      if (argmax_beats(rv[w], ri[w], best, bi)) { best = rv[w]; bi = ri[w]; }
     out[blockIdx.x] = bi;
   }
 }

@@ -203,9 +203,15 @@ constexpr int kV2Waves = 8;
 #ifndef SGL_SKINNY_PD
 #define SGL_SKINNY_PD 0
 #endif
+int g_skinny_allin = 1;  // measurement hook (sgl_mi355_skinny_gemm_force_generic(2 / 3)): 0 = the one-tile-ahead form for 8-row tiles too
 constexpr int g_skinny_pd_test = SGL_SKINNY_PD;  // (A/B hook, tools/build_variant.sh: force the prefetch depth of the epilogue-fused launches)
 
-template <int ES, int MT, int DS, int PD, int TPP, typename OutT, int EPI = EPI_NONE, int NWV = kV2Waves>
+// R8 (round 4): an instantiation for 8-row tiles only (rpt == 8).  The general kernel issues DS load instructions per tile
+// whatever the tile height (the upper half re-reads row lr: an L1 hit, but a staging register); with R8 a tile is DS / 2 loads and
+// DS / 2 registers per lane, which lets a workgroup with <= 3 tiles (qkv_proj of Llama-3-8B: 768 tiles of 8 rows over 256
+// workgroups) request ALL of them before the first is consumed (PD = TPP = 3: ONE HBM round trip instead of three dependent
+// 32 KiB ones).  Same k order per wave, same cross-wave sum: the same bits.
+template <int ES, int MT, int DS, int PD, int TPP, typename OutT, int EPI = EPI_NONE, int NWV = kV2Waves, bool R8 = false>
 __global__ __launch_bounds__(NWV * 64, 1) void skinny_gemm_v2_kernel(const SkinnyParams p, int rpt, int ntiles,
                                                                           float* slabs, const EpiParams ep = EpiParams{}) {
   constexpr int kw = DS * 64;             // bytes of K per wave
@@ -232,7 +238,8 @@ __global__ __launch_bounds__(NWV * 64, 1) void skinny_gemm_v2_kernel(const Skinn
 
   const int G = gridDim.x;
   const int cnt = (ntiles - (int)blockIdx.x + G - 1) / G;  // tiles of this workgroup: blockIdx.x + j * G, >= 1
-  const int nload = (rpt == 16) ? DS : DS / 2;             // 8-row tiles load half the instructions
+  constexpr int WN = R8 ? DS / 2 : DS;                     // staging registers (load instructions) per tile
+  const int nload = (R8 || rpt != 16) ? DS / 2 : DS;       // 8-row tiles load half the instructions
   // this thread's output elements of every tile are (m = tid / 16 + e * NWV * 4, n = tid % 16)
   const int em0 = tid >> 4, en = tid & 15;
   const bool has_bias = p.bias != nullptr;
@@ -274,11 +281,11 @@ __global__ __launch_bounds__(NWV * 64, 1) void skinny_gemm_v2_kernel(const Skinn
       }
   };
   load_x(0);
-  u32x4_t wreg[PD][DS];
+  u32x4_t wreg[PD][WN];
   auto issue = [&](int slot, int j) {
     const int n0t = (blockIdx.x + j * G) * rpt;
 #pragma unroll
-    for (int i = 0; i < DS; ++i) {
+    for (int i = 0; i < WN; ++i) {
       const int row = (i < nload) ? lr + RPI * i : lr;  // (8-row tiles: the upper half re-reads row lr, an L1 hit)
       const unsigned off = (j < cnt && kok) ? (unsigned)((int64_t)min(n0t + row, p.N - 1) * p.w_stride) + koff : 0xFFFFFFF0u;
       // cache policy 2 = nt: each weight byte is read by ONE CU, once per decode step (MI355X_MICROARCH.md "nt-weights").
@@ -345,7 +352,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void skinny_gemm_v2_kernel(const Skinn
       const int slot = (TPP == 1) ? 0 : (jj % PD);
       // staged registers -> swizzled image (wave private: same-wave LDS ops are ordered, no barrier needed)
 #pragma unroll
-      for (int i = 0; i < DS; ++i) {
+      for (int i = 0; i < WN; ++i) {
         const int row = lr + RPI * i;
         *(u32x4_t*)(wl + row * kw + (((lc ^ row) & (LPR - 1)) << 4)) = wreg[slot][i];
       }
@@ -513,6 +520,10 @@ int launch_mt(const SkinnyParams& p, float* workspace, int64_t workspace_floats,
 }  // namespace
 
 extern "C" int sgl_mi355_skinny_gemm_force_generic(int on) {
+  if (on == 2 || on == 3) {   // measurement hook: 2 = 8-row tiles one tile ahead (the round-3 form), 3 = all tiles up front (default)
+    g_skinny_allin = on - 2;
+    return SGL_MI355_OK;
+  }
   g_skinny_force_v1 = on != 0;
   return SGL_MI355_OK;
 }
@@ -628,12 +639,23 @@ int launch_v2_epi(const SkinnyParams& p, const EpiParams& ep, int rpt, hipStream
   // qkv_proj need two dependent HBM round trips instead of three, but the deeper queue delays every other load of the CU (X rows,
   // epilogue operands): same-box A/B in the model (round 3) 4.39 ms/step with two sets against 4.26 with one.
   constexpr int PDV = (g_skinny_pd_test > 0 && TPP % (g_skinny_pd_test > 0 ? g_skinny_pd_test : 1) == 0) ? g_skinny_pd_test : 1;
-  if (ntiles <= gx)
+  if (ntiles <= gx) {
     hipLaunchKernelGGL((skinny_gemm_v2_kernel<ES, MT, DS, 1, 1, OutT, EPI>), dim3(gx, 1), dim3(kV2Waves * 64), 0, st, p, rpt,
                        ntiles, (float*)nullptr, ep);
-  else
-    hipLaunchKernelGGL((skinny_gemm_v2_kernel<ES, MT, DS, PDV, TPP, OutT, EPI>), dim3(gx, 1), dim3(kV2Waves * 64), 0, st,
-                       p, rpt, ntiles, (float*)nullptr, ep);
+    SGL_HIP_LAUNCH_CHECK();
+    return SGL_MI355_OK;
+  }
+  if constexpr (DS >= 4 && DS <= 8 && MT <= 2) {
+    if (rpt == 8 && ntiles <= 3 * gx && g_skinny_allin) {
+      // two or three 8-row tiles per workgroup: every tile requested up front (see R8 above)
+      hipLaunchKernelGGL((skinny_gemm_v2_kernel<ES, MT, DS, 3, 3, OutT, EPI, kV2Waves, true>), dim3(gx, 1), dim3(kV2Waves * 64), 0, st,
+                         p, rpt, ntiles, (float*)nullptr, ep);
+      SGL_HIP_LAUNCH_CHECK();
+      return SGL_MI355_OK;
+    }
+  }
+  hipLaunchKernelGGL((skinny_gemm_v2_kernel<ES, MT, DS, PDV, TPP, OutT, EPI>), dim3(gx, 1), dim3(kV2Waves * 64), 0, st,
+                     p, rpt, ntiles, (float*)nullptr, ep);
   SGL_HIP_LAUNCH_CHECK();
   return SGL_MI355_OK;
 }

@@ -54,8 +54,8 @@ def apply_rope_with_cos_sin_cache_inplace(positions: torch.Tensor, query: torch.
 def embedding(ids: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
     assert ids.dtype == torch.int64 and table.is_contiguous()
     out = torch.empty((ids.numel(), table.shape[1]), dtype=table.dtype, device=table.device)
-    check(lib.sgl_mi355_embedding(ptr(out), ptr(ids), ptr(table), ids.numel(), table.shape[1], dtype_code(table.dtype),
-                                  current_stream()))
+    check(lib.sgl_mi355_embedding(ptr(out), ptr(ids), ptr(table), ids.numel(), table.shape[1], table.shape[0],
+                                  dtype_code(table.dtype), current_stream()))
     return out
 
 

@@ -265,6 +265,39 @@ def test_embedding_and_argmax(sk):
     assert torch.equal(sk.argmax(logits.float().to(DEV)).cpu(), torch.argmax(logits.float(), dim=-1))
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("vocab", [2048, 1000, 128256, 9])
+def test_argmax_degenerate_rows_follow_torch(vocab, dtype, sk):
+    """torch.argmax's order -- NaN is the maximum, the first index among equals wins -- on the rows a plain `v > best` scan gets
+    wrong: all NaN, all -inf, NaN somewhere, +inf ties.  (Round 4: such a row returned INT64_MAX and the next step's embedding
+    lookup faulted the GPU.)  Both kernels: the vectorised one (16-bit, aligned rows) and the scalar one (f32 / ragged rows)."""
+    g = torch.Generator().manual_seed(vocab)
+    rows = torch.randn(8, vocab, generator=g)
+    rows[0] = float("nan")
+    rows[1] = float("-inf")
+    rows[2, vocab // 2] = float("nan")
+    rows[3, vocab - 1] = float("nan"); rows[3, 3] = float("inf")
+    rows[4, 5] = rows[4, vocab - 2] = float("inf")
+    rows[5, : vocab - 1] = float("-inf")
+    rows[6, 1:] = float("nan")
+    rows = rows.to(dtype)
+    want = torch.argmax(rows.float(), dim=-1)
+    got = sk.argmax(rows.to(DEV)).cpu()
+    assert torch.equal(got, want), (got.tolist(), want.tolist())
+    assert int(got.max()) < vocab and int(got.min()) >= 0
+
+
+def test_embedding_out_of_range_id_gives_nan_row_not_a_fault(sk):
+    g = torch.Generator().manual_seed(5)
+    table = torch.randn(512, 128, generator=g).bfloat16()
+    ids = torch.tensor([3, 511, 512, -1, 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64)
+    out = sk.embedding(ids.to(DEV), table.to(DEV)).cpu()
+    assert torch.equal(out[[0, 1, 5]], table[[3, 511, 0]])
+    assert torch.isnan(out[[2, 3, 4]].float()).all()
+    out16 = sk.embedding(ids.to(DEV), table.half().to(DEV)).cpu()
+    assert torch.equal(out16[[0, 1, 5]], table.half()[[3, 511, 0]]) and torch.isnan(out16[[2, 3, 4]].float()).all()
+
+
 # ---------------------------------------------------------------- AWQ dequant (bit exact)
 @pytest.mark.parametrize("case", _cases.AWQ_CASES, ids=lambda c: c["name"])
 def test_awq_dequantize_bit_exact_vs_golden(case, sk, golden):
@@ -844,9 +877,12 @@ def test_fp8_gemm_silu_mul_prefill_form_bit_exact(m, n, k, sk):
 
 
 @pytest.mark.parametrize("tile_rows", [16, 8])
-@pytest.mark.parametrize("m,hq,hkv,bias", [(32, 8, 2, False), (5, 4, 4, True), (17, 28, 4, True), (48, 32, 8, False)])
+@pytest.mark.parametrize("m,hq,hkv,bias", [(32, 8, 2, False), (5, 4, 4, True), (17, 28, 4, True), (48, 32, 8, False), (32, 32, 8, False),
+                                           (9, 20, 4, True)])
 def test_fp8_qkv_rope_set_kv_bit_exact(m, hq, hkv, bias, tile_rows, sk):
-    """qkv GEMM with the RoPE + KV-write epilogue == fp8_scaled_mm -> rope -> set_kv_buffer (K = 3584 covers the K tail)."""
+    """qkv GEMM with the RoPE + KV-write epilogue == fp8_scaled_mm -> rope -> set_kv_buffer (K = 3584 covers the K tail).
+    (32, 32, 8) and (17, 28, 4) / (9, 20, 4) at 8-row tiles are two or three tiles per workgroup on 256 CUs: the round-4 form that
+    requests every tile of a workgroup up front (skinny_gemm_v2_kernel<..., R8>)."""
     d, k = 128, 3584
     n = (hq + 2 * hkv) * d
     c = _cases.build_gemm_case(dict(m=m, n=n, k=k, bias=bias, out="bf16"), seed=m)
@@ -869,6 +905,16 @@ def test_fp8_qkv_rope_set_kv_bit_exact(m, hq, hkv, bias, tile_rows, sk):
     q2 = sk.fp8_qkv_rope_set_kv(a, sa, wi, il(sb), None if bvec is None else il(bvec), positions, cache, loc, kb2, vb2, hq, hkv, d,
                                 torch.bfloat16, tile_rows)
     assert torch.equal(q2, q.contiguous()) and torch.equal(kb1, kb2) and torch.equal(vb1, vb2)
+    if tile_rows == 8:   # the one-tile-ahead form of round 3 (measurement hook) gives the same bits
+        from ltp_sglang_amd import _cabi
+        try:
+            _cabi.check(_cabi.lib.sgl_mi355_skinny_gemm_force_generic(2))
+            kb3, vb3 = torch.zeros_like(kb1), torch.zeros_like(kb1)
+            q3 = sk.fp8_qkv_rope_set_kv(a, sa, wi, il(sb), None if bvec is None else il(bvec), positions, cache, loc, kb3, vb3, hq, hkv,
+                                        d, torch.bfloat16, tile_rows)
+        finally:
+            _cabi.check(_cabi.lib.sgl_mi355_skinny_gemm_force_generic(3))
+        assert torch.equal(q3, q2) and torch.equal(kb3, kb2) and torch.equal(vb3, vb2)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
