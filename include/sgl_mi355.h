@@ -394,6 +394,10 @@ int sgl_mi355_awq_unpack_nk(const void* qpacked, const void* sz, void* out, int 
 /* split-K ranges of sgl_mi355_awq_gemm (f32 [M, N] slabs of workspace it wants; 1: none): 4096 k per range for M <= 32, 2048 k
  * for 33..64 rows */
 int sgl_mi355_awq_gemm_num_kranges(int M, int K);
+/* Parity switch (process-wide): 1 = the int4 GEMM multiplies by awq_dequantize's weights rounded to the scale dtype for bf16 too,
+ * bit-compatible with the reference's awq_dequantize -> torch.matmul (awq.py:401-418); 0 (default) = bf16 operands with one scale
+ * group per 128-k block use the exact (q - z) * s (faster, closer to exact arithmetic, not bit-identical to dequantise + matmul). */
+int sgl_mi355_awq_set_exact_weights(int on);
 int sgl_mi355_awq_gemm(const void* x, int64_t x_stride_elems, const void* qpacked, const void* sz, void* y,
                        int64_t y_stride_elems, const void* bias, int M, int N, int K, int group_size, int dtype,
                        float* workspace, int64_t workspace_floats, void* stream);

@@ -207,7 +207,10 @@ constexpr int awq_bpw(int mt) { return mt >= 4 ? 2 : 4; }
 
 // SG = scale groups per 128-k block (1: G % 128 == 0, 2: G = 64, 4: G = 32); EPI: gemm_epilogue.h (single k-range, columns
 // interleaved at repack time so that the two values an output needs are 8 columns apart in one 16-column tile)
-template <typename T, int MT, int PD, int TPP, int SG, int EPI = EPI_NONE>
+// EXACTW (round 4, a RUN-TIME choice: sgl_mi355_awq_set_exact_weights / SGL_MI355_AWQ_EXACT_WEIGHTS=1): the per-weight form for
+// bf16 too -- the weights awq_dequantize produces, rounded to bf16, i.e. bit-compatible with the reference's
+// awq_dequantize -> matmul (awq.py:401-418) for parity runs; the default offset form multiplies by the exact (q - z) s.
+template <typename T, int MT, int PD, int TPP, int SG, int EPI = EPI_NONE, bool EXACTW = false>
 __global__ __launch_bounds__(kAwqWaves * 64, 1) void awq_gemm_kernel(const AwqGemmParams p, int ntiles, float* slabs,
                                                                      const EpiParams ep = EpiParams{}) {
   typedef ElemTraits<T> Tr;
@@ -263,7 +266,7 @@ __global__ __launch_bounds__(kAwqWaves * 64, 1) void awq_gemm_kernel(const AwqGe
   // bf16 only: with f16 operands the per-weight form is 2 PACKED f16 ops per two weights and the offset form measured 5 % slower
   // in the model (Qwen2-7B AWQ f16, same box: 3.03 vs 3.19 ms/step, with the correction applied one block late as well as in
   // place); with bf16 operands (no packed bf16 arithmetic: cvt_ubyte + fma in f32 + cvt_pk) it is 7 % faster (3.16 vs 3.40).
-  constexpr bool OFFS = (SG == 1) && (SGL_AWQ_EXACT_WEIGHTS == 0) && (sizeof(T) == 2 && !__is_same(T, _Float16));
+  constexpr bool OFFS = (SG == 1) && !EXACTW && (SGL_AWQ_EXACT_WEIGHTS == 0) && (sizeof(T) == 2 && !__is_same(T, _Float16));
   AwqRaw<T> raw;
   raw.init();
   // (kept in LDS, 512 bytes per wave, read back as one broadcast ds_read_b128 per block: in registers they were 32 VGPRs too
@@ -476,6 +479,8 @@ __global__ __launch_bounds__(256) void awq_repack_sz_kernel(const uint32_t* __re
   }
 }
 
+int g_awq_exact_weights = 0;   // sgl_mi355_awq_set_exact_weights
+
 inline int awq_cus() {
   static int cus = 0;
   if (cus == 0) {
@@ -493,6 +498,16 @@ int awq_launch(const AwqGemmParams& p, int kranges, float* slabs, hipStream_t st
   const int ntiles = p.N / 16;
   const int gx = ntiles < per_range ? ntiles : per_range;
   const dim3 grid(gx, kranges);
+  if constexpr (SG == 1 && !__is_same(T, _Float16) && SGL_AWQ_EXACT_WEIGHTS == 0) {   // the only instantiations the two forms differ in
+    if (g_awq_exact_weights) {
+      if (ntiles <= gx)
+        hipLaunchKernelGGL((awq_gemm_kernel<T, MT, 1, 1, SG, EPI, true>), grid, dim3(kAwqWaves * 64), 0, st, p, ntiles, slabs, ep);
+      else
+        hipLaunchKernelGGL((awq_gemm_kernel<T, MT, 2, (MT >= 4 ? 2 : 4), SG, EPI, true>), grid, dim3(kAwqWaves * 64), 0, st, p, ntiles, slabs, ep);
+      SGL_HIP_LAUNCH_CHECK();
+      return SGL_MI355_OK;
+    }
+  }
   if (ntiles <= gx)
     hipLaunchKernelGGL((awq_gemm_kernel<T, MT, 1, 1, SG, EPI>), grid, dim3(kAwqWaves * 64), 0, st, p, ntiles, slabs, ep);
   else
@@ -622,6 +637,15 @@ extern "C" int sgl_mi355_awq_repack(const void* qweight, const void* scales, con
 }
 
 // f32 [M, N] slabs of workspace sgl_mi355_awq_gemm wants (1: none)
+// 1: sgl_mi355_awq_gemm (and its fused forms) multiply by awq_dequantize's weights ROUNDED to the scale dtype for bf16 as well --
+// bit-compatible with the reference's awq_dequantize -> matmul (awq.py:401-418), for parity runs; 0 (default): the offset form
+// for bf16 operands with one scale group per 128-k block, which multiplies by the exact (q - z) * s (7 % faster, closer to exact
+// arithmetic, not bit-identical to dequantise + matmul).  f16 always uses the rounded weights.  Process-wide; not a per-call flag.
+extern "C" int sgl_mi355_awq_set_exact_weights(int on) {
+  g_awq_exact_weights = on ? 1 : 0;
+  return SGL_MI355_OK;
+}
+
 extern "C" int sgl_mi355_awq_gemm_num_kranges(int M, int K) {
   const int blocks = kAwqWaves * awq_bpw(M > 32 ? 4 : 2);  // 128-k blocks per k-range: 4096 k for M <= 32, 2048 k for 33..64
   return (K / 128 + blocks - 1) / blocks;

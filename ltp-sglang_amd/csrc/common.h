@@ -65,6 +65,9 @@ struct ElemTraits<__bf16> {
   static __device__ __forceinline__ f32x4_t mfma16(vec8 a, vec8 b, f32x4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
   }
+  static __device__ __forceinline__ f32x16_t mfma32(vec8 a, vec8 b, f32x16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
   static __device__ __forceinline__ float to_f32(__bf16 x) { return (float)x; }
   static __device__ __forceinline__ __bf16 from_f32(float x) { return (__bf16)x; }
 };
@@ -75,6 +78,9 @@ struct ElemTraits<_Float16> {
   typedef f16x4_t vec4;
   static __device__ __forceinline__ f32x4_t mfma16(vec8 a, vec8 b, f32x4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f32x16_t mfma32(vec8 a, vec8 b, f32x16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
   }
   static __device__ __forceinline__ float to_f32(_Float16 x) { return (float)x; }
   static __device__ __forceinline__ _Float16 from_f32(float x) { return (_Float16)x; }

@@ -44,8 +44,8 @@ enum { ES_FP8 = 0, ES_BF16 = 1, ES_F16 = 2 };
 #ifdef SGL_SKINNY_TIMELINE
 #define SK_STAMP(i)                                                                  \
   do {                                                                               \
-    const long long t_ = (long long)__builtin_amdgcn_s_memtime();                    \
-    if (lane == 0) p.tl[((int64_t)blockIdx.x * 8 + w) * 8 + (i)] = t_;               \
+    const long long t_ = (long long)__builtin_amdgcn_s_memrealtime();  /* 100 MHz */ \
+    if (lane == 0) p.tl[(((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + w) * 8 + (i)] = t_; \
   } while (0)
 #else
 #define SK_STAMP(i)
@@ -357,6 +357,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void skinny_gemm_v2_kernel(const Skinn
         *(u32x4_t*)(wl + row * kw + (((lc ^ row) & (LPR - 1)) << 4)) = wreg[slot][i];
       }
       if constexpr (TPP > 1) issue(slot, j + PD);
+      if (j == 0) { SK_STAMP(5); }  // first weight tile landed and staged
       f32x4_t acc[MT];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -472,10 +473,23 @@ int launch_v2(const SkinnyParams& p, int kranges, float* slabs, hipStream_t st) 
   const dim3 grid(gx, kranges);
   constexpr int PD = 1;
   constexpr int TPP = (DS >= 16 || MT >= 4) ? 2 : 4;  // (LDS: the cross-wave reduce buffer grows with MT)
-  if (ntiles <= gx)
+  if (ntiles <= gx) {
     hipLaunchKernelGGL((skinny_gemm_v2_kernel<ES, MT, DS, 1, 1, OutT>), grid, dim3(kV2Waves * 64), 0, st, p, rpt, ntiles, slabs);
-  else
-    hipLaunchKernelGGL((skinny_gemm_v2_kernel<ES, MT, DS, PD, TPP, OutT>), grid, dim3(kV2Waves * 64), 0, st, p, rpt, ntiles, slabs);
+    SGL_HIP_LAUNCH_CHECK();
+    return SGL_MI355_OK;
+  }
+  if constexpr (ES == ES_FP8 && DS >= 4 && DS <= 8 && MT <= 2) {
+    if (use8 && ntiles <= 3 * gx && g_skinny_allin) {
+      // two or three 8-row tiles per workgroup: all of them requested up front (the R8 instantiation, round 4) -- e.g. the plain
+      // qkv_proj shapes of the reference's table at M <= 32 (N 6144 / 4608: 768 / 576 tiles over 256 workgroups: 10.0 -> 9.2 us,
+      // 9.0 -> 7.8 us).  Not at 33..64 rows (MT = 4: 252 registers and all 160 KiB of LDS -- 6144 x 4096 a tie, 1280 x 8192 16 % slower)
+      hipLaunchKernelGGL((skinny_gemm_v2_kernel<ES, MT, DS, 3, 3, OutT, EPI_NONE, kV2Waves, true>), grid, dim3(kV2Waves * 64), 0, st, p,
+                         rpt, ntiles, slabs);
+      SGL_HIP_LAUNCH_CHECK();
+      return SGL_MI355_OK;
+    }
+  }
+  hipLaunchKernelGGL((skinny_gemm_v2_kernel<ES, MT, DS, PD, TPP, OutT>), grid, dim3(kV2Waves * 64), 0, st, p, rpt, ntiles, slabs);
   SGL_HIP_LAUNCH_CHECK();
   return SGL_MI355_OK;
 }

@@ -43,6 +43,7 @@ from .gemm import (
     awq_gemm,
     awq_gemm_num_kranges,
     awq_repack,
+    awq_set_exact_weights,
     awq_unpack_nk,
     dense_linear,
     dense_linear_kranges,

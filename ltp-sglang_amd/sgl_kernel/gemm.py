@@ -2,6 +2,8 @@
 (sgl-kernel/python/sgl_kernel/gemm.py:7-10,34-42,100-146)."""
 from typing import Optional, Tuple
 
+import os
+
 import torch
 
 from .._cabi import check, current_stream, dtype_code, lib, ptr
@@ -109,6 +111,17 @@ def awq_gemm(x: torch.Tensor, qpacked: torch.Tensor, sz: torch.Tensor, group_siz
     check(lib.sgl_mi355_awq_gemm(ptr(x), x.stride(0), ptr(qpacked), ptr(sz), ptr(out), out.stride(0), ptr(bias), m, n, k,
                                  int(group_size), dtype_code(x.dtype), ptr(ws), ws_n, current_stream()))
     return out
+
+
+def awq_set_exact_weights(on: bool) -> None:
+    """True: awq_gemm (and the fused int4 forms) multiply by awq_dequantize's rounded weights for bf16 as well -- bit-compatible
+    with the reference's dequantise + matmul, for parity runs (also: SGL_MI355_AWQ_EXACT_WEIGHTS=1 at import).  False (default):
+    the offset form for bf16 (exact (q - z) s)."""
+    check(lib.sgl_mi355_awq_set_exact_weights(1 if on else 0))
+
+
+if os.environ.get("SGL_MI355_AWQ_EXACT_WEIGHTS", "0") == "1":
+    awq_set_exact_weights(True)
 
 
 def awq_gemm_num_kranges(m: int, k: int) -> int:

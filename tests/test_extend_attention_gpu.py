@@ -123,6 +123,32 @@ def test_extend_lds_dma_kernel_equals_register_staged_kernel(dtype, hq, hkv, pre
         _cabi.lib.sgl_mi355_extend_attention_set_kv_hint(0)
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("hq,hkv,pre,ext", [(32, 8, [0, 0], [300, 77]), (8, 2, [130, 64, 0], [45, 200, 513]), (12, 12, [5], [260]),
+                                            (16, 2, [70, 0], [129, 33]), (4, 2, [257, 31], [64, 1]), (8, 2, [1700], [300]),
+                                            (8, 1, [0, 3, 64], [1, 65, 256]), (2, 2, [0], [1000])])
+def test_extend_64_rows_per_wave_kernel_vs_oracle(dtype, hq, hkv, pre, ext, pkg):
+    """extend_attn_w64_kernel (round 4: 256-row workgroups, 64 rows per wave on 32x32x16 MFMAs, one wave per SIMD; head groups
+    1 / 2 / 4 / 8) against the float64 oracle at the attention tolerance, causal and not, over prefix + extend phases, ragged tiles and
+    blocks, one-token requests; and against the 16x16x32 kernels (another summation order inside the MFMAs: a tolerance of a few
+    output ulps, not bit-identity)."""
+    from ltp_sglang_amd import _cabi
+    case = dict(name="w64", kind="extend", dtype=dtype, hq=hq, hkv=hkv, d=128, pre=pre, ext=ext)
+    c = _cases.build_attn_case(case, seed=hq + len(pre))
+    for causal in (True, False):
+        try:
+            _cabi.check(_cabi.lib.sgl_mi355_extend_attention_set_mode(4))
+            new = _run(pkg, c, causal=causal)
+            _cabi.check(_cabi.lib.sgl_mi355_extend_attention_set_mode(3))
+            old = _run(pkg, c, causal=causal)
+        finally:
+            _cabi.lib.sgl_mi355_extend_attention_set_mode(1)
+        ref = _f64(c, causal=causal)
+        assert torch.isfinite(new.float()).all()
+        assert (new.double() - ref).abs().max().item() <= TOL_F64[c["dtype"]], (new.double() - ref).abs().max().item()
+        assert (new.double() - old.double()).abs().max().item() <= TOL_F64[c["dtype"]]
+
+
 def test_extend_long_sequence_properties(pkg):
     """seq 2048 without prefix at Llama-3-8B heads (BASELINE shape per request): compare 2 requests fully against
     the f64 oracle and check the causal first-row property o[0] == v[0]."""

@@ -367,6 +367,34 @@ def test_awq_gemm_vs_oracle(m, k, n, g, dtype, bias, sk):
     assert err <= tol, (err, tol)
 
 
+@pytest.mark.parametrize("m,k,n", [(32, 3584, 512), (8, 1024, 4608), (48, 2048, 256)])
+def test_awq_gemm_exact_weights_switch_bf16(m, k, n, sk):
+    """bf16 operands, one scale group per 128-k block.  Default: the offset form, whose weights are the EXACT (q - z) s; with
+    sgl_kernel.awq_set_exact_weights(True) (a run-time parity switch) the per-weight form, whose weights are
+    awq_dequantize's values ROUNDED to bf16 -- the reference's awq_dequantize -> matmul operands (awq.py:401-418).  Each result is
+    compared, in float64, with the product over ITS weights at an f32-accumulation tolerance far below the difference between the
+    two weight sets, so the test tells the forms apart."""
+    g = 128
+    qw, qz, sc = _awq_case(k, n, g, torch.bfloat16, seed=m + n)
+    x = torch.randn(m, k, generator=torch.Generator().manual_seed(m)).to(torch.bfloat16)
+    qp, sz = sk.awq_repack(qw.to(DEV), sc.to(DEV), qz.to(DEV))
+    w_rounded = oq.awq_dequantize(qw, sc, qz, g).double()                                  # [K, N], rounded to bf16
+    w_exact = (oq._awq_unpack(qw).double() - oq._awq_unpack(qz).double().repeat_interleave(g, 0)) * sc.double().repeat_interleave(g, 0)
+    assert (w_exact.to(torch.bfloat16).double() - w_rounded).abs().max().item() == 0.0     # same weights before / after the rounding
+    try:
+        sk.awq_set_exact_weights(True)
+        y_rounded = sk.awq_gemm(x.to(DEV), qp, sz, g).cpu().double()
+    finally:
+        sk.awq_set_exact_weights(False)
+    y_offset = sk.awq_gemm(x.to(DEV), qp, sz, g).cpu().double()
+    ref_r, ref_e = x.double() @ w_rounded, x.double() @ w_exact
+    out_ulp = 2.0 ** -8 * max(1.0, ref_e.abs().max().item())                               # one bf16 rounding of the output
+    gap = (ref_r - ref_e).abs().max().item()
+    assert (y_rounded - ref_r).abs().max().item() <= out_ulp + 1e-3 * ref_r.abs().max().item()
+    assert (y_offset - ref_e).abs().max().item() <= out_ulp + 1e-3 * ref_e.abs().max().item()
+    assert not torch.equal(y_rounded, y_offset) or gap == 0.0
+
+
 @pytest.mark.parametrize("m,k", [(20, 768), (64, 768), (50, 4608)])
 def test_awq_gemm_exact_small_integers(m, k, sk):
     # power-of-two scales and small-integer activations: every product and partial sum is exact, so the fused kernel
@@ -486,6 +514,28 @@ def test_fp8_scaled_mm_m33_to_64_weight_streaming_kernel(m, n, k, out, bias, sk)
     o = sk.fp8_scaled_mm(c["a"].to(DEV), c["w"].to(DEV).t(), c["sa"].to(DEV), c["sb"].to(DEV), c["out_dtype"], b)
     ref = oq.scaled_mm(c["a"], c["w"].t(), c["sa"], c["sb"], c["out_dtype"], c["bias"] if bias else None)
     torch.testing.assert_close(o.cpu().float(), ref.float(), rtol=1.6e-2, atol=0.3)
+
+
+@pytest.mark.parametrize("m,n,k,bias", [(16, 6144, 4096, False), (32, 6144, 4096, True), (64, 6144, 4096, False), (32, 4608, 3584, True),
+                                        (7, 5000, 2048, False), (64, 4608, 3584, False)])
+def test_fp8_scaled_mm_eight_row_tiles_all_up_front(m, n, k, bias, sk):
+    """Shapes whose 16-row tiles would leave the last round of workgroups mostly idle run on 8-row tiles, two or three per workgroup
+    on 256 CUs; round 4 requests all of them before the first is consumed at M <= 32 (skinny_gemm_v2_kernel<..., R8>; M = 64 keeps the
+    one-tile-ahead form and is here as the control).  Same bits as the
+    one-tile-ahead form (measurement hook 2), and both within the GEMM tolerance of the oracle."""
+    from ltp_sglang_amd import _cabi
+    c = _cases.build_gemm_case(dict(m=m, n=n, k=k, bias=bias, out="bf16"), seed=m + n)
+    a, wt, sa, sb = (c[x].to(DEV) for x in ("a", "w", "sa", "sb"))
+    b = c["bias"].to(DEV) if bias else None
+    new = sk.fp8_scaled_mm(a, wt.t(), sa, sb, torch.bfloat16, b)
+    try:
+        _cabi.check(_cabi.lib.sgl_mi355_skinny_gemm_force_generic(2))
+        old = sk.fp8_scaled_mm(a, wt.t(), sa, sb, torch.bfloat16, b)
+    finally:
+        _cabi.check(_cabi.lib.sgl_mi355_skinny_gemm_force_generic(3))
+    assert torch.equal(new, old)
+    ref = oq.scaled_mm(c["a"], c["w"].t(), c["sa"], c["sb"], torch.bfloat16, c["bias"] if bias else None)
+    torch.testing.assert_close(new.cpu().float(), ref.float(), rtol=1.6e-2, atol=0.3)
 
 
 # ---------------------------------------------------------------- tiled GEMM at prefill-sized M

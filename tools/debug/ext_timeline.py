@@ -31,6 +31,8 @@ torch.cuda.synchronize()
 fn(ctypes.c_void_p(0))
 tl = buf.cpu().view(8, 24, 6)
 names = ["idx + DMA issue", "K reads + QK^T", "mask + softmax + rescale", "V reads + PV", "wait DMA + barrier"]
+if mode == 4:   # the 64-rows-per-wave kernel's stamps (round 4)
+    names = ["DMA issue", "QK(q0) + max + rescale?", "QK(q1) || exp(q0) + max + rescale?", "PV(q0) || exp(q1), PV(q1)", "wait DMA + barrier"]
 for w in range(4 if mode != 2 else 8):
     x = tl[w]
     if int(x[4, 0]) == 0:

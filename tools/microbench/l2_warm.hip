@@ -50,6 +50,16 @@ __global__ __launch_bounds__(256) void row_k(const u32x4* __restrict__ x, uint32
     return;
   }
   if (map == 0) return;
+  if (map >= 3) {
+    // TLB warm-up only (map = 3 + log2(stride / 4 KiB)): the first eight spare workgroups -- one per XCD class -- touch ONE 16-byte
+    // word every `stride` bytes of the WHOLE next weight (pf_tiles * kTile bytes): translations for the consuming XCD, almost no data
+    if (b >= kRowWgs + 8) return;
+    const size_t stride = (size_t)4096 << (map - 3), total = (size_t)pf_tiles * kTile;
+    u32x4 acc = {0, 0, 0, 0};
+    for (size_t off = (size_t)tid * stride; off < total; off += 256 * stride) acc ^= *(const u32x4*)(next_w + off);
+    if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x9E3779B9u) out[1u << 20] = 1;
+    return;
+  }
   // prefetch workgroup: class = blockIdx % 8 (+ 4 when shifted); tiles t of that class with t < pf_tiles, dealt round-robin over the
   // (gridDim - 32) / 8 workgroups of the class
   const int per_class = (gridDim.x - kRowWgs) / 8;
@@ -108,11 +118,13 @@ int main() {
     for (auto& p : w) { hipMalloc(&p, bytes); hipMemset(p, 1, bytes); }
     struct V { const char* name; int grid; int map; int pf_mb; };
     std::vector<V> vs = {{"base: row grid 32            ", 32, 0, 0}, {"idle: row grid 256, no loads ", 256, 0, 0}};
-    for (int pf : {4, 8, 16, 24}) if ((size_t)pf <= mb) vs.push_back({"prefetch same XCD class      ", 256, 1, pf});
-    vs.push_back({"prefetch whole weight, same  ", 256, 1, (int)mb});
+    for (int pf : {4, 8}) if ((size_t)pf <= mb) vs.push_back({"prefetch same XCD class      ", 256, 1, pf});
     vs.push_back({"prefetch XCD class + 4       ", 256, 2, 8});
-    vs.push_back({"prefetch XCD class + 4       ", 256, 2, 16 <= (int)mb ? 16 : (int)mb});
-    for (int nt = 1; nt >= 0; --nt) {
+    vs.push_back({"TLB touch, stride 4 KiB      ", 256, 3, (int)mb});
+    vs.push_back({"TLB touch, stride 64 KiB     ", 256, 7, (int)mb});
+    vs.push_back({"TLB touch, stride 2 MiB      ", 256, 12, (int)mb});
+    vs.push_back({"base again                   ", 32, 0, 0});
+    for (int nt = 1; nt >= 1; --nt) {
       for (const V& v : vs) {
         const int pf_tiles = (int)(((size_t)v.pf_mb << 20) / kTile) > ntiles ? ntiles : (int)(((size_t)v.pf_mb << 20) / kTile);
         hipGraph_t g; hipGraphExec_t ge;
