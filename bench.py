@@ -56,7 +56,8 @@ def parse_args():
                          "sweep on one box: 4 / 8 / 16 / 32 requests -> 1 915 / 1 950 / 1 958 / 1 978 TFLOP/s)")
     ap.add_argument("--gemm-hook", type=int, default=0, help="measurement hook: value passed to sgl_mi355_fp8_gemm_force_tile")
     ap.add_argument("--skinny-hook", type=int, default=0, help="measurement hook: value passed to sgl_mi355_skinny_gemm_force_generic "
-                    "(2 = 8-row tiles one tile ahead, the round-3 form; 3 = all tiles of a workgroup up front, the default)")
+                    "(2 = 8-row tiles one tile ahead, the round-3 form; 3 = all tiles of a workgroup up front, the default; 4 / 5 = slab-mode "
+                    "launches with one / two tiles in flight per wave)")
     ap.add_argument("--kv-split-rule", type=int, default=2, help="0 = the reference's heuristic, 1 = max splits everywhere, 2 = the MI355X balance rule")
     ap.add_argument("--max-kv-splits", type=int, default=16, help="triton_attention_num_kv_splits (16 = the reference's HIP default)")
     ap.add_argument("--all-reduce", default="auto", choices=["auto", "rccl", "p2p"],

@@ -203,6 +203,7 @@ constexpr int kV2Waves = 8;
 #ifndef SGL_SKINNY_PD
 #define SGL_SKINNY_PD 0
 #endif
+int g_skinny_slab_pd2 = 0;  // measurement hook (force_generic(4 / 5)): 1 = slab-mode launches keep TWO tiles in flight per wave (measured slower)
 int g_skinny_allin = 1;  // measurement hook (sgl_mi355_skinny_gemm_force_generic(2 / 3)): 0 = the one-tile-ahead form for 8-row tiles too
 constexpr int g_skinny_pd_test = SGL_SKINNY_PD;  // (A/B hook, tools/build_variant.sh: force the prefetch depth of the epilogue-fused launches)
 
@@ -489,6 +490,18 @@ int launch_v2(const SkinnyParams& p, int kranges, float* slabs, hipStream_t st) 
       return SGL_MI355_OK;
     }
   }
+  if constexpr (ES == ES_FP8 && DS == 8 && MT <= 2) {
+    // slab mode (raw partial sums for a consumer kernel: down_proj of the decode step, 4 k-ranges x 4 tiles per workgroup) with TWO
+    // tiles in flight per wave: a measurement hook, OFF by default.  No epilogue operands ride in this launch's memory queue, so
+    // the round-3 explanation of why deeper prefetch lost in the epilogue-fused launches does not apply -- and it still lost:
+    // same-box A/B of the headline step (round 4, order 4 5 4 5): 4.180 / 4.165 ms with one tile in flight, 4.199 / 4.180 with two.
+    // The X rows of the same CU share the queue with the deeper weight stream, and the stream is bandwidth-, not latency-bound.
+    if (slabs != nullptr && g_skinny_slab_pd2 && ntiles >= 2 * gx) {
+      hipLaunchKernelGGL((skinny_gemm_v2_kernel<ES, MT, DS, 2, TPP, OutT>), grid, dim3(kV2Waves * 64), 0, st, p, rpt, ntiles, slabs);
+      SGL_HIP_LAUNCH_CHECK();
+      return SGL_MI355_OK;
+    }
+  }
   hipLaunchKernelGGL((skinny_gemm_v2_kernel<ES, MT, DS, PD, TPP, OutT>), grid, dim3(kV2Waves * 64), 0, st, p, rpt, ntiles, slabs);
   SGL_HIP_LAUNCH_CHECK();
   return SGL_MI355_OK;
@@ -536,6 +549,10 @@ int launch_mt(const SkinnyParams& p, float* workspace, int64_t workspace_floats,
 extern "C" int sgl_mi355_skinny_gemm_force_generic(int on) {
   if (on == 2 || on == 3) {   // measurement hook: 2 = 8-row tiles one tile ahead (the round-3 form), 3 = all tiles up front (default)
     g_skinny_allin = on - 2;
+    return SGL_MI355_OK;
+  }
+  if (on == 4 || on == 5) {   // measurement hook: 4 = slab-mode launches one tile ahead (default), 5 = two tiles in flight
+    g_skinny_slab_pd2 = on - 4;
     return SGL_MI355_OK;
   }
   g_skinny_force_v1 = on != 0;

@@ -791,6 +791,25 @@ def test_fused_rmsnorm_from_splitk_slabs_bit_exact(sk, pkg):
     assert torch.equal(r1, r2) and torch.equal(y, y2) and torch.equal(s1, s2) and torch.equal(q1.view(torch.uint8), q2.view(torch.uint8))
 
 
+@pytest.mark.parametrize("m,n,k", [(32, 4096, 14336), (16, 4096, 14336), (32, 2048, 12288), (9, 4104, 14336)])
+def test_slab_mode_two_tiles_in_flight_same_bits(m, n, k, sk):
+    """Slab-mode launches of the weight-streaming kernel (down_proj of the decode step: 4 k-ranges x 4 tiles per workgroup) with two
+    weight tiles in flight per wave (measurement hook 5; measured 0.4 % slower in the step, so one tile ahead stays the default):
+    the same partial sums, element for element."""
+    from ltp_sglang_amd import _cabi
+    c = _cases.build_gemm_case(dict(m=m, n=n, k=k, bias=False, out="bf16"), seed=m + n)
+    a, wt = c["a"].to(DEV), c["w"].to(DEV)
+    old = sk.fp8_linear_slabs(a, wt, m, n, k)
+    try:
+        _cabi.check(_cabi.lib.sgl_mi355_skinny_gemm_force_generic(5))
+        new = sk.fp8_linear_slabs(a, wt, m, n, k)
+    finally:
+        _cabi.check(_cabi.lib.sgl_mi355_skinny_gemm_force_generic(4))
+    assert new.shape[0] > 1 and torch.equal(new, old)
+    ref = c["a"].float() @ c["w"].float().t()
+    torch.testing.assert_close(new.sum(0).cpu(), ref, rtol=2e-3, atol=2e-2 * ref.abs().max().item())
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_silu_and_mul_quant_bit_exact(dtype, sk):
     x = (torch.randn(5, 2 * 14336, generator=torch.Generator().manual_seed(2)) * 2).to(dtype).to(DEV)
