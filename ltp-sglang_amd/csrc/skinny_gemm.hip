@@ -36,6 +36,7 @@ struct SkinnyParams {
   int kbytes;  // K * element size
 #ifdef SGL_SKINNY_TIMELINE
   long long* tl;  // tools/microbench/skinny_timeline.hip: s_memtime stamps [workgroup][wave][8]
+  int x_tiled = 0;  // experiment (decode_gemm_timeline): X laid out [k-slice of a wave][row][bytes of the slice] instead of row-major
 #endif
 };
 
@@ -277,7 +278,13 @@ __global__ __launch_bounds__(NWV * 64, 1) void skinny_gemm_v2_kernel(const Skinn
 #pragma unroll
       for (int i = 0; i < DS; ++i) {
         const int m = (mt0 + q) * 16 + lr + RPI * ((i + xrot) & (DS - 1));
+#ifdef SGL_SKINNY_TIMELINE
+        const char* xsrc = p.x_tiled ? p.x + ((int64_t)(kr * NWV + w) * (MT * 16) + min(m, p.M - 1)) * kw + lc * 16
+                                     : p.x + (int64_t)min(m, p.M - 1) * p.x_stride + (kok ? koff : 0);
+        const u32x4_t v = *(const u32x4_t*)xsrc;
+#else
         const u32x4_t v = *(const u32x4_t*)(p.x + (int64_t)min(m, p.M - 1) * p.x_stride + (kok ? koff : 0));
+#endif
         xr[q][i] = (m < p.M && kok) ? v : zero4;
       }
   };

@@ -14,8 +14,10 @@ __global__ void small_k(float* o) { if (threadIdx.x == 0) o[blockIdx.x] += 1.0f;
 
 int main() {
   const int M = 32, L = 8;
-  struct G { const char* name; int N, K, kind; } gs[] = {{"qkv + RoPE (8-row tiles, all up front)", 6144, 4096, 0}, {"qkv + RoPE (8-row tiles, one ahead)", 6144, 4096, 4},
-                                                          {"o_proj", 4096, 4096, 1}, {"gate_up + SiluAndMul", 28672, 4096, 2}, {"down_proj -> slabs", 4096, 14336, 3}};
+  struct G { const char* name; int N, K, kind, tiled; } gs[] = {{"qkv + RoPE (8-row tiles, all up front)", 6144, 4096, 0, 0}, {"qkv + RoPE (8-row tiles, one ahead)", 6144, 4096, 4, 0},
+                                                          {"o_proj", 4096, 4096, 1, 0}, {"gate_up + SiluAndMul", 28672, 4096, 2, 0}, {"down_proj -> slabs", 4096, 14336, 3, 0},
+                                                          {"o_proj, X tiled per wave slice", 4096, 4096, 1, 1}, {"qkv all up front, X tiled", 6144, 4096, 0, 1},
+                                                          {"gate_up, X tiled", 28672, 4096, 2, 1}, {"down_proj, X tiled", 4096, 14336, 3, 1}, {"o_proj again (row-major)", 4096, 4096, 1, 0}};
   hipStream_t st; hipStreamCreate(&st);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   float* dummy; hipMalloc(&dummy, 4096); hipMemset(dummy, 0, 4096);
@@ -31,7 +33,7 @@ int main() {
     hipMemcpy(pos, hp.data(), M * 8, hipMemcpyHostToDevice); hipMemcpy(loc, hl.data(), M * 8, hipMemcpyHostToDevice);
     SkinnyParams p;
     p.x = x; p.x_stride = K; p.y = y; p.y_stride = g.kind == 2 ? N / 2 : N; p.sx = sx; p.sw = sw; p.bias = nullptr; p.M = M; p.N = N; p.K = K; p.kbytes = K;
-    p.w_stride = K; p.tl = tl;
+    p.w_stride = K; p.tl = tl; p.x_tiled = g.tiled;
     EpiParams ep; ep.positions = pos; ep.cos_sin = cs; ep.loc = loc; ep.k_buf = kb; ep.v_buf = vb; ep.k_slot_stride = 8 * 128; ep.v_slot_stride = 8 * 128; ep.hq = 32; ep.hkv = 8;
     auto launch_one = [&](int l) {
       p.w = w + (size_t)l * N * K;
