@@ -1012,6 +1012,7 @@ __global__ __launch_bounds__(256, 1) void extend_attn_w64_kernel(const ExtendPar
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) kf[kk][ks] = *(const vec8*)(kl + row * ROWB + (((2 * ks + h) ^ (row & 15)) << 4));
       }
+      __builtin_amdgcn_sched_barrier(0);   // (left free, every read is sunk to just before its MFMA and waited for alone: 16 exposed LDS round trips)
 #pragma unroll
       for (int kk = 0; kk < KB; ++kk)
 #pragma unroll
@@ -1029,6 +1030,7 @@ __global__ __launch_bounds__(256, 1) void extend_attn_w64_kernel(const ExtendPar
     // masking + row maximum (in exponent units) of one q block
     auto row_max = [&](int qq, f32x16_t (&sq)[KB]) __attribute__((always_inline)) -> float {
       if (need_mask) {
+        asm volatile("" ::: "memory");   // a real wave-uniform branch: if-converted, the 64 compare + select pairs ran on every tile
         const int lim = min(klimit - 1, causal ? qpos[qq] : 0x7fffffff) - kbase - 4 * h;   // key index relative to 32 kk + crow(r, 0)
 #pragma unroll
         for (int kk = 0; kk < KB; ++kk)
@@ -1078,28 +1080,38 @@ __global__ __launch_bounds__(256, 1) void extend_attn_w64_kernel(const ExtendPar
       l_i[qq] += lsum;
     };
     // O^T += V^T P^T of one q block: d block n (32 d) x 4 k-steps of 16 keys in the accumulator's key order
-    auto pv = [&](int qq, const vec8 (&pq)[4]) __attribute__((always_inline)) {
+    auto vread = [&](int n, vec8 (&vf)[4]) __attribute__((always_inline)) {
 #pragma unroll
-      for (int n = 0; n < DB; ++n) {
-        vec8 vf[4];
-#pragma unroll
-        for (int sI = 0; sI < 4; ++sI) {
-          const int chunk = 2 * n + (gq & 1);
-          s16x4_t t0, t1;
-          {
-            const int row = 16 * sI + 4 * h + (a >> 2);
-            t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (s16x4_t __attribute__((address_space(3)))*)(vl + row * ROWB + ((chunk ^ ((row & 3) << 1)) << 5) + ((a & 3) << 3)));
-          }
-          {
-            const int row = 16 * sI + 8 + 4 * h + (a >> 2);
-            t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (s16x4_t __attribute__((address_space(3)))*)(vl + row * ROWB + ((chunk ^ ((row & 3) << 1)) << 5) + ((a & 3) << 3)));
-          }
-          vf[sI] = __builtin_bit_cast(vec8, __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7));
+      for (int sI = 0; sI < 4; ++sI) {
+        const int chunk = 2 * n + (gq & 1);
+        s16x4_t t0, t1;
+        {
+          const int row = 16 * sI + 4 * h + (a >> 2);
+          t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (s16x4_t __attribute__((address_space(3)))*)(vl + row * ROWB + ((chunk ^ ((row & 3) << 1)) << 5) + ((a & 3) << 3)));
         }
+        {
+          const int row = 16 * sI + 8 + 4 * h + (a >> 2);
+          t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (s16x4_t __attribute__((address_space(3)))*)(vl + row * ROWB + ((chunk ^ ((row & 3) << 1)) << 5) + ((a & 3) << 3)));
+        }
+        vf[sI] = __builtin_bit_cast(vec8, __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7));
+      }
+    };
+    // d block n + 1's fragments are requested before d block n's MFMAs (two register sets), the scheduler held to that order
+    auto pv = [&](int qq, const vec8 (&pq)[4]) __attribute__((always_inline)) {
+      vec8 vfa[4], vfb[4];
+      vread(0, vfa);
 #pragma unroll
-        for (int sI = 0; sI < 4; ++sI) acc[qq][n] = Tr::mfma32(vf[sI], pq[sI], acc[qq][n]);
+      for (int n = 0; n < DB; n += 2) {
+        vread(n + 1, vfb);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int sI = 0; sI < 4; ++sI) acc[qq][n] = Tr::mfma32(vfa[sI], pq[sI], acc[qq][n]);
+        if (n + 2 < DB) vread(n + 2, vfa);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int sI = 0; sI < 4; ++sI) acc[qq][n + 1] = Tr::mfma32(vfb[sI], pq[sI], acc[qq][n + 1]);
       }
     };
 
@@ -1126,11 +1138,6 @@ __global__ __launch_bounds__(256, 1) void extend_attn_w64_kernel(const ExtendPar
     exps(1, s1, pf1);   // beside it: VALU
 #pragma unroll
     for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(pf1[i]));
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
-      __builtin_amdgcn_sched_group_barrier(0x002, 8, 1);
-    }
     pv(1, pf1);
     EXT_STAMP(4);
 
