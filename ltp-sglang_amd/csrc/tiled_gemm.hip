@@ -920,7 +920,19 @@ __global__ __launch_bounds__(512, 1) void fp8_gemm128s_kernel(const GemmParams p
   const int bid = blockIdx.x;
   const int q = nwg / 8, r8 = nwg % 8, xcd = bid % 8;
   const int wgid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + bid / 8;
-  const int tm = wgid / p.tiles_n, tn = wgid - tm * p.tiles_n;
+  // Row tiles FASTEST while they are few (M <= 1024; round 4): the row tiles of one column tile then sit next to each other inside
+  // ONE XCD's contiguous range, so the W tile they all stream is fetched from HBM once and hit in that XCD's L2 by the others.  With
+  // column tiles fastest (rounds 2-3) the two row tiles of M = 256 landed on XCDs x and x + 4 and every weight byte was fetched
+  // twice: profiles/round4_pmc_mid_m_gemm.json, 243.6 MB fetched for the 117.4 MB gate_up matrix -- at 53 us that fetch WAS the
+  // time.  X (M x K <= 4 MiB here) is small enough to be shared by every XCD.  Same arithmetic per tile: the same bits.
+  int tm, tn;
+  if (p.tiles_m <= 8) {
+    tn = wgid / p.tiles_m;
+    tm = wgid - tn * p.tiles_m;
+  } else {
+    tm = wgid / p.tiles_n;
+    tn = wgid - tm * p.tiles_n;
+  }
   const int m0 = tm * S_BM, n0 = tn * S_BN;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
