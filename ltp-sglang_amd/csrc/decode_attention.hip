@@ -69,7 +69,22 @@ struct DecodeParams {
   //                prefix partials is its initial (m, l, acc) -- the math of merge_state, merge_attn_states.cu, applied before
   //                instead of after), so the in-launch merge sees suffix slots only.
   int prefix_len, prefix_splits;
+#ifdef SGL_DEC_TIMELINE
+  long long* tl;   // tools/debug/dec_timeline.py: s_memrealtime stamps [workgroup (linear)][wave][8]
+#endif
 };
+
+#ifdef SGL_DEC_TIMELINE
+long long* g_dec_tl = nullptr;
+#define DEC_STAMP(k)                                                                                                   \
+  do {                                                                                                                 \
+    const long long t_ = (long long)__builtin_amdgcn_s_memrealtime();                                                  \
+    if (p.tl && lane == 0)                                                                                             \
+      p.tl[((((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + w) * 8 + (k)] = t_;        \
+  } while (0)
+#else
+#define DEC_STAMP(k) do { } while (0)
+#endif
 
 constexpr int kTile = 32;  // tokens per wave tile == reference _MIN_BLOCK_KV (decode_attention.py:35)
 constexpr float kLog2e = 1.4426950408889634f;
@@ -186,6 +201,7 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attn_stage1(const DecodePar
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   static_assert(CASC == 0 || (CASC == 2 && MODE == 0), "the cascade suffix pass is a MODE 0 form");
+  DEC_STAMP(0);
   const int hchunks = (p.group + 15) >> 4;
   int khc, split;
   if constexpr (MODE == 0) {
@@ -206,6 +222,7 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attn_stage1(const DecodePar
   request_range(p, b, idx_row, seq_len);
   const int nsplit = max(1, min(p.num_kv_splits[b], p.max_kv_splits - (CASC == 2 ? p.prefix_splits : 0)));
   if (split >= nsplit) return;  // MODE 1: a whole-wave exit; the kernel has no barrier in that mode
+  DEC_STAMP(1);
   const int per = split_len(seq_len, nsplit);
   const int start = split * per;
   const int end = min(start + per, seq_len);
@@ -305,9 +322,16 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attn_stage1(const DecodePar
   int tile = (MODE == 0) ? w : 0;
   int idx_next = 0;
   if (tile < ntiles) {
+    // (Round 4 tried the first tile's 32 slot ids by SCALAR loads -- s_load_dwordx16 x 2, a select chain per load instruction -- on
+    // the theory that the younger workgroup's index load waits behind the older one's 64 KiB of K / V loads in the CU's in-order
+    // vector queue: the timeline moved by 0.3 us and the step not at all (profiles/round4_ab_attn_timeline.json).  Removed.)
     issue(load_idx(tile));
     idx_next = load_idx(tile + TS);
   }
+  DEC_STAMP(2);
+#ifdef SGL_DEC_TIMELINE
+  bool first_tile = true;
+#endif
 
   for (; tile < ntiles; tile += TS) {
     const int tok0 = start + tile * kTile;
@@ -334,6 +358,9 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attn_stage1(const DecodePar
         *(u32x4_t*)(vl + row * ROWB + (((c16 ^ fv) << 5) | 16)) = v1;
       }
     }
+#ifdef SGL_DEC_TIMELINE
+    if (first_tile) { DEC_STAMP(3); first_tile = false; }
+#endif
     // ---- issue the gather of this wave's next tile, prefetch indices two tiles ahead ----
     if (tile + TS < ntiles) issue(idx_next);
     idx_next = load_idx(tile + 2 * TS);
@@ -415,6 +442,7 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attn_stage1(const DecodePar
     }
   }
 
+  DEC_STAMP(4);
   // ---- merge the NW wave-private states, write the split partial ----
   l_i = pair32_sum(pair16_sum(l_i));
   if constexpr (MODE == 1) {
@@ -469,7 +497,9 @@ __global__ __launch_bounds__(NW * 64, 2) void decode_attn_stage1(const DecodePar
       if (d == 0) p.attn_lse[slot] = lv;
     }
   }
+  DEC_STAMP(5);
   if (p.merge_cnt) arrive_and_merge<T, CASC == 2>(p, b, seq_len, nsplit, hchunks, smem);
+  DEC_STAMP(6);
 }
 
 // Any-head-dim fallback (D, Dv <= 256, not multiples of 32 allowed): one wave per
@@ -628,6 +658,13 @@ int launch_all(const DecodeParams& p, int d_qk, hipStream_t st) {
 
 }  // namespace
 
+#ifdef SGL_DEC_TIMELINE
+extern "C" int sgl_mi355_decode_attention_debug_timeline(long long* buf) {
+  g_dec_tl = buf;
+  return SGL_MI355_OK;
+}
+#endif
+
 extern "C" int sgl_mi355_decode_attention_set_mode(int mode) {
   g_decode_mode = mode ? 1 : 0;
   return SGL_MI355_OK;
@@ -668,6 +705,9 @@ static int decode_entry(
               "decode_attention: q/k/v rows must be 16-byte aligned for the MFMA path");
   }
   DecodeParams p;
+#ifdef SGL_DEC_TIMELINE
+  p.tl = g_dec_tl;
+#endif
   p.q = q; p.q_stride_t = q_stride_t;
   p.k_buf = k_buffer; p.v_buf = v_buffer;
   p.k_stride_t = k_stride_t; p.k_stride_h = k_stride_h; p.v_stride_t = v_stride_t; p.v_stride_h = v_stride_h;
