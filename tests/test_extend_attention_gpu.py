@@ -1,6 +1,7 @@
 """GPU parity of the HIP extend-attention kernel (through the C-ABI) against the reference's torch-native golden
 vectors and the CPU oracle.  Tolerances: bf16 |err| <= 2e-2 vs the float64 oracle (reference's own extend
 tolerance is atol = rtol = 1e-2 against its bf16 SDPA, test/srt/cpu/test_extend.py:180), f16 <= 3e-3."""
+import numpy as np
 import pytest
 import torch
 
@@ -147,6 +148,29 @@ def test_extend_64_rows_per_wave_kernel_vs_oracle(dtype, hq, hkv, pre, ext, pkg)
         assert torch.isfinite(new.float()).all()
         assert (new.double() - ref).abs().max().item() <= TOL_F64[c["dtype"]], (new.double() - ref).abs().max().item()
         assert (new.double() - old.double()).abs().max().item() <= TOL_F64[c["dtype"]]
+
+
+def test_extend_64_rows_per_wave_kernel_random_ragged_batches(pkg):
+    """Twelve seeded ragged batches (1-5 requests, prefix 0..300, extend 1..700, head groups 1 / 2 / 4 / 8) through the 64-rows-per-wave
+    kernel against the float64 oracle."""
+    from ltp_sglang_amd import _cabi
+    rng = np.random.RandomState(77)
+    try:
+        _cabi.check(_cabi.lib.sgl_mi355_extend_attention_set_mode(4))
+        for it in range(12):
+            group = int(rng.choice([1, 2, 4, 8]))
+            hkv = int(rng.choice([1, 2, 4]))
+            nreq = int(rng.randint(1, 6))
+            pre = [int(rng.randint(0, 301)) if rng.rand() < 0.7 else 0 for _ in range(nreq)]
+            ext = [int(rng.randint(1, 701)) for _ in range(nreq)]
+            dtype = "bf16" if it % 2 == 0 else "f16"
+            c = _cases.build_attn_case(dict(name="w64r", kind="extend", dtype=dtype, hq=group * hkv, hkv=hkv, d=128, pre=pre, ext=ext), seed=500 + it)
+            causal = bool(it % 3 != 2)
+            o = _run(pkg, c, causal=causal)
+            err = (o.double() - _f64(c, causal=causal)).abs().max().item()
+            assert torch.isfinite(o.float()).all() and err <= TOL_F64[c["dtype"]], (it, group, hkv, pre, ext, err)
+    finally:
+        _cabi.lib.sgl_mi355_extend_attention_set_mode(1)
 
 
 def test_extend_long_sequence_properties(pkg):

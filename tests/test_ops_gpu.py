@@ -538,6 +538,36 @@ def test_fp8_scaled_mm_eight_row_tiles_all_up_front(m, n, k, bias, sk):
     torch.testing.assert_close(new.cpu().float(), ref.float(), rtol=1.6e-2, atol=0.3)
 
 
+def test_fp8_scaled_mm_eight_row_tiles_random_shapes_same_bits(sk):
+    """40 seeded shapes around the band where 8-row tiles are chosen (N between one and three rounds of 16-row tiles on 256 CUs, ragged
+    N and K tails included, M 1..32): the all-tiles-up-front form against the one-tile-ahead form, bit for bit, and a row sample
+    against the float64 product."""
+    from ltp_sglang_amd import _cabi
+    rng = np.random.RandomState(404)
+    hit = 0
+    for it in range(40):
+        m = int(rng.randint(1, 33))
+        n = int(rng.randint(2056 // 8, 12288 // 8 + 1)) * 8
+        k = int(rng.randint(512 // 64, 4096 // 64 + 1)) * 64
+        g = torch.Generator().manual_seed(1000 + it)
+        a = (torch.randn(m, k, generator=g) * 2).to(torch.float8_e4m3fn).to(DEV)
+        wt = torch.randn(n, k, generator=g).to(torch.float8_e4m3fn).to(DEV)
+        sa = (torch.rand(m, generator=g) * 0.1 + 0.01).to(DEV)
+        sb = (torch.rand(n, generator=g) * 0.1 + 0.01).to(DEV)
+        new = sk.fp8_scaled_mm(a, wt.t(), sa, sb, torch.bfloat16)
+        try:
+            _cabi.check(_cabi.lib.sgl_mi355_skinny_gemm_force_generic(2))
+            old = sk.fp8_scaled_mm(a, wt.t(), sa, sb, torch.bfloat16)
+        finally:
+            _cabi.check(_cabi.lib.sgl_mi355_skinny_gemm_force_generic(3))
+        assert torch.equal(new, old), (m, n, k)
+        ref = (a.cpu().double() @ wt.cpu().double().t()) * sa.cpu().double().view(-1, 1) * sb.cpu().double().view(1, -1)
+        torch.testing.assert_close(new.cpu().double(), ref, rtol=1.6e-2, atol=0.3)
+        t16 = (n + 15) // 16
+        hit += int(256 < t16 and (t16 % 256) != 0 and (t16 % 256) < 192 and (n + 7) // 8 <= 768)
+    assert hit >= 5   # the band was really sampled
+
+
 # ---------------------------------------------------------------- tiled GEMM at prefill-sized M
 @pytest.mark.parametrize("tile_mode", [1, 2, 3, 4, 5])
 @pytest.mark.parametrize("m,n,k,out", [(256, 384, 4096, "bf16"), (1000, 136, 1024, "bf16"), (129, 6144, 512, "f16"),
