@@ -311,6 +311,12 @@ int sgl_mi355_fp8_qkv_rope_set_kv(const void* x, int64_t x_stride_elems, const v
 int sgl_mi355_gemm_silu_mul(const void* x, int64_t x_stride_elems, const void* w_interleaved, int64_t w_stride_elems, void* act,
                             int64_t act_stride_elems, const float* scales_x, const float* scales_w_interleaved, int M, int N,
                             int K, int in_dtype, int out_dtype, int tile_rows, void* stream);
+/* sgl_mi355_gemm_silu_mul with per-launch scratch: sched = 16 int32 words of device memory that no other launch in flight uses (one
+ * buffer per stream suffices).  With it the M > 64 (prefill) form runs the persistent 256 x 256 kernel on a dynamic per-XCD tile
+ * schedule -- the same bits; NULL: exactly sgl_mi355_gemm_silu_mul.  (models/llama.py:94-98 at prefill sizes.) */
+int sgl_mi355_gemm_silu_mul_ws(const void* x, int64_t x_stride_elems, const void* w_interleaved, int64_t w_stride_elems, void* act,
+                               int64_t act_stride_elems, const float* scales_x, const float* scales_w_interleaved, int M, int N,
+                               int K, int in_dtype, int out_dtype, int tile_rows, void* sched, void* stream);
 int sgl_mi355_qkv_rope_set_kv(const void* x, int64_t x_stride_elems, const void* w_interleaved, int64_t w_stride_elems,
                               void* q_out, int64_t q_stride_elems, const float* scales_x, const float* scales_w_interleaved,
                               const void* bias_interleaved, const int64_t* positions, const float* cos_sin_cache,

@@ -18,7 +18,8 @@
 #include "gemm_epilogue.h"
 
 int sgl_mi355_internal_tiled_gemm_silu_mul(const void* x, int64_t x_stride_b, const void* w, int64_t w_stride_b, void* act,
-                                           int64_t act_stride, const float* sx, const float* sw, int M, int N, int K, hipStream_t st);
+                                           int64_t act_stride, const float* sx, const float* sw, int M, int N, int K, hipStream_t st,
+                                           int* sched);
 
 namespace {
 
@@ -762,10 +763,10 @@ int run_epi(SkinnyParams& p, const EpiParams& ep, int in_dtype, int out_dtype, i
 // out_dtype == in_dtype).  w_interleaved [N, K] / scales_w [N]: tile t of tile_rows = 2 H rows (16 or 8) = gate rows H t .. H t + H - 1
 // then the up rows of the same indices.  8-row tiles balance the workgroups when N / 16 is between one and a few times the CU
 // count.  K must fit one k-range of the weight-streaming kernel (4096 bytes; 8192 at M <= 32).  Strides in elements.
-extern "C" int sgl_mi355_gemm_silu_mul(const void* x, int64_t x_stride_elems, const void* w_interleaved, int64_t w_stride_elems,
-                                       void* act, int64_t act_stride_elems, const float* scales_x,
-                                       const float* scales_w_interleaved, int M, int N, int K, int in_dtype, int out_dtype,
-                                       int tile_rows, void* stream) {
+static int gemm_silu_mul_impl(const void* x, int64_t x_stride_elems, const void* w_interleaved, int64_t w_stride_elems,
+                              void* act, int64_t act_stride_elems, const float* scales_x,
+                              const float* scales_w_interleaved, int M, int N, int K, int in_dtype, int out_dtype,
+                              int tile_rows, void* stream, int* sched) {
   SGL_CHECK(x && w_interleaved && act, "gemm_silu_mul: null pointer");
   if (M > 64) {   // prefill-sized: the 256x256 tile with the SiluAndMul epilogue (tiled_gemm.hip)
     SGL_CHECK(in_dtype == SGL_FP8_E4M3 && out_dtype == SGL_BF16 && tile_rows == 16 && scales_x && scales_w_interleaved,
@@ -773,13 +774,34 @@ extern "C" int sgl_mi355_gemm_silu_mul(const void* x, int64_t x_stride_elems, co
     SGL_CHECK(x_stride_elems % 16 == 0 && w_stride_elems % 16 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)w_interleaved % 16) == 0,
               "gemm_silu_mul: rows must be 16-byte aligned");
     return sgl_mi355_internal_tiled_gemm_silu_mul(x, x_stride_elems, w_interleaved, w_stride_elems, act, act_stride_elems, scales_x,
-                                                  scales_w_interleaved, M, N, K, (hipStream_t)stream);
+                                                  scales_w_interleaved, M, N, K, (hipStream_t)stream, sched);
   }
   SkinnyParams p;
   p.x = (const char*)x; p.x_stride = x_stride_elems; p.w = (const char*)w_interleaved; p.w_stride = w_stride_elems;
   p.y = act; p.y_stride = act_stride_elems; p.sx = scales_x; p.sw = scales_w_interleaved; p.bias = nullptr;
   p.M = M; p.N = N; p.K = K; p.kbytes = 0;
   return run_epi<EPI_SILU>(p, EpiParams{}, in_dtype, out_dtype, tile_rows, (hipStream_t)stream, "gemm_silu_mul");
+}
+
+extern "C" int sgl_mi355_gemm_silu_mul(const void* x, int64_t x_stride_elems, const void* w_interleaved, int64_t w_stride_elems,
+                                       void* act, int64_t act_stride_elems, const float* scales_x,
+                                       const float* scales_w_interleaved, int M, int N, int K, int in_dtype, int out_dtype,
+                                       int tile_rows, void* stream) {
+  return gemm_silu_mul_impl(x, x_stride_elems, w_interleaved, w_stride_elems, act, act_stride_elems, scales_x, scales_w_interleaved, M, N, K,
+                            in_dtype, out_dtype, tile_rows, stream, nullptr);
+}
+
+// The same with per-launch scratch (round 4): `sched` = 16 int32 words of device memory that no other launch in flight uses (one
+// buffer per stream is enough: launches of a stream are ordered).  With it the M > 64 form runs the persistent 256 x 256 kernel on a
+// DYNAMIC per-XCD tile schedule (workgroups that finish early take more tiles; the launcher zeroes the words with a memset node, the
+// kernel leaves them dirty) -- the same bits as without; NULL or M <= 64: exactly sgl_mi355_gemm_silu_mul.
+extern "C" int sgl_mi355_gemm_silu_mul_ws(const void* x, int64_t x_stride_elems, const void* w_interleaved, int64_t w_stride_elems,
+                                          void* act, int64_t act_stride_elems, const float* scales_x,
+                                          const float* scales_w_interleaved, int M, int N, int K, int in_dtype, int out_dtype,
+                                          int tile_rows, void* sched, void* stream) {
+  SGL_CHECK(sched == nullptr || ((uintptr_t)sched & 3) == 0, "gemm_silu_mul_ws: sched must be 4-byte aligned");
+  return gemm_silu_mul_impl(x, x_stride_elems, w_interleaved, w_stride_elems, act, act_stride_elems, scales_x, scales_w_interleaved, M, N, K,
+                            in_dtype, out_dtype, tile_rows, stream, (int*)sched);
 }
 
 extern "C" int sgl_mi355_fp8_gemm_silu_mul(const void* x, int64_t x_stride_elems, const void* w_interleaved,

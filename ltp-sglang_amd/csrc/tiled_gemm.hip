@@ -32,6 +32,8 @@ struct GemmParams {
   int kt_per;
   const uint16_t* silu_lut = nullptr;  // SiluAndMul epilogue of the 256x256 kernel: the table of silu_lut.h in global memory
   int stagger_q, stagger_cus;  // 256x256 kernel: start stagger of each CU's first workgroup (quantum in 1024-cycle units; CU count)
+  int* sched = nullptr;  // persistent 256x256 kernel, DYNAMIC tile schedule (round 4): 8 words, one ticket counter per XCD class, ZERO at launch
+                         // (the launcher enqueues the memset); NULL = the static schedule (tile j, j + per, ... of the XCD's range)
 #ifdef SGL_GEMM_TIMELINE
   long long* tl;  // tools/microbench/gemm256_timeline.hip: s_memtime stamps of workgroup 0, slices 8..11
 #endif
@@ -830,12 +832,26 @@ __global__ __launch_bounds__(512, 1) void fp8_gemm256p_kernel(const GemmParams p
   if constexpr (SILU) {   // the silu table -> LDS once per workgroup, behind the first slice's DMA
     for (int i = tid; i < kSiluLut / 8; i += NWV * 64) *(u32x4_t*)(smem + kSiluLdsOff + 16 * i) = *(const u32x4_t*)(p.silu_lut + 8 * i);
   }
+  // Dynamic tile schedule (round 4; measured in round 3 at -1.7 ... -5.8 % over the static one, not kept then for want of per-launch
+  // storage): the first tile of a workgroup is static (tile bid / 8 of its XCD's range); every later one is `per_eff` + a ticket drawn
+  // from the XCD class's counter -- the workgroups that finish early take more tiles, the order of tiles inside the XCD's range (and
+  // with it the grouped L2 reuse) is unchanged.  Tickets are drawn ONE TILE AHEAD by thread 0, at the point where the tile's second
+  // slice is staged: the returning atomic rides under the same wait as that DMA; it reaches the other waves through two words of LDS
+  // and the barriers the tile loop already has.  No workgroup ever waits for another: a ticket past the range ends the loop.
+  __shared__ int sched_l[2];
+  const int per_eff = min(per, cnt);
+  int next_ti = ti + per;
+  if (p.sched != nullptr && tid == 0) sched_l[0] = per_eff + __hip_atomic_fetch_add(p.sched + xcd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
+  if (p.sched != nullptr) next_ti = sched_l[0];
+  int iter = 0;
   for (;;) {
     stage_at(wo0, xo0, 1, b0 ^ 1);
-    const bool has_next = ti + per < cnt;
+    int ticket = 0;
+    if (p.sched != nullptr && tid == 0) ticket = __hip_atomic_fetch_add(p.sched + xcd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the tile after next
+    const bool has_next = next_ti < cnt;
     int m1 = m0, n1 = n0;
-    if (has_next) origin(ti + per, m1, n1);
+    if (has_next) origin(next_ti, m1, n1);
     wo1 = (int)((int64_t)n1 * p.w_stride);   // (no next tile: this tile's own slice 0 once more, into a drained buffer nobody reads)
     xo1 = (int)((int64_t)m1 * p.x_stride);
 #pragma unroll
@@ -891,13 +907,16 @@ __global__ __launch_bounds__(512, 1) void fp8_gemm256p_kernel(const GemmParams p
         epilogue_scaled<OutT, 8, JN>(p, acc, m0 + wm + (lane_e & 15), n0 + wn + 4 * (lane_e >> 4));
     }
     if (!has_next) break;
-    ti += per;
+    if (p.sched != nullptr && tid == 0) sched_l[(iter + 1) & 1] = per_eff + ticket;
+    ti = next_ti;
     m0 = m1;
     n0 = n1;
     wo0 = wo1;
     xo0 = xo1;
     b0 = (nk + b0) & 1;   // = the buffer of slice nk - 2
     __syncthreads();      // the epilogue's LDS reads are done: its buffer may take slice 1
+    next_ti = p.sched != nullptr ? sched_l[(iter + 1) & 1] : ti + per;
+    ++iter;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may be in flight when the workgroup ends
 }
@@ -1049,15 +1068,21 @@ int launch256(GemmParams& p, hipStream_t st) {
 }
 
 int g_tiled_persistent = 1;  // measurement hook (force_tile 3000 / 3001): 0 = one tile per workgroup always
+int g_tiled_dynamic = 1;  // measurement hook (force_tile 4000 / 4001): 0 = the static tile schedule even where per-launch counters were given
 template <typename OutT, int ES = TG_FP8, bool SILU = false>
-int launch256p(GemmParams& p, hipStream_t st) {
+int launch256p(GemmParams& p, hipStream_t st, int* sched = nullptr) {
   const int cus = tg_cus() / 8 * 8;
   const int64_t tiles = (int64_t)((p.M + T2 - 1) / T2) * ((p.N + T2 - 1) / T2);
+  if (!g_tiled_dynamic) sched = nullptr;
+  if constexpr (SILU) {
+    // the SiluAndMul form measured a TIE between the static persistent schedule and one tile per workgroup (round 3); it takes the
+    // persistent kernel only with the dynamic schedule, i.e. when the caller gave per-launch counters
+    if (sched == nullptr) return launch256<OutT, 8, true, ES, SILU>(p, st);
+  }
   // (measured, tools/debug/persistent_256.py / persistent_silu.py, M = 65 536: K = 4096 x N = 6144 / 4096 / 28672 -5 % / -5 % / -2.5 %, K = 384-640
   // -10...-16 %; K = 14336 a tie (the hand-over is 4 % of a tile there and the static tile schedule gives up the dispatcher's load
   // balancing); the SiLU form a tie as well -- both stay on one tile per workgroup)
-  static_assert(!SILU, "the SiluAndMul form stays on one tile per workgroup (a tie, see above); fp8_gemm256p_kernel supports it");
-  if (!g_tiled_persistent || p.kbytes > 8192 || cus < 8 || tiles < 2 * (int64_t)cus || p.kbytes < 3 * BKB || (int64_t)p.N * p.w_stride >= (1ll << 31) ||
+  if (!g_tiled_persistent || (p.kbytes > 8192 && !(sched != nullptr && g_tiled_dynamic >= 2)) || cus < 8 || tiles < 2 * (int64_t)cus || p.kbytes < 3 * BKB || (int64_t)p.N * p.w_stride >= (1ll << 31) ||
       (int64_t)p.M * p.x_stride >= (1ll << 31))   // (the tile origin travels in a signed 32-bit scalar offset)
     return launch256<OutT, 8, true, ES, SILU>(p, st);
   constexpr int smem = 2 * 2 * OPB + (SILU ? kSiluLut * 2 : 0);
@@ -1071,6 +1096,11 @@ int launch256p(GemmParams& p, hipStream_t st) {
   p.group_m = g_tiled_group_m;
   p.stagger_cus = cus;
   p.stagger_q = g_tiled_stagger;
+  p.sched = sched;
+  if (sched != nullptr) {   // the counters start every launch at zero whatever an aborted launch left there (a memset node: capturable)
+    const hipError_t e = hipMemsetAsync(sched, 0, 8 * sizeof(int), st);
+    SGL_CHECK(e == hipSuccess, "fp8_gemm: hipMemsetAsync of the tile counters failed: %s", hipGetErrorString(e));
+  }
   hipLaunchKernelGGL((fp8_gemm256p_kernel<OutT, ES, SILU>), dim3(cus), dim3(512), smem, st, p);
   SGL_HIP_LAUNCH_CHECK();
   return SGL_MI355_OK;
@@ -1261,6 +1291,9 @@ int run(const void* x, int64_t xs, const void* w, int64_t ws, void* y, int64_t y
   p.sx = sx; p.sw = sw; p.bias = bias;
   p.M = M; p.N = N; p.kbytes = K * es;
   hipStream_t st = (hipStream_t)stream;
+  // per-launch tile counters of the persistent kernel's dynamic schedule: the LAST 16 words of the caller's workspace (this call's
+  // scratch for the duration of the call, like the split-K slabs the other tiles put at its head; zeroed by the launcher)
+  int* sched = (workspace != nullptr && workspace_floats >= 4096) ? (int*)(workspace + workspace_floats - 16) : nullptr;
   if (in_dtype == SGL_FP8_E4M3) {
     // both LDS-DMA kernels want whole 128-byte K slices
     const bool can256 = p.kbytes % BKB == 0 && p.kbytes >= BKB && (int64_t)N * p.w_stride < 0xFFFFFFF0ll &&
@@ -1276,7 +1309,7 @@ int run(const void* x, int64_t xs, const void* w, int64_t ws, void* y, int64_t y
     if (can256 && g_tiled_force == 3) return out_dtype == SGL_BF16 ? launch256<__bf16, 4>(p, st) : launch256<_Float16, 4>(p, st);
     // (the old 128x128 kernel is left with the shapes neither LDS-DMA kernel accepts: K not whole 128-byte slices, > 4 GiB operands)
     if (can256 && g_tiled_force != 1)
-      return out_dtype == SGL_BF16 ? launch256p<__bf16>(p, st) : launch256p<_Float16>(p, st);
+      return out_dtype == SGL_BF16 ? launch256p<__bf16>(p, st, sched) : launch256p<_Float16>(p, st, sched);
     return out_dtype == SGL_BF16 ? launch<TG_FP8, __bf16>(p, st, workspace, workspace_floats)
                                  : launch<TG_FP8, _Float16>(p, st, workspace, workspace_floats);
   }
@@ -1289,8 +1322,8 @@ int run(const void* x, int64_t xs, const void* w, int64_t ws, void* y, int64_t y
     }
     if (tile == kTile256) {
       if (in_dtype == SGL_BF16)
-        return out_dtype == SGL_BF16 ? launch256p<__bf16, TG_BF16>(p, st) : launch256p<_Float16, TG_BF16>(p, st);
-      return out_dtype == SGL_BF16 ? launch256p<__bf16, TG_F16>(p, st) : launch256p<_Float16, TG_F16>(p, st);
+        return out_dtype == SGL_BF16 ? launch256p<__bf16, TG_BF16>(p, st, sched) : launch256p<_Float16, TG_BF16>(p, st, sched);
+      return out_dtype == SGL_BF16 ? launch256p<__bf16, TG_F16>(p, st, sched) : launch256p<_Float16, TG_F16>(p, st, sched);
     }
   }
   if (in_dtype == SGL_BF16)
@@ -1330,7 +1363,8 @@ extern "C" int sgl_mi355_silu_table_init(void* stream) {
 // gate_up_proj + SiluAndMul for M > 64 (called by sgl_mi355_gemm_silu_mul, skinny_gemm.hip): fp8 operands, bf16 out, 16-row
 // interleaving, N % 256 == 0, whole 128-byte K slices.  Returns SGL_MI355_EINVAL with a message otherwise.
 int sgl_mi355_internal_tiled_gemm_silu_mul(const void* x, int64_t x_stride_b, const void* w, int64_t w_stride_b, void* act,
-                                           int64_t act_stride, const float* sx, const float* sw, int M, int N, int K, hipStream_t st) {
+                                           int64_t act_stride, const float* sx, const float* sw, int M, int N, int K, hipStream_t st,
+                                           int* sched) {
   SGL_CHECK(M > 0 && N > 0 && N % 256 == 0 && K % BKB == 0 && K >= BKB, "gemm_silu_mul: the prefill form needs N %% 256 == 0 and K %% 128 == 0 (N=%d K=%d)", N, K);
   SGL_CHECK((int64_t)N * w_stride_b < 0xFFFFFFF0ll && (int64_t)M * x_stride_b < 0xFFFFFFF0ll, "gemm_silu_mul: operands above 4 GiB");
   SGL_CHECK(act_stride % 8 == 0 && ((uintptr_t)act & 15) == 0, "gemm_silu_mul: act rows must be 16-byte aligned");
@@ -1354,12 +1388,17 @@ int sgl_mi355_internal_tiled_gemm_silu_mul(const void* x, int64_t x_stride_b, co
   SGL_CHECK(g_silu_table_ready[dev].load(std::memory_order_acquire),
             "gemm_silu_mul: the silu table of device %d is not initialised -- call sgl_mi355_silu_table_init(stream) once per device "
             "(outside stream capture) and order later work after it", dev);
-  return launch256<__bf16, 8, true, TG_FP8, true>(p, st);   // (the persistent form measured a tie for this epilogue: launch256p)
+  // one tile per workgroup, or -- given per-launch counters -- the persistent kernel on the dynamic tile schedule (launch256p decides)
+  return launch256p<__bf16, TG_FP8, true>(p, st, sched);
 }
 
 extern "C" int sgl_mi355_fp8_gemm_force_tile(int mode) {
-  if (mode >= 3000) {  // measurement hook: 3001 = persistent 256x256 kernel where a launch has at least two tiles per CU (default), 3000 = never
+  if (mode >= 3000 && mode < 4000) {  // measurement hook: 3001 = persistent 256x256 kernel where a launch has at least two tiles per CU (default), 3000 = never
     g_tiled_persistent = mode - 3000;
+    return SGL_MI355_OK;
+  }
+  if (mode >= 4000) {  // measurement hook: 4001 = dynamic tile schedule where counters are available (default), 4000 = static schedule
+    g_tiled_dynamic = mode - 4000;
     return SGL_MI355_OK;
   }
   SGL_CHECK(mode < 2000 || mode >= 3000, "fp8_gemm_force_tile: the 2000 range (in-launch split-K combine) was removed in round 4");

@@ -5,6 +5,7 @@ from typing import Optional, Tuple
 import torch
 
 from .._cabi import check, current_stream, dtype_code, lib, ptr
+from .gemm import _workspace
 
 
 def fused_add_rmsnorm_quant_fp8(x: Optional[torch.Tensor], residual: Optional[torch.Tensor], weight: torch.Tensor, eps: float,
@@ -104,10 +105,18 @@ def silu_table_init(device) -> None:
 def fp8_gemm_silu_mul(x_q, x_s, w_interleaved_nk, w_s_interleaved, out_dtype, tile_rows: int = 16):
     """act [M, I] = SiluAndMul(fp8_scaled_mm(x_q, W)) with W's rows interleaved by interleave_gate_up_rows."""
     m, k = x_q.shape
-    if m > 64:
-        silu_table_init(x_q.device)
     n = w_interleaved_nk.shape[0]
     act = torch.empty((m, n // 2), dtype=out_dtype, device=x_q.device)
+    if m > 64:
+        silu_table_init(x_q.device)
+        # prefill sizes: the persistent kernel's ticket counters = the last 16 words of the per-device GEMM scratch (gemm._workspace)
+        ws, ws_n = _workspace(x_q.device, 4096)
+        sched = ws[ws_n - 16:]
+        st = current_stream()
+        check(lib.sgl_mi355_gemm_silu_mul_ws(ptr(x_q), x_q.stride(0), ptr(w_interleaved_nk), w_interleaved_nk.stride(0), ptr(act),
+                                             act.stride(0), ptr(x_s), ptr(w_s_interleaved), m, n, k, dtype_code(x_q.dtype),
+                                             dtype_code(out_dtype), int(tile_rows), ptr(sched), st))
+        return act
     check(lib.sgl_mi355_fp8_gemm_silu_mul(ptr(x_q), x_q.stride(0), ptr(w_interleaved_nk), w_interleaved_nk.stride(0), ptr(act),
                                           act.stride(0), ptr(x_s), ptr(w_s_interleaved), m, n, k, dtype_code(out_dtype),
                                           int(tile_rows), current_stream()))

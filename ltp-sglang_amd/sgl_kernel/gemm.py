@@ -14,7 +14,10 @@ WORKSPACE_FLOATS = 1 << 25  # 128 MiB: 4 k-ranges x 64 rows x 128 256 columns (7
 
 
 def _workspace(device, need: int):
-    """The per-device f32 split-K scratch shared by the skinny, tiled and AWQ GEMMs.
+    """The per-device f32 scratch shared by the skinny, tiled and AWQ GEMMs: split-K slabs at its head, the persistent tile
+    kernel's ticket counters in its last 16 words.  ONE per device, not per stream (torch.cuda.graph captures on a fresh side
+    stream each time: a per-stream buffer would be allocated -- and zero-filled -- inside every captured graph), so GEMMs of two
+    streams of one process must not run side by side; the model runner and the bench use one stream per process.
 
     Its address must stay valid for every HIP graph that captured a launch using it, so it is allocated ONCE at
     ``WORKSPACE_FLOATS`` (covers every shape of the BASELINE configs); a larger request allocates a new buffer and the old
@@ -24,8 +27,7 @@ def _workspace(device, need: int):
     if buf is None or buf.numel() < need:
         if buf is not None:
             _RETIRED.append(buf)
-        # zeros: the last 1024 floats are the in-launch split-K combine's counters of the streaming-tile GEMM (csrc/tiled_gemm.hip),
-        # which that kernel leaves at zero after every launch
+        # (the last 16 words are the persistent tile kernel's ticket counters, zeroed by its launcher before every launch)
         buf = torch.zeros(max(int(need), WORKSPACE_FLOATS), dtype=torch.float32, device=device)
         _WORKSPACES[device] = buf
     return buf, buf.numel()

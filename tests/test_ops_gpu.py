@@ -667,6 +667,79 @@ def test_fp8_scaled_mm_persistent_256_kernel_bits_equal_one_tile_per_workgroup(m
     assert torch.equal(outs[3000], outs[3001])
 
 
+@pytest.mark.parametrize("m,n,k", [(8192, 4096, 512), (4100, 8200, 384), (4352, 7936, 9216)])
+def test_persistent_256_kernel_dynamic_tile_schedule_same_bits(m, n, k, sk):
+    """Round 4: the persistent kernel draws its tiles after the first from per-XCD ticket counters (the last 16 words of the caller's
+    workspace, zeroed by the launcher's memset node) instead of the static stride: which workgroup computes a tile changes, the
+    tile's arithmetic does not -- same bits as the static schedule (force_tile 4000) for fp8 and 16-bit operands, launches back to
+    back on one stream (the counters are re-zeroed between them), under capture and replay, and with K > 8 KiB (mode 4002)."""
+    from ltp_sglang_amd import _cabi
+    c = _cases.build_gemm_case(dict(m=m, n=n, k=k, bias=True, out="bf16"), seed=m + n + k)
+    a, wt, sa, sb, bias = (c[x].to(DEV) for x in ("a", "w", "sa", "sb", "bias"))
+    g = torch.Generator().manual_seed(5)
+    x16 = torch.randn(m, k // 2, generator=g).to(torch.bfloat16).to(DEV)
+    w16 = (torch.randn(n, k // 2, generator=g) * 0.05).to(torch.bfloat16).to(DEV)
+    outs, outs16 = {}, {}
+    try:
+        for mode in (4000, 4001, 4002):
+            _cabi.check(_cabi.lib.sgl_mi355_fp8_gemm_force_tile(mode))
+            outs[mode] = [sk.fp8_scaled_mm(a, wt.t(), sa, sb, torch.bfloat16, bias) for _ in range(4)]
+            outs16[mode] = sk.dense_linear(x16, w16)
+        st = torch.cuda.Stream()
+        st.wait_stream(torch.cuda.current_stream())
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=st):
+            y1 = sk.fp8_scaled_mm(a, wt.t(), sa, sb, torch.bfloat16, bias)
+            y2 = sk.fp8_scaled_mm(a, wt.t(), sa, sb, torch.bfloat16, bias)
+        for _ in range(2):
+            y1.zero_(); y2.zero_()
+            gr.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(y1, outs[4000][0]) and torch.equal(y2, outs[4000][0])
+    finally:
+        _cabi.lib.sgl_mi355_fp8_gemm_force_tile(4001)
+    for mode in (4001, 4002):
+        assert all(torch.equal(o, outs[4000][0]) for o in outs[mode])
+        assert torch.equal(outs16[mode], outs16[4000])
+    ref = oq.scaled_mm(c["a"], c["w"].t(), c["sa"], c["sb"], c["out_dtype"], c["bias"])
+    torch.testing.assert_close(outs[4002][0].cpu().float(), ref.float(), rtol=1.6e-2, atol=0.3)
+
+
+@pytest.mark.parametrize("m,n,k", [(8192, 8192, 512), (4100, 8704, 384)])
+def test_gemm_silu_mul_ws_dynamic_schedule_same_bits(m, n, k, sk):
+    """sgl_mi355_gemm_silu_mul_ws (round 4): gate_up + SiluAndMul on the persistent kernel with the dynamic tile schedule when the
+    caller passes eight ticket words; bits equal to the entry point without them (one tile per workgroup), for repeated launches,
+    with dirty counters on entry (the launcher zeroes them), and NULL counters = the old entry point."""
+    from ltp_sglang_amd import _cabi
+    from ltp_sglang_amd._cabi import check, current_stream, dtype_code, lib, ptr
+    c = _cases.build_gemm_case(dict(m=m, n=n, k=k, bias=False, out="bf16"), seed=m + n)
+    a, wt, sa, sb = c["a"].to(DEV), c["w"].to(DEV), c["sa"].to(DEV) * 3, c["sb"].to(DEV) * 3
+    wi = sk.interleave_gate_up_rows(wt.view(torch.uint8), 16).view(torch.float8_e4m3fn)
+    sbi = sk.interleave_gate_up_rows(sb, 16)
+    sk.silu_table_init(a.device)
+
+    def run(sched):
+        act = torch.empty(m, n // 2, dtype=torch.bfloat16, device=DEV)
+        check(lib.sgl_mi355_gemm_silu_mul_ws(ptr(a), a.stride(0), ptr(wi), wi.stride(0), ptr(act), act.stride(0), ptr(sa), ptr(sbi),
+                                             m, n, k, dtype_code(a.dtype), dtype_code(torch.bfloat16), 16, ptr(sched), current_stream()))
+        return act
+
+    ref = run(None)
+    _cabi.check(_cabi.lib.sgl_mi355_fp8_gemm_force_tile(2))
+    try:
+        two_step = sk.silu_and_mul(sk.fp8_scaled_mm(a, wt.t(), sa, sb, torch.bfloat16))
+    finally:
+        _cabi.lib.sgl_mi355_fp8_gemm_force_tile(0)
+    assert torch.equal(ref, two_step)
+    sched = torch.full((16,), 12345, dtype=torch.int32, device=DEV)   # dirty on entry
+    got = [run(sched) for _ in range(4)]
+    assert all(torch.equal(g_, ref) for g_ in got)
+    assert torch.equal(sk.fp8_gemm_silu_mul(a, sa, wi, sbi, torch.bfloat16, 16), ref)   # the host wrapper (workspace tail as counters)
+    with pytest.raises(RuntimeError, match="aligned"):
+        check(lib.sgl_mi355_gemm_silu_mul_ws(ptr(a), a.stride(0), ptr(wi), wi.stride(0), ptr(ref), ref.stride(0), ptr(sa), ptr(sbi), m, n, k,
+                                             dtype_code(a.dtype), dtype_code(torch.bfloat16), 16, sched.data_ptr() + 2, current_stream()))
+
+
 def test_fp8_scaled_mm_random_shapes_default_dispatch_vs_oracle(sk):
     """Whatever kernel the host cost lines pick (skinny, streaming 128x128 with or without split-K, 256x128, 256x256 one-tile or
     persistent, the old 128x128 kernel for K that is not whole 128-byte slices): 28 seeded shapes with ragged M / N / K against the
