@@ -388,7 +388,8 @@ int64_t sgl_mi355_radix_node_info(void* tree, int64_t node, int64_t* parent, int
  * sgl_mi355_awq_dequantize's and nothing but int4 read from HBM.  The weight is re-laid once at load time
  * (process_weights_after_loading, awq.py:393-399; the role awq_marlin_repack plays for the reference's Marlin path,
  * sgl-kernel/csrc/gemm/marlin/awq_marlin_repack.cu) into MFMA-fragment order:
- *   qpacked int32 [N/16][K/128][64][4], sz int32 [K/G][N] = (zero << 16) | scale bits.   K % 128 == 0, N % 16 == 0,
+ *   qpacked int32 [N/16][K/128][64][4], sz int32 [K/G][N] = (zero << 16) | scale bits (bf16 scales) or ((0xE400 | zero) << 16) |
+ *   scale bits (f16 scales: the upper half is the f16 constant -(1024 + zero), round 4).   K % 128 == 0, N % 16 == 0,
  *   group_size 32, 64 or a multiple of 128. */
 int sgl_mi355_awq_repack(const void* qweight, const void* scales, const void* qzeros, void* qpacked, void* sz, int K, int N,
                          int group_size, int scale_dtype, void* stream);

@@ -54,15 +54,20 @@ __global__ __launch_bounds__(256) void awq_dequant_kernel(const uint32_t* __rest
 //   qpacked int32 [N/16][K/128][64 lanes][4]:  word s of lane (a = n % 16, g) of tile n/16, block k/128 holds
 //   q[k = 128 b + 32 s + 8 g + e][n], e = 0..7, in nibble (e & 1) * 4 + e / 2, so (word >> 4 i) & 0x000F000F is the pair
 //   (e = 2 i, 2 i + 1) in the two 16-bit halves     (1 KiB contiguous per (tile, block): perfectly coalesced)
-//   sz     int32 [K/G][N]:  (zero point << 16) | scale bits     (one 4-byte load per lane, block and scale group)
+//   sz     int32 [K/G][N]:  scale bits | (zero point << 16) for bf16 scales; scale bits | (0xE400 | zero point) << 16 for f16
+//          scales -- the upper half is then the f16 constant -(1024 + z) the dequantisation subtracts, ready made (round 4)
+//          (one 4-byte load per lane, block and scale group)
 // Structure = the X-stationary skinny GEMM of skinny_gemm.hip without the LDS re-layout: one 512-thread workgroup per
 // CU; wave w owns k-blocks w, w+8, w+16, w+24 of the k-range (blockIdx.y: 32 blocks = 4096 k) for the whole launch and
 // keeps their X fragments in registers; the workgroup walks 16-column tiles; the 8 waves' partial sums of TPP tiles
 // meet in LDS between two barriers.  k-ranges > 1 (K > 4096) go through f32 slabs and a reduce kernel.  33..64 rows (MT = 4):
 // two k-blocks per wave (k-range 2048), so the X fragments stay at 128 VGPRs; two output rows per thread in the epilogue.
 // Dequantisation, bit-identical to awq_dequantize's T(float(q - z) * float(s)):
-//   f16:  pair | 0x64006400 = (1024 + q) as packed f16; v_pk_add_f16 with -(1024 + z) gives q - z exactly; v_pk_mul_f16 by
-//         the scale rounds once  ->  2 VALU lane-ops per weight;
+//   f16:  even nibble pairs: (word & 0x000F000F) | 0x64006400 = (1024 + q) as packed f16; odd pairs IN PLACE: (word & 0x00F000F0) |
+//         0x54005400 = (64 + q) -- mantissa bits 4..7 of 64.0 weigh 1, 2, 4, 8 -- so ONE shift (by 8) serves the four pairs of a
+//         word instead of three (r4; always exact, no condition on the scales); v_pk_add_f16 with -(1024 + z) / -(64 + z) gives
+//         q - z exactly; v_pk_mul_f16 by the scale rounds once.  The scale and -(1024 + z) are the two halves of the sz word
+//         (op_sel, no instruction), -(64 + z) takes two: 13 VALU lane-ops per 8 weights + 2 per scale group (15 + 8 before);
 //   bf16: v_cvt_f32_ubyteN of the nibbles, v_pk_fma_f32 (q * s - z * s is exact in f32), v_cvt_pk_bf16_f32  ->  2.4 per weight.
 // ---------------------------------------------------------------------------------------------------------
 struct AwqGemmParams {
@@ -108,21 +113,26 @@ struct AwqDequant;
 // (szw: zero << 16 | scale bits)  ->  per-lane constants of one scale group, then 8 weights of one packed word
 template <>
 struct AwqDequant<_Float16> {
-  uint32_t s2;      // scale in both halves
-  f16x2_t negzm;    // -(1024 + z) in both halves
+  f16x2_t s2, nz0, nz1;   // scale, -(1024 + z), -(64 + z) in both halves
+  // (one uint32_t, never an element of a u32x2_t: `bit_cast<f16x2_t>(v[1])[0]` of a two-word vector compiles to word 0's half with
+  // ROCm 7.2's hipcc -- tools/microbench/buffer_b64_halves.hip)
   __device__ __forceinline__ void setup(uint32_t szw) {
-    s2 = (szw & 0xFFFFu) * 0x00010001u;
-    const _Float16 nz = -(_Float16)(float)(1024u + (szw >> 16));
-    negzm = f16x2_t{nz, nz};
+    const f16x2_t c = __builtin_bit_cast(f16x2_t, szw);
+    s2 = f16x2_t{c[0], c[0]};      // op_sel on the sz word: no instruction
+    nz0 = f16x2_t{c[1], c[1]};     // 0xE400 | z
+    const f16x2_t d = __builtin_bit_cast(f16x2_t, ((szw >> 12) & 0xF0u) | 0xD400u);   // -(64 + z): z in mantissa bits 4..7
+    nz1 = f16x2_t{d[0], d[0]};
   }
   __device__ __forceinline__ f16x8_t run(uint32_t wq) const {
     f16x2_t o[4];
+    const uint32_t w8 = wq >> 8;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      uint32_t pr;  // (1024 + q[2i], 1024 + q[2i+1]); one v_and_or_b32 (hipcc emits v_and + v_or for two literals)
-      asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(pr) : "v"(wq >> (4 * i)), "s"(0x000F000Fu), "v"(0x64006400u));
-      const f16x2_t d = __builtin_bit_cast(f16x2_t, pr) + negzm;         // exact small integers
-      o[i] = d * __builtin_bit_cast(f16x2_t, s2);                        // one rounding: T(d * s)
+      uint32_t pr;  // i even: (1024 + q[2i], 1024 + q[2i+1]); i odd: (64 + q[2i], 64 + q[2i+1]); one v_and_or_b32 each
+      if (i & 1) asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(pr) : "v"(i < 2 ? wq : w8), "s"(0x00F000F0u), "v"(0x54005400u));
+      else asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(pr) : "v"(i < 2 ? wq : w8), "s"(0x000F000Fu), "v"(0x64006400u));
+      const f16x2_t d = __builtin_bit_cast(f16x2_t, pr) + ((i & 1) ? nz1 : nz0);   // exact small integers
+      o[i] = d * s2;                                                              // one rounding: T(d * s)
     }
     struct P { f16x2_t v[4]; } pk{{o[0], o[1], o[2], o[3]}};
     return __builtin_bit_cast(f16x8_t, pk);
@@ -475,7 +485,8 @@ __global__ __launch_bounds__(256) void awq_repack_sz_kernel(const uint32_t* __re
     const int64_t grp = o / N;
     const int shift = 4 * ((n & 1) * 4 + ((n & 7) >> 1));
     const uint32_t z = (qzeros[grp * NC + (n >> 3)] >> shift) & 0xFu;
-    sz[o] = (z << 16) | (uint32_t)__builtin_bit_cast(uint16_t, scales[o]);
+    const uint32_t hi = __is_same(T, _Float16) ? (0xE400u | z) : z;   // f16: the bits of -(1024 + z)
+    sz[o] = (hi << 16) | (uint32_t)__builtin_bit_cast(uint16_t, scales[o]);
   }
 }
 

@@ -70,7 +70,8 @@ def awq_dequantize(qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.Te
 
 def awq_repack(qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     """One-off re-layout of an AWQ weight into MFMA-fragment order for :func:`awq_gemm`.
-    Returns (qpacked int32 [N/16, K/128, 64, 4], sz int32 [K/G, N] = zero << 16 | scale bits)."""
+    Returns (qpacked int32 [N/16, K/128, 64, 4], sz int32 [K/G, N] = zero << 16 | scale bits; f16 scales:
+    (0xE400 | zero) << 16 | scale bits, include/sgl_mi355.h)."""
     _cuda(qweight, scales, qzeros)
     if qweight.dtype != torch.int32 or qzeros.dtype != torch.int32:
         raise RuntimeError("qweight and qzeros must be int32")

@@ -62,7 +62,8 @@ def _awq_unpack(packed):
 
 def awq_repack(qweight, scales, qzeros):
     """Layout oracle of sgl_mi355_awq_repack (include/sgl_mi355.h): qpacked int32 [N/16, K/128, 64, 4] whose word s of lane
-    (a = n % 16, g) holds q[128 b + 32 s + 8 g + e][n] in nibble (e & 1) * 4 + e / 2; sz int32 [K/G, N] = zero << 16 | scale bits."""
+    (a = n % 16, g) holds q[128 b + 32 s + 8 g + e][n] in nibble (e & 1) * 4 + e / 2; sz int32 [K/G, N] = zero << 16 | scale bits (bf16 scales),
+    (0xE400 | zero) << 16 | scale bits (f16 scales: the upper half is the f16 bit pattern of -(1024 + zero))."""
     k, nc = qweight.shape
     n = nc * 8
     q = _awq_unpack(qweight).to(torch.int64)                                 # [K, N] natural column order
@@ -72,7 +73,7 @@ def awq_repack(qweight, scales, qzeros):
     words = (qb << (4 * nib.view(1, 1, 1, 8, 1, 1))).sum(dim=3)              # [b, s, g, t, a]
     words = words.permute(3, 0, 2, 4, 1).reshape(n // 16, k // 128, 64, 4)   # [t, b, (g, a), s]
     sbits = scales.contiguous().view(torch.int16).to(torch.int64) & 0xFFFF
-    sz = (z << 16) | sbits
+    sz = (((z | 0xE400) if scales.dtype == torch.float16 else z) << 16) | sbits
     to_i32 = lambda t: torch.where(t >= 2**31, t - 2**32, t).to(torch.int32)
     return to_i32(words), to_i32(sz)
 

@@ -85,7 +85,10 @@ def test_awq_repack_oracle_round_trips_to_golden_dequant(case, golden):
                 + 8 * torch.arange(4).view(1, 1, 4, 1, 1) + e).expand_as(q)
         cols = (16 * torch.arange(n // 16).view(-1, 1, 1, 1, 1) + torch.arange(16).view(1, 1, 1, 16, 1)).expand_as(q)
         w[rows.reshape(-1), cols.reshape(-1)] = q.reshape(-1).float()
-    z = (sz >> 16).float().repeat_interleave(g, dim=0)
+    if c["scales"].dtype == torch.float16:   # the upper half is the f16 constant -(1024 + z) the kernel subtracts
+        hi = (sz >> 16).to(torch.int16).view(torch.float16).double()
+        assert torch.equal(hi, -(1024.0 + ((sz >> 16) & 0xF).double()))
+    z = ((sz >> 16) & 0xF).float().repeat_interleave(g, dim=0)
     sc = (sz & 0xFFFF).to(torch.int16).view(c["scales"].dtype).float().repeat_interleave(g, dim=0)
     deq = ((w - z) * sc).to(c["scales"].dtype)
     assert np.array_equal(_cases.bits16(deq), golden("quant")[case["name"] + ".deq"])
