@@ -102,9 +102,12 @@ __global__ __launch_bounds__(512) void stream_k(const char* __restrict__ w, int 
   }
 }
 
-int main() {
+int main(int argc, char** argv) {
   const int N = 32;
-  const size_t sizes_mb[] = {17, 25, 59, 117};
+  // default: the 8B decode streams; `./l2_warm shard` = the TP-8 shard streams (2 / 3 / 7 / 15 MB: the whole weight fits the L2 slice of
+  // its consumers, so the prefetch variants cover ALL of it)
+  const bool shard = argc > 1 && argv[1][0] == 's';
+  std::vector<size_t> sizes_mb = shard ? std::vector<size_t>{2, 3, 7, 15} : std::vector<size_t>{17, 25, 59, 117};
   hipStream_t st; hipStreamCreate(&st);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   u32x4* x; uint32_t *rout, *sout, *xlog;
@@ -118,8 +121,9 @@ int main() {
     for (auto& p : w) { hipMalloc(&p, bytes); hipMemset(p, 1, bytes); }
     struct V { const char* name; int grid; int map; int pf_mb; };
     std::vector<V> vs = {{"base: row grid 32            ", 32, 0, 0}, {"idle: row grid 256, no loads ", 256, 0, 0}};
-    for (int pf : {4, 8}) if ((size_t)pf <= mb) vs.push_back({"prefetch same XCD class      ", 256, 1, pf});
-    vs.push_back({"prefetch XCD class + 4       ", 256, 2, 8});
+    if (shard) vs.push_back({"prefetch same XCD class (all)", 256, 1, (int)mb});
+    else for (int pf : {4, 8}) if ((size_t)pf <= mb) vs.push_back({"prefetch same XCD class      ", 256, 1, pf});
+    vs.push_back({"prefetch XCD class + 4       ", 256, 2, shard ? (int)mb : 8});
     vs.push_back({"TLB touch, stride 4 KiB      ", 256, 3, (int)mb});
     vs.push_back({"TLB touch, stride 64 KiB     ", 256, 7, (int)mb});
     vs.push_back({"TLB touch, stride 2 MiB      ", 256, 12, (int)mb});
