@@ -94,8 +94,11 @@ int sgl_mi355_decode_attention_cascade(const void* q, int64_t q_stride_t, const 
                                        float logit_cap, int dtype, int kv_dtype, float k_scale, float v_scale,
                                        int32_t* merge_counters, void* out_o, void* out_q, float* out_s, void* stream);
 
-/* Measurement hook: 1 (default) = every wave owns one (request, kv head, split) unit; 0 = the first design, a
- * 4-wave workgroup sharing one split with an LDS merge. */
+/* Kernel form of the MFMA decode path.  0 (default) = the waves of a workgroup share one (request, kv head, split) and merge in
+ * LDS: four waves per workgroup, or eight (one 512-thread workgroup per CU, round 4) when the launch has at most one (request,
+ * kv head, head chunk) unit per two CUs -- sgl_mi355_decode_metadata's balance rule (static_splits = 2) applies the same test and then
+ * sizes the splits for one workgroup per CU; 1 = every wave owns one unit (no LDS merge; 1 kv head per rank); measurement hooks:
+ * 2 = always four waves, 3 = always eight. */
 int sgl_mi355_decode_attention_set_mode(int mode);
 
 /* Kernel choice of sgl_mi355_extend_attention for 16-bit K/V, D = 128, no mask / cap / cascade (all forms implement

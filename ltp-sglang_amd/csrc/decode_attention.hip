@@ -177,7 +177,7 @@ __device__ __forceinline__ void cvt16_fp8(const u32x4_t& in, u32x4_t& lo, u32x4_
 // (shared-prefix) decode, a form of MODE 0 whose split 0 starts from the prefix state (DecodeParams::prefix_*) -- its own
 // instantiation, so the extra code stays out of the ordinary one.
 template <typename T, int D, int NW, int MODE, int KVB = 2, int CASC = 0>
-__global__ __launch_bounds__(NW * 64, 2) void decode_attn_stage1(const DecodeParams p) {
+__global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void decode_attn_stage1(const DecodeParams p) {
   using Tr = ElemTraits<T>;
   using vec8 = typename Tr::vec8;
   constexpr int ROWB = D * 2;
@@ -593,7 +593,23 @@ __global__ __launch_bounds__(128) void decode_attn_stage2(const DecodeParams p) 
   }
 }
 
-int g_decode_mode = 0;  // 0 = workgroup-shared split (default: faster at batch 32), 1 = wave-per-unit (faster for 1 kv head per rank)
+// 0 = workgroup-shared split, four waves per workgroup -- or EIGHT (one 512-thread workgroup per CU, round 4) when the launch has
+//     at most one (request, kv head, head chunk) unit per TWO CUs: half as many splits fill the chip, so the in-launch merge reads
+//     half as many partials (sgl_mi355_decode_metadata's balance rule makes the same test and sizes the splits for one workgroup
+//     per CU).  Measured on whole decode steps (profiles/round4_ab_attn_eight_waves.json): batch 8 / 16 -0.6 / -0.8 %; with one
+//     unit per CU (batch 32: every request ONE split) +1.6 %, at batch 24 (1.5 rounds of 512-thread workgroups) +1.4 % -- hence
+//     the factor two;
+// 1 = wave-per-unit (faster for 1 kv head per rank); 2 / 3 = measurement hooks: always four / always eight waves
+int g_decode_mode = 0;
+int decode_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+  }
+  return cus;
+}
 
 template <typename T, int D, int KVB>
 int launch_mfma(const DecodeParams& p, hipStream_t st) {
@@ -608,7 +624,17 @@ int launch_mfma(const DecodeParams& p, hipStream_t st) {
     }
     dim3 grid(p.hkv * hchunks, p.bs, p.max_kv_splits - p.prefix_splits);
     hipLaunchKernelGGL((decode_attn_stage1<T, D, NW, 0, KVB, 2>), grid, dim3(NW * 64), smem, st, p);
-  } else if (g_decode_mode == 0) {
+  } else if (g_decode_mode == 3 || (g_decode_mode == 0 && 2ll * p.hkv * hchunks * p.bs <= decode_cus())) {
+    constexpr int NW = 8;
+    constexpr int smem = NW * 2 * kTile * D * 2;   // 128 KiB at D = 128: one workgroup per CU
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)decode_attn_stage1<T, D, NW, 0, KVB>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+      attr_set = true;
+    }
+    dim3 grid(p.hkv * hchunks, p.bs, p.max_kv_splits);
+    hipLaunchKernelGGL((decode_attn_stage1<T, D, NW, 0, KVB>), grid, dim3(NW * 64), smem, st, p);
+  } else if (g_decode_mode != 1) {
     constexpr int NW = 4;
     constexpr int smem = NW * 2 * kTile * D * 2;
     static bool attr_set = false;
@@ -666,7 +692,7 @@ extern "C" int sgl_mi355_decode_attention_debug_timeline(long long* buf) {
 #endif
 
 extern "C" int sgl_mi355_decode_attention_set_mode(int mode) {
-  g_decode_mode = mode ? 1 : 0;
+  g_decode_mode = (mode >= 0 && mode <= 3) ? mode : 0;
   return SGL_MI355_OK;
 }
 
@@ -723,14 +749,14 @@ static int decode_entry(
   p.merge_cnt = merge_cnt; p.mq_o = mq_o; p.mq_q = mq_q; p.mq_s = mq_s;
   p.prefix_len = prefix_len; p.prefix_splits = prefix_splits;
   if (prefix_splits > 0) {
-    SGL_CHECK(head_dim == v_head_dim && (head_dim == 128 || head_dim == 64) && g_decode_mode == 0,
+    SGL_CHECK(head_dim == v_head_dim && (head_dim == 128 || head_dim == 64) && g_decode_mode != 1,
               "decode_attention_cascade: needs the MFMA kernel (head_dim 64 / 128) in its workgroup-per-split mode");
     SGL_CHECK(prefix_len > 0 && prefix_splits < max_kv_splits,
               "decode_attention_cascade: prefix_len=%d, prefix_splits=%d must be positive and leave split slots for the suffix (max_kv_splits=%d)",
               prefix_len, prefix_splits, max_kv_splits);
   }
   if (merge_cnt != nullptr) {
-    SGL_CHECK(head_dim == v_head_dim && (head_dim == 128 || head_dim == 64) && g_decode_mode == 0,
+    SGL_CHECK(head_dim == v_head_dim && (head_dim == 128 || head_dim == 64) && g_decode_mode != 1,
               "decode_attention_merge_quant: needs the MFMA kernel (head_dim 64 / 128) in its workgroup-per-split mode");
     SGL_CHECK((mq_o || mq_q) && (!mq_q || mq_s) && (num_q_heads * v_head_dim) % 8 == 0 && num_q_heads * v_head_dim <= 16384,
               "decode_attention_merge_quant: bad outputs or Hq*Dv=%d", num_q_heads * v_head_dim);

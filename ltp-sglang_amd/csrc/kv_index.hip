@@ -153,7 +153,9 @@ __global__ __launch_bounds__(1024) void decode_meta_kernel(int32_t* kv_indptr, i
     for (int w = 0; w < 16; ++w) tot += scan[w];
     const int kv_group = num_head / num_kv_head;
     const int64_t units = (int64_t)num_kv_head * ((kv_group + 15) / 16) * num_group;
-    const int64_t target_wgs = 2ll * device_core_count;
+    // (round 4) at most one unit per two CUs: the kernel runs ONE 512-thread workgroup per CU (csrc/decode_attention.hip launch_mfma
+    // makes the same test), so half as many splits fill the chip
+    const int64_t target_wgs = (2 * units * num_seq <= device_core_count ? 1ll : 2ll) * device_core_count;
     int64_t T = (tot * units + target_wgs - 1) / target_wgs;
     T = (T + 31) / 32 * 32;
     if (T < 64) T = 64;

@@ -12,6 +12,23 @@ import torch
 import _cases
 from oracle import attention as oa
 
+
+@pytest.fixture(autouse=True, params=["auto", "four_waves", "eight_waves"])
+def _decode_workgroup_form(request):
+    """Every test of this file runs under the launcher's own choice and with each workgroup form forced (round 4: eight waves per
+    workgroup when a launch has at most one unit per CU, four otherwise -- sgl_mi355_decode_attention_set_mode 0 / 2 / 3): the small
+    parity cases would otherwise only ever see the eight-wave form."""
+    import torch as _t
+    if not _t.cuda.is_available():
+        yield
+        return
+    from __graft_entry__ import load_package
+    load_package()
+    from ltp_sglang_amd import _cabi
+    _cabi.check(_cabi.lib.sgl_mi355_decode_attention_set_mode({"auto": 0, "four_waves": 2, "eight_waves": 3}[request.param]))
+    yield
+    _cabi.lib.sgl_mi355_decode_attention_set_mode(0)
+
 pytestmark = pytest.mark.gpu
 
 TOL_F64 = {torch.bfloat16: 2e-2, torch.float16: 3e-3}
@@ -127,7 +144,7 @@ def test_decode_baseline_shape_properties(pkg):
         sgl_kernel.decode_attention_fwd(qd, kd, vd, o, kv_indptr.to(dev), kv_indices.to(dev), logits, lse,
                                         torch.full((bs,), ns, dtype=torch.int32, device=dev), 16, d ** -0.5)
         outs.append(o.float().cpu())
-    assert (outs[0] - outs[1]).abs().max().item() <= 1.6e-2
+    assert max((outs[0] - o_).abs().max().item() for o_ in outs[1:]) <= 1.6e-2
     assert (outs[0] - outs[2]).abs().max().item() <= 1.6e-2
     # (b) one-hot V: output = probability mass per (slot mod D); rows sum to 1
     onehot = torch.zeros(pool, hkv, d, dtype=torch.bfloat16)
@@ -302,7 +319,7 @@ def test_decode_config5_shard_shape_bs128_ragged(pkg):
     sgl_kernel.create_kv_indices(r2t.to(dev), rpi.to(dev), seq.to(dev), kv_indptr, None, kv_indices)
     assert int(kv_indptr[-1]) == total and int(nsplit.min()) >= 1 and int(nsplit.max()) <= 16
     outs = []
-    for mode in (0, 1):
+    for mode in (0, 1, 2, 3):
         _cabi.check(_cabi.lib.sgl_mi355_decode_attention_set_mode(mode))
         try:
             o = torch.full((bs, hq, d), float("nan"), dtype=torch.bfloat16, device=dev)
@@ -314,7 +331,7 @@ def test_decode_config5_shard_shape_bs128_ragged(pkg):
             _cabi.lib.sgl_mi355_decode_attention_set_mode(0)
         outs.append(o.float().cpu())
         assert torch.isfinite(outs[-1]).all()
-    assert (outs[0] - outs[1]).abs().max().item() <= 1.6e-2
+    assert max((outs[0] - o_).abs().max().item() for o_ in outs[1:]) <= 1.6e-2
     sample = sorted({int(seq.argmin()), int(seq.argmax()), 17, 101})
     for b in sample:
         ref = oa.decode_attention_f64(q[b:b + 1], k, v, r2t, rpi[b:b + 1], seq[b:b + 1], d ** -0.5)

@@ -53,7 +53,7 @@ def _quantise_pool(c, k_scale, v_scale):
 
 
 @pytest.mark.parametrize("dtype,d,scales", [("bf16", 128, (1.0, 1.0)), ("f16", 128, (0.25, 1.5)), ("bf16", 64, (2.0, 0.5))])
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
 def test_decode_attention_fp8_pool_vs_oracle(dtype, d, scales, mode, pkg):
     from ltp_sglang_amd import _cabi, sgl_kernel
 
