@@ -251,7 +251,10 @@ int sgl_mi355_fp8_gemm_tile_choice(int M, int N, int K, int64_t workspace_floats
 int sgl_mi355_fp8_gemm_slabs(const void* x, int64_t x_stride_elems, const void* w, int64_t w_stride_elems, float* slabs, int M,
                              int N, int K, int64_t workspace_floats, void* stream);
 /* (workspace: optional f32 scratch for split-K when a launch has fewer 128x128 output tiles than half the CUs -- decode at
- * 64 < M <= 256, the continuous-batching regime, where the weights are streamed once; NULL disables it) */
+ * 64 < M <= 256, the continuous-batching regime, where the weights are streamed once; NULL disables it)
+ * Round 4: workspaces of at least 4096 floats also lend their LAST 512 words to the persistent 256x256 kernel as 64 eight-word
+ * ticket slots (dynamic per-XCD tile schedule; taken round robin, zeroed by the launcher).  A workspace is this call's scratch: one
+ * workspace must not serve GEMMs of two streams at the same time (the split-K slabs at its head would collide). */
 /* Unquantised bf16/f16 linear for M > 64 (UnquantizedLinearMethod.apply, layers/quantization/unquant.py);
  * also the matmul half of AWQLinearMethod.apply (layers/quantization/awq.py:401-418). */
 int sgl_mi355_dense_gemm(const void* x, int64_t x_stride_elems, const void* w, int64_t w_stride_elems, void* y,
@@ -314,8 +317,8 @@ int sgl_mi355_fp8_qkv_rope_set_kv(const void* x, int64_t x_stride_elems, const v
 int sgl_mi355_gemm_silu_mul(const void* x, int64_t x_stride_elems, const void* w_interleaved, int64_t w_stride_elems, void* act,
                             int64_t act_stride_elems, const float* scales_x, const float* scales_w_interleaved, int M, int N,
                             int K, int in_dtype, int out_dtype, int tile_rows, void* stream);
-/* sgl_mi355_gemm_silu_mul with per-launch scratch: sched = 16 int32 words of device memory that no other launch in flight uses (one
- * buffer per stream suffices).  With it the M > 64 (prefill) form runs the persistent 256 x 256 kernel on a dynamic per-XCD tile
+/* sgl_mi355_gemm_silu_mul with per-launch scratch: sched = 8 int32 words (32-byte aligned is best) of device memory that no other launch
+ * in flight uses (one buffer per stream suffices; the Python wrapper rotates over 64 slots).  With it the M > 64 (prefill) form runs the persistent 256 x 256 kernel on a dynamic per-XCD tile
  * schedule -- the same bits; NULL: exactly sgl_mi355_gemm_silu_mul.  (models/llama.py:94-98 at prefill sizes.) */
 int sgl_mi355_gemm_silu_mul_ws(const void* x, int64_t x_stride_elems, const void* w_interleaved, int64_t w_stride_elems, void* act,
                                int64_t act_stride_elems, const float* scales_x, const float* scales_w_interleaved, int M, int N,

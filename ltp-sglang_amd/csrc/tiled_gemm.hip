@@ -1291,9 +1291,14 @@ int run(const void* x, int64_t xs, const void* w, int64_t ws, void* y, int64_t y
   p.sx = sx; p.sw = sw; p.bias = bias;
   p.M = M; p.N = N; p.kbytes = K * es;
   hipStream_t st = (hipStream_t)stream;
-  // per-launch tile counters of the persistent kernel's dynamic schedule: the LAST 16 words of the caller's workspace (this call's
-  // scratch for the duration of the call, like the split-K slabs the other tiles put at its head; zeroed by the launcher)
-  int* sched = (workspace != nullptr && workspace_floats >= 4096) ? (int*)(workspace + workspace_floats - 16) : nullptr;
+  // per-launch tile counters of the persistent kernel's dynamic schedule: one of 64 eight-word slots in the LAST 512 words of the
+  // caller's workspace, taken round robin (zeroed by the launcher's memset node) -- launches that overlap on two streams of a process
+  // therefore do not share tickets unless 64 further persistent GEMMs were launched in between (the split-K slabs at the workspace's
+  // head have no such ring: one workspace must not serve two streams at once, include/sgl_mi355.h)
+  static std::atomic<unsigned> sched_slot{0};
+  int* sched = (workspace != nullptr && workspace_floats >= 4096)
+                   ? (int*)(workspace + workspace_floats - 512) + 8 * (sched_slot.fetch_add(1, std::memory_order_relaxed) & 63u)
+                   : nullptr;
   if (in_dtype == SGL_FP8_E4M3) {
     // both LDS-DMA kernels want whole 128-byte K slices
     const bool can256 = p.kbytes % BKB == 0 && p.kbytes >= BKB && (int64_t)N * p.w_stride < 0xFFFFFFF0ll &&

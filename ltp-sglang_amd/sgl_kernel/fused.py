@@ -5,7 +5,6 @@ from typing import Optional, Tuple
 import torch
 
 from .._cabi import check, current_stream, dtype_code, lib, ptr
-from .gemm import _workspace
 
 
 def fused_add_rmsnorm_quant_fp8(x: Optional[torch.Tensor], residual: Optional[torch.Tensor], weight: torch.Tensor, eps: float,
@@ -84,6 +83,8 @@ def interleave_rope_rows(t: torch.Tensor, num_q_heads: int, num_kv_heads: int, h
 
 
 _SILU_TABLE_READY = set()   # device indices whose silu table has been filled AND waited for
+_TILE_TICKETS = {}          # device index -> [64, 8] int32: ticket-word slots of sgl_mi355_gemm_silu_mul_ws, taken round robin
+_TILE_TICKET_NEXT = [0]
 
 
 def silu_table_init(device) -> None:
@@ -98,6 +99,8 @@ def silu_table_init(device) -> None:
                            "run the op (or sgl_kernel.silu_table_init) once eagerly first")
     with torch.cuda.device(idx):
         check(lib.sgl_mi355_silu_table_init(current_stream()))
+        # (allocated here, i.e. never under capture: the ticket words of the prefill form's dynamic tile schedule)
+        _TILE_TICKETS[idx] = torch.zeros((64, 8), dtype=torch.int32, device=f"cuda:{idx}")
         torch.cuda.synchronize(idx)
     _SILU_TABLE_READY.add(idx)
 
@@ -109,9 +112,11 @@ def fp8_gemm_silu_mul(x_q, x_s, w_interleaved_nk, w_s_interleaved, out_dtype, ti
     act = torch.empty((m, n // 2), dtype=out_dtype, device=x_q.device)
     if m > 64:
         silu_table_init(x_q.device)
-        # prefill sizes: the persistent kernel's ticket counters = the last 16 words of the per-device GEMM scratch (gemm._workspace)
-        ws, ws_n = _workspace(x_q.device, 4096)
-        sched = ws[ws_n - 16:]
+        # prefill sizes: the persistent kernel's ticket words -- one of 64 slots, round robin, so that launches overlapping on two
+        # streams do not share them (the launcher zeroes the slot with a memset node; a captured launch keeps the slot it drew)
+        idx = x_q.device.index if x_q.device.index is not None else torch.cuda.current_device()
+        slot = _TILE_TICKET_NEXT[0] = (_TILE_TICKET_NEXT[0] + 1) & 63
+        sched = _TILE_TICKETS[idx][slot]
         st = current_stream()
         check(lib.sgl_mi355_gemm_silu_mul_ws(ptr(x_q), x_q.stride(0), ptr(w_interleaved_nk), w_interleaved_nk.stride(0), ptr(act),
                                              act.stride(0), ptr(x_s), ptr(w_s_interleaved), m, n, k, dtype_code(x_q.dtype),

@@ -15,7 +15,7 @@ WORKSPACE_FLOATS = 1 << 25  # 128 MiB: 4 k-ranges x 64 rows x 128 256 columns (7
 
 def _workspace(device, need: int):
     """The per-device f32 scratch shared by the skinny, tiled and AWQ GEMMs: split-K slabs at its head, the persistent tile
-    kernel's ticket counters in its last 16 words.  ONE per device, not per stream (torch.cuda.graph captures on a fresh side
+    kernel's 64 ticket slots in its last 512 words.  ONE per device, not per stream (torch.cuda.graph captures on a fresh side
     stream each time: a per-stream buffer would be allocated -- and zero-filled -- inside every captured graph), so GEMMs of two
     streams of one process must not run side by side; the model runner and the bench use one stream per process.
 
@@ -27,7 +27,7 @@ def _workspace(device, need: int):
     if buf is None or buf.numel() < need:
         if buf is not None:
             _RETIRED.append(buf)
-        # (the last 16 words are the persistent tile kernel's ticket counters, zeroed by its launcher before every launch)
+        # (the last 512 words are the persistent tile kernel's ticket slots, zeroed by its launcher before every launch)
         buf = torch.zeros(max(int(need), WORKSPACE_FLOATS), dtype=torch.float32, device=device)
         _WORKSPACES[device] = buf
     return buf, buf.numel()

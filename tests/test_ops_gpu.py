@@ -705,6 +705,33 @@ def test_persistent_256_kernel_dynamic_tile_schedule_same_bits(m, n, k, sk):
     torch.testing.assert_close(outs[4002][0].cpu().float(), ref.float(), rtol=1.6e-2, atol=0.3)
 
 
+def test_persistent_gemm_ticket_slots_on_two_streams(sk):
+    """The ticket words of the dynamic tile schedule are one of 64 slots taken round robin (workspace tail for fp8_scaled_mm /
+    dense_linear, the wrapper's own ring for fp8_gemm_silu_mul): persistent GEMMs launched alternately on TWO streams, with nothing
+    ordering them, give the bits of the serial runs."""
+    m, n, k = 8192, 4096, 512
+    c = _cases.build_gemm_case(dict(m=m, n=n, k=k, bias=False, out="bf16"), seed=77)
+    a, wt, sa, sb = (c[x].to(DEV) for x in ("a", "w", "sa", "sb"))
+    c2 = _cases.build_gemm_case(dict(m=m, n=2 * n, k=k, bias=False, out="bf16"), seed=78)
+    a2, wt2, sa2, sb2 = (c2[x].to(DEV) for x in ("a", "w", "sa", "sb"))
+    wi = sk.interleave_gate_up_rows(wt2.view(torch.uint8), 16).view(torch.float8_e4m3fn)
+    sbi = sk.interleave_gate_up_rows(sb2, 16)
+    ref1 = sk.fp8_scaled_mm(a, wt.t(), sa, sb, torch.bfloat16)
+    ref2 = sk.fp8_gemm_silu_mul(a2, sa2, wi, sbi, torch.bfloat16, 16)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs1, outs2 = [], []
+    for _ in range(6):
+        with torch.cuda.stream(s1):
+            outs1.append(sk.fp8_scaled_mm(a, wt.t(), sa, sb, torch.bfloat16))
+            outs2.append(sk.fp8_gemm_silu_mul(a2, sa2, wi, sbi, torch.bfloat16, 16))
+        with torch.cuda.stream(s2):
+            outs2.append(sk.fp8_gemm_silu_mul(a2, sa2, wi, sbi, torch.bfloat16, 16))
+            outs1.append(sk.fp8_scaled_mm(a, wt.t(), sa, sb, torch.bfloat16))
+    torch.cuda.synchronize()
+    assert all(torch.equal(o, ref1) for o in outs1) and all(torch.equal(o, ref2) for o in outs2)
+
+
 @pytest.mark.parametrize("m,n,k", [(8192, 8192, 512), (4100, 8704, 384)])
 def test_gemm_silu_mul_ws_dynamic_schedule_same_bits(m, n, k, sk):
     """sgl_mi355_gemm_silu_mul_ws (round 4): gate_up + SiluAndMul on the persistent kernel with the dynamic tile schedule when the
