@@ -473,6 +473,14 @@ int sgl_mi355_car_all_reduce_add_rmsnorm_quant_algo(const void* partial, void* r
                                                     void* out_norm, void* out_q, float* out_s, int rows, int hidden, int dtype,
                                                     const void* const* peer_bufs, int rank, int world, int64_t max_bytes,
                                                     int algo, void* stream);
+/* The same with this rank's operand given as the split-K slabs of its row-parallel GEMM (raw f32 accumulators [nslabs][rows][hidden]
+ * from sgl_mi355_fp8_gemm_slabs / sgl_mi355_skinny_gemm_slabs_min) and the GEMM's scale vectors (NULL: none): the kernel forms
+ * x = T((slab 0 + slab 1 + ...) * slab_sx[row] * slab_sw[col]) while it publishes the row, so the GEMM's reduce launch and its
+ * [rows, hidden] round trip go away (round 4).  Bit-identical to that launch followed by the entry point above. */
+int sgl_mi355_car_all_reduce_add_rmsnorm_quant_slabs(const float* slabs, int nslabs, const float* slab_sx, const float* slab_sw,
+                                                     void* residual, const void* weight, float eps, void* out_norm, void* out_q,
+                                                     float* out_s, int rows, int hidden, int dtype, const void* const* peer_bufs,
+                                                     int rank, int world, int64_t max_bytes, int algo, void* stream);
 /* all-gather along the last dimension with the same buffers and protocol (the logits all-gather of a vocab-sharded lm_head,
  * python/sglang/srt/layers/logits_processor.py:471-500): out [rows, world * row_bytes] <- rank r's in [rows, row_bytes] */
 int sgl_mi355_car_all_gather(const void* in, void* out, int64_t rows, int64_t row_bytes, const void* const* peer_bufs, int rank,

@@ -182,7 +182,11 @@ __global__ __launch_bounds__(kThreads) void one_shot_all_reduce_kernel(const Car
 // result is bit-identical to the unfused pair; what it removes is one launch and one [M, hidden] round trip per all-reduce site.
 struct CarNormParams {
   char* buf[kMaxRanks];
-  const void* partial;   // [rows, hidden] T: this rank's partial sums
+  const void* partial;   // [rows, hidden] T: this rank's partial sums -- or NULL and the next four (round 4):
+  const float* slabs;    // [nslabs][rows][hidden] f32 split-K partial sums of this rank's GEMM (raw accumulators, no scales yet)
+  int nslabs;            // the kernel forms x = T((slab 0 + slab 1 + ...) * slab_sx[row] * slab_sw[col]) -- add_rmsnorm_quant_kernel's
+  const float* slab_sx;  // [rows] or NULL     slab path, i.e. what the GEMM's own reduce launch would have written -- while it
+  const float* slab_sw;  // [hidden] or NULL   publishes the row, so that launch and its [rows, hidden] round trip go away
   void* residual;        // [rows, hidden] T, updated in place (may be NULL: no residual add)
   const void* weight;    // [hidden] T
   void* out_norm;        // optional [rows, hidden] T
@@ -193,6 +197,30 @@ struct CarNormParams {
   float eps;
   int rank, world;
 };
+
+// packet i (8 elements) of row `row` of this rank's operand: from `partial`, or formed from the split-K slabs
+template <typename T>
+__device__ __forceinline__ u32x4_t car_operand_packet(const CarNormParams& p, int row, int nvec, int i) {
+  if (p.slabs == nullptr) return *((const u32x4_t*)p.partial + (int64_t)row * nvec + i);
+  const int64_t plane = (int64_t)p.rows * p.hidden;
+  const float* sp = p.slabs + (int64_t)row * p.hidden + i * 8;
+  float f[8];
+  {
+    const f32x4_t a0 = *(const f32x4_t*)sp, a1 = *(const f32x4_t*)(sp + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { f[j] = a0[j]; f[4 + j] = a1[j]; }
+  }
+  for (int sI = 1; sI < p.nslabs; ++sI) {   // ascending slab order: add_rmsnorm_quant_kernel's
+    const f32x4_t a0 = *(const f32x4_t*)(sp + sI * plane), a1 = *(const f32x4_t*)(sp + sI * plane + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { f[j] += a0[j]; f[4 + j] += a1[j]; }
+  }
+  const float sxm = p.slab_sx ? p.slab_sx[row] : 1.0f;
+  V8<T> o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o.v[j] = (T)round_via<T>(f[j] * sxm * (p.slab_sw ? p.slab_sw[i * 8 + j] : 1.0f));
+  return __builtin_bit_cast(u32x4_t, o);
+}
 
 template <typename T, int MAXV>
 __global__ __launch_bounds__(256) void all_reduce_add_rmsnorm_quant_kernel(const CarNormParams p) {
@@ -208,7 +236,7 @@ __global__ __launch_bounds__(256) void all_reduce_add_rmsnorm_quant_kernel(const
 #pragma unroll
     for (int it = 0; it < MAXV; ++it) {
       const int i = tid + it * 256;
-      if (i < nvec) store_sys(p.buf[p.rank], half + ((int64_t)row * nvec + i) * 16, *((const u32x4_t*)p.partial + (int64_t)row * nvec + i));
+      if (i < nvec) store_sys(p.buf[p.rank], half + ((int64_t)row * nvec + i) * 16, car_operand_packet<T>(p, row, nvec, i));
     }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -344,7 +372,7 @@ __global__ __launch_bounds__(256) void two_stage_all_reduce_add_rmsnorm_quant_ke
 #pragma unroll
         for (int it = 0; it < MAXV; ++it) {
           const int i = tid + it * 256;
-          if (i < nvec) store_sys(p.buf[p.rank], in_half + ((int64_t)row * nvec + i) * 16, *((const u32x4_t*)p.partial + (int64_t)row * nvec + i));
+          if (i < nvec) store_sys(p.buf[p.rank], in_half + ((int64_t)row * nvec + i) * 16, car_operand_packet<T>(p, row, nvec, i));
         }
       }
     }
@@ -608,21 +636,23 @@ extern "C" int sgl_mi355_car_all_gather(const void* in, void* out, int64_t rows,
 // hidden % 8 == 0, hidden <= 8192.
 // algo as for sgl_mi355_car_all_reduce_algo (two-stage needs hidden % 16 == 0, else the one-shot form is taken).  On one
 // communicator every fused call must use the same `hidden` (the row -> block map of the no-closing-barrier protocol).
-extern "C" int sgl_mi355_car_all_reduce_add_rmsnorm_quant_algo(const void* partial, void* residual, const void* weight, float eps,
-                                                               void* out_norm, void* out_q, float* out_s, int rows, int hidden,
-                                                               int dtype, const void* const* peer_bufs, int rank, int world,
-                                                               int64_t max_bytes, int algo, void* stream) {
-  SGL_CHECK(partial && weight && peer_bufs && (out_norm || out_q) && (!out_q || out_s), "car_all_reduce_add_rmsnorm_quant: null pointer");
+static int car_fused_impl(const void* partial, const float* slabs, int nslabs, const float* slab_sx, const float* slab_sw, void* residual,
+                          const void* weight, float eps, void* out_norm, void* out_q, float* out_s, int rows, int hidden, int dtype,
+                          const void* const* peer_bufs, int rank, int world, int64_t max_bytes, int algo, void* stream) {
+  SGL_CHECK((partial != nullptr) != (slabs != nullptr), "car_all_reduce_add_rmsnorm_quant: exactly one of partial / slabs");
+  SGL_CHECK(slabs == nullptr || (nslabs >= 1 && nslabs <= 64 && ((uintptr_t)slabs % 16) == 0), "car_all_reduce_add_rmsnorm_quant: bad slabs (nslabs=%d)", nslabs);
+  SGL_CHECK(weight && peer_bufs && (out_norm || out_q) && (!out_q || out_s), "car_all_reduce_add_rmsnorm_quant: null pointer");
   SGL_CHECK(algo >= 0 && algo <= 2, "car_all_reduce_add_rmsnorm_quant: algo %d (0 = rule, 1 = one-shot, 2 = two-stage)", algo);
   SGL_CHECK(world >= 2 && world <= kMaxRanks && rank >= 0 && rank < world, "car_all_reduce_add_rmsnorm_quant: rank %d / world %d unsupported", rank, world);
   SGL_CHECK(dtype == SGL_BF16 || dtype == SGL_F16, "car_all_reduce_add_rmsnorm_quant: dtype must be bf16 or f16");
   SGL_CHECK(rows > 0 && hidden > 0 && hidden % 8 == 0 && hidden <= 8192 && (int64_t)rows * hidden * 2 <= max_bytes &&
-                ((uintptr_t)partial % 16) == 0,
+                (partial == nullptr || ((uintptr_t)partial % 16) == 0),
             "car_all_reduce_add_rmsnorm_quant: rows=%d hidden=%d unsupported (hidden %% 8, <= 8192, rows * hidden * 2 <= %lld)", rows,
             hidden, (long long)max_bytes);
   CarNormParams p;
   for (int r = 0; r < kMaxRanks; ++r) p.buf[r] = (char*)(r < world ? peer_bufs[r] : peer_bufs[0]);
   p.partial = partial; p.residual = residual; p.weight = weight; p.out_norm = out_norm; p.out_q = (uint8_t*)out_q; p.out_s = out_s;
+  p.slabs = slabs; p.nslabs = nslabs; p.slab_sx = slab_sx; p.slab_sw = slab_sw;
   p.half_bytes = max_bytes;
   p.rows = rows; p.hidden = hidden; p.eps = eps; p.rank = rank; p.world = world;
   hipStream_t st = (hipStream_t)stream;
@@ -651,6 +681,28 @@ extern "C" int sgl_mi355_car_all_reduce_add_rmsnorm_quant_algo(const void* parti
   }
   SGL_HIP_LAUNCH_CHECK();
   return SGL_MI355_OK;
+}
+
+extern "C" int sgl_mi355_car_all_reduce_add_rmsnorm_quant_algo(const void* partial, void* residual, const void* weight, float eps,
+                                                               void* out_norm, void* out_q, float* out_s, int rows, int hidden,
+                                                               int dtype, const void* const* peer_bufs, int rank, int world,
+                                                               int64_t max_bytes, int algo, void* stream) {
+  SGL_CHECK(partial, "car_all_reduce_add_rmsnorm_quant: null pointer");
+  return car_fused_impl(partial, nullptr, 0, nullptr, nullptr, residual, weight, eps, out_norm, out_q, out_s, rows, hidden, dtype, peer_bufs,
+                        rank, world, max_bytes, algo, stream);
+}
+
+// The same with this rank's operand given as the split-K slabs of its GEMM (sgl_mi355_fp8_gemm_slabs / skinny slabs: raw f32
+// accumulators [nslabs][rows][hidden]) and the GEMM's scale vectors: x = T((slab 0 + slab 1 + ...) * sx[row] * sw[col]) is formed while
+// the row is published -- bit-identical to the GEMM's reduce launch followed by the entry point above.
+extern "C" int sgl_mi355_car_all_reduce_add_rmsnorm_quant_slabs(const float* slabs, int nslabs, const float* slab_sx, const float* slab_sw,
+                                                                void* residual, const void* weight, float eps, void* out_norm,
+                                                                void* out_q, float* out_s, int rows, int hidden, int dtype,
+                                                                const void* const* peer_bufs, int rank, int world, int64_t max_bytes,
+                                                                int algo, void* stream) {
+  SGL_CHECK(slabs, "car_all_reduce_add_rmsnorm_quant_slabs: null pointer");
+  return car_fused_impl(nullptr, slabs, nslabs, slab_sx, slab_sw, residual, weight, eps, out_norm, out_q, out_s, rows, hidden, dtype,
+                        peer_bufs, rank, world, max_bytes, algo, stream);
 }
 
 extern "C" int sgl_mi355_car_all_reduce_add_rmsnorm_quant(const void* partial, void* residual, const void* weight, float eps,

@@ -73,12 +73,30 @@ def tensor_model_parallel_all_reduce(input_: torch.Tensor) -> torch.Tensor:
     return input_
 
 
-def tensor_model_parallel_all_reduce_add_rmsnorm_quant(partial, residual, weight, eps, want_norm=False, want_quant=True):
+def fused_all_reduce_takes_slabs(rows: int, hidden: int, dtype) -> bool:
+    """True when tensor_model_parallel_all_reduce_add_rmsnorm_quant can take the row-parallel GEMM's split-K slabs instead of its
+    reduced output (the P2P communicator's fused kernels, or the emulated-TP stand-in): the GEMM's reduce launch is then skipped."""
+    if _TP_SIZE <= 1:
+        return False
+    if _EMULATED:
+        return True
+    return _CUSTOM_AR is not None and hasattr(_CUSTOM_AR, "fused_norm_takes") and _CUSTOM_AR.fused_norm_takes(rows, hidden, dtype)
+
+
+def tensor_model_parallel_all_reduce_add_rmsnorm_quant(partial, residual, weight, eps, want_norm=False, want_quant=True,
+                                                       slabs=None, slab_sx=None, slab_sw=None, dtype=None):
     """The all-reduce of a row-parallel linear together with the fused add + RMSNorm (+ per-token fp8 quant) that consumes it
     on the decode path: one launch when the one-shot P2P communicator can take the message, the unfused pair otherwise (same
-    bits either way).  ``residual`` is updated in place.  Returns (y or None, y_q or None, y_scale or None)."""
+    bits either way).  ``residual`` is updated in place.  Returns (y or None, y_q or None, y_scale or None).
+    ``partial=None, slabs=...``: the operand as the GEMM's split-K partial sums (only where fused_all_reduce_takes_slabs says so)."""
     from ...sgl_kernel import fused_add_rmsnorm_quant_fp8
 
+    if partial is None:
+        if _EMULATED:   # stand-in: the consumer kernel sums the slabs, as the fused all-reduce kernel does on real ranks
+            return fused_add_rmsnorm_quant_fp8(None, residual, weight, eps, want_norm=want_norm, want_quant=want_quant, slabs=slabs,
+                                               slab_sx=slab_sx, slab_sw=slab_sw, dtype=dtype)
+        return _CUSTOM_AR.all_reduce_add_rmsnorm_quant(None, residual, weight, eps, want_norm, want_quant, slabs=slabs,
+                                                       slab_sx=slab_sx, slab_sw=slab_sw, dtype=dtype)
     if _TP_SIZE > 1 and not _EMULATED and _CUSTOM_AR is not None and _CUSTOM_AR.should_use_fused_norm(partial):
         return _CUSTOM_AR.all_reduce_add_rmsnorm_quant(partial, residual, weight, eps, want_norm, want_quant)
     if not _EMULATED:   # (emulated TP: the fused kernel's cost is the norm kernel's -- the stand-in copy is dropped with the launch)

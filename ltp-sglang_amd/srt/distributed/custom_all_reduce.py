@@ -153,11 +153,25 @@ class CustomAllreduce:
         return (self.should_use(partial) and partial.dim() == 2 and partial.dtype in (torch.bfloat16, torch.float16)
                 and partial.shape[1] % 8 == 0 and partial.shape[1] <= 8192)
 
-    def all_reduce_add_rmsnorm_quant(self, partial, residual, weight, eps, want_norm=False, want_quant=True, algo: int = 0):
+    def fused_norm_takes(self, rows: int, hidden: int, dtype) -> bool:
+        """should_use_fused_norm for an operand that does not exist as a tensor yet (the slab form)."""
+        return (not self.disabled and dtype in (torch.bfloat16, torch.float16) and hidden % 8 == 0 and hidden <= 8192
+                and 0 < rows * hidden * 2 <= self.max_size)
+
+    def all_reduce_add_rmsnorm_quant(self, partial, residual, weight, eps, want_norm=False, want_quant=True, algo: int = 0,
+                                     slabs=None, slab_sx=None, slab_sw=None, dtype=None):
         """all_reduce(partial) -> residual += . -> rmsnorm * weight -> per-token fp8 quant, ONE launch, bit-identical to the
         unfused pair.  Returns (y or None, y_q or None, y_scale [M, 1] or None); ``residual`` is updated in place.  ``algo`` as
-        for ``all_reduce`` (two-stage: the owner of a row finishes it once, the other ranks collect it)."""
-        m, h = partial.shape
+        for ``all_reduce`` (two-stage: the owner of a row finishes it once, the other ranks collect it).
+        ``partial=None, slabs=[S, M, H] f32`` (+ the GEMM's ``slab_sx`` [M] / ``slab_sw`` [H], ``dtype``): the operand is formed from
+        the split-K partial sums of this rank's GEMM inside the launch (sgl_mi355_car_all_reduce_add_rmsnorm_quant_slabs)."""
+        if partial is None:
+            assert slabs is not None and slabs.dtype == torch.float32 and slabs.dim() == 3 and slabs.is_contiguous() and dtype is not None
+            _, m, h = slabs.shape
+            out_dtype, dev = dtype, slabs.device
+        else:
+            m, h = partial.shape
+            out_dtype, dev = partial.dtype, partial.device
         if getattr(self, "_fused_hidden", h) != h:
             # The protocol has no closing barrier: block b may re-enter a data half because the peers' blocks b have left it,
             # which needs the row -> byte-range map of the fused family to stay the same from call to call.  It depends on
@@ -166,10 +180,17 @@ class CustomAllreduce:
             torch.cuda.synchronize(self.device)
             dist.barrier(group=self.group)
         self._fused_hidden = h
-        dev = partial.device
-        out_norm = torch.empty((m, h), dtype=partial.dtype, device=dev) if want_norm else None
+        out_norm = torch.empty((m, h), dtype=out_dtype, device=dev) if want_norm else None
         out_q = torch.empty((m, h), dtype=torch.float8_e4m3fn, device=dev) if want_quant else None
         out_s = torch.empty((m, 1), dtype=torch.float32, device=dev) if want_quant else None
+        if partial is None:
+            check(lib.sgl_mi355_car_all_reduce_add_rmsnorm_quant_slabs(
+                slabs.data_ptr(), int(slabs.shape[0]), None if slab_sx is None else slab_sx.data_ptr(),
+                None if slab_sw is None else slab_sw.data_ptr(), None if residual is None else residual.data_ptr(), weight.data_ptr(),
+                float(eps), None if out_norm is None else out_norm.data_ptr(), None if out_q is None else out_q.data_ptr(),
+                None if out_s is None else out_s.data_ptr(), m, h, dtype_code(out_dtype), self._ptrs, self.rank, self.world_size,
+                self.max_size, self._algo(algo), current_stream()))
+            return out_norm, out_q, out_s
         check(lib.sgl_mi355_car_all_reduce_add_rmsnorm_quant_algo(
             partial.data_ptr(), None if residual is None else residual.data_ptr(), weight.data_ptr(), float(eps),
             None if out_norm is None else out_norm.data_ptr(), None if out_q is None else out_q.data_ptr(),

@@ -288,7 +288,7 @@ class LlamaForCausalLM(nn.Module):
         sequence it replaces, so this path and forward() give the same logits.  Under tensor parallelism the two
         row-parallel outputs are materialised and all-reduced at the reference's call sites (linear.py:1302-1303); the
         split-K slab hand-off is a single-rank shortcut."""
-        from ..distributed.communication_op import (tensor_model_parallel_all_gather,
+        from ..distributed.communication_op import (fused_all_reduce_takes_slabs, tensor_model_parallel_all_gather,
                                                     tensor_model_parallel_all_reduce_add_rmsnorm_quant as ar_norm_quant)
 
         tp = self.tp_size
@@ -315,6 +315,9 @@ class LlamaForCausalLM(nn.Module):
                 # `hidden` is this rank's PARTIAL down_proj output: its all-reduce (linear.py:1302-1303) rides in the same
                 # launch as the add + RMSNorm + quant that consumes it (one-shot P2P communicator; else the unfused pair)
                 _, xq, xs = ar_norm_quant(hidden, residual, ln1.weight.data, ln1.variance_epsilon)
+            elif tp > 1:   # ... handed over as the GEMM's split-K partial sums: the fused all-reduce forms the operand itself (r4)
+                _, xq, xs = ar_norm_quant(None, residual, ln1.weight.data, ln1.variance_epsilon, slabs=slabs, slab_sx=slab_sx,
+                                          slab_sw=slab_sw, dtype=self.dtype)
             elif slabs is None:
                 _, xq, xs = K.fused_add_rmsnorm_quant_fp8(hidden, residual, ln1.weight.data, ln1.variance_epsilon)
             else:
@@ -361,6 +364,13 @@ class LlamaForCausalLM(nn.Module):
                                                  fw["mlp_down"], mlp_scratch, li)
                 slab_sw = mlp.down_proj.weight_scale.view(-1)
                 continue
+            elif (tp > 1 and K.fp8_gemm_num_slabs(m, wo.shape[1], wo.shape[0], wo.device) > 1
+                  and fused_all_reduce_takes_slabs(m, wo.shape[1], self.dtype)):
+                # tensor parallel, 64 < M <= 256: this rank's o_proj shard as split-K partial sums; the fused all-reduce forms its
+                # operand from them while it publishes the row (no reduce launch, no [M, hidden] round trip; bit-identical)
+                o_slabs = K.fp8_gemm_slabs(oq, wo.t())
+                _, hq2, hs2 = ar_norm_quant(None, residual, ln2.weight.data, ln2.variance_epsilon, slabs=o_slabs, slab_sx=osc.view(-1),
+                                            slab_sw=attn.o_proj.weight_scale.view(-1), dtype=self.dtype)
             else:
                 attn_out = K.fp8_scaled_mm(oq, wo, osc.view(-1), attn.o_proj.weight_scale.view(-1), self.dtype)
                 if tp > 1:   # partial sums: all-reduce + add + RMSNorm + quant in one launch
@@ -377,13 +387,17 @@ class LlamaForCausalLM(nn.Module):
             if tp == 1 and m <= 64:
                 slabs = K.fp8_linear_slabs(aq, wd.t(), m, wd.shape[1], wd.shape[0])
                 slab_sx, slab_sw = asc.view(-1), mlp.down_proj.weight_scale.view(-1)
-            elif tp == 1 and K.fp8_gemm_num_slabs(m, wd.shape[1], wd.shape[0], wd.device) > 1:
+            elif ((tp == 1 or fused_all_reduce_takes_slabs(m, wd.shape[1], self.dtype))
+                  and K.fp8_gemm_num_slabs(m, wd.shape[1], wd.shape[0], wd.device) > 1):
                 slabs = K.fp8_gemm_slabs(aq, wd.t())   # 64 < M <= 256: the streaming tile's partial sums, same hand-off
                 slab_sx, slab_sw = asc.view(-1), mlp.down_proj.weight_scale.view(-1)
             else:
                 slabs = None
                 hidden = K.fp8_scaled_mm(aq, wd, asc.view(-1), mlp.down_proj.weight_scale.view(-1), self.dtype)   # (tp > 1: partial)
-        if slabs is not None:
+        if slabs is not None and tp > 1:
+            hidden, _, _ = ar_norm_quant(None, residual, self.norm.weight.data, self.norm.variance_epsilon, want_norm=True,
+                                         want_quant=False, slabs=slabs, slab_sx=slab_sx, slab_sw=slab_sw, dtype=self.dtype)
+        elif slabs is not None:
             hidden, _, _ = K.fused_add_rmsnorm_quant_fp8(None, residual, self.norm.weight.data, self.norm.variance_epsilon,
                                                          slabs=slabs, slab_sx=slab_sx, slab_sw=slab_sw, want_norm=True,
                                                          want_quant=False, dtype=self.dtype)

@@ -171,6 +171,32 @@ def _worker(rank, world, port, q):
         yc, _, _ = comm.tensor_model_parallel_all_reduce_add_rmsnorm_quant(part.clone(), None, w, 1e-5, want_norm=True, want_quant=False)
         yd, _, _ = K.fused_add_rmsnorm_quant_fp8(summed, None, w, 1e-5, want_norm=True, want_quant=False)
         ok = ok and torch.equal(yc, yd)
+        # slab inputs (round 4): this rank's operand as the split-K partial sums of its GEMM + the GEMM's scale vectors -- the
+        # kernel forms x = T((s0 + s1 + s2) * sx[row] * sw[col]) while it publishes the row.  Same bits as handing it that x.
+        gs_ = torch.Generator().manual_seed(1000 + 17 * m + rank)
+        slabs = torch.randn(3, m, h, generator=gs_).to(dev)
+        sx = (0.5 + torch.rand(m, generator=gs_)).to(dev)
+        sw = (0.5 + torch.rand(h, generator=gs_)).to(dev)
+        acc = slabs[0] + slabs[1]
+        acc = acc + slabs[2]
+        x_ref = ((acc * sx[:, None]) * sw[None, :]).to(dtype)
+        for algo in (1, 2):
+            res_p, res_s = res0.clone(), res0.clone()
+            yp, qp, sp_ = car.all_reduce_add_rmsnorm_quant(x_ref.clone(), res_p, w, 1e-5, want_norm=True, want_quant=True, algo=algo)
+            ys, qs, ss_ = car.all_reduce_add_rmsnorm_quant(None, res_s, w, 1e-5, want_norm=True, want_quant=True, algo=algo,
+                                                           slabs=slabs, slab_sx=sx, slab_sw=sw, dtype=dtype)
+            car.check_error()
+            same3 = (torch.equal(yp, ys) and torch.equal(qp.view(torch.uint8), qs.view(torch.uint8)) and torch.equal(sp_, ss_)
+                     and torch.equal(res_p, res_s))
+            if not same3:
+                print(f"[rank {rank}] slab-input fused all-reduce differs at {(m, h)} {dtype} algo {algo}", flush=True)
+            ok = ok and same3
+        assert comm.fused_all_reduce_takes_slabs(m, h, dtype)
+        res_s = res0.clone()
+        yt, _, _ = comm.tensor_model_parallel_all_reduce_add_rmsnorm_quant(None, res_s, w, 1e-5, want_norm=True, want_quant=False, slabs=slabs,
+                                                                          slab_sx=sx, slab_sw=sw, dtype=dtype)
+        car.check_error()
+        ok = ok and torch.equal(yt, yp)
     # all-gather along the last dimension (the vocab-sharded logits), through the call site as well
     for shape in ((32, 16032), (3, 8), (128, 2048)):
         part = torch.randn(shape, generator=torch.Generator().manual_seed(7 + rank)).to(torch.bfloat16)
