@@ -344,8 +344,13 @@ def main():
     # (ids below 10 000 as bench_one_batch.py:215 draws them, and below the vocabulary: `--model tiny` has 2 048 rows -- round 4
     # found its lookups reading 8 MB past the embedding table, garbage that ended in a GPU fault one step later)
     ids = torch.from_numpy(np.random.RandomState(0).randint(0, min(10000, cfg.vocab_size), (bs, seq))).to(dev)
-    # untimed warm-up prefill (one short chunk: loads every prefill kernel's code object, sets the LDS attributes), undone
-    runner.extend([ids[i][: min(seq, 512)] for i in range(min(bs, args.prefill_chunk))])
+    # untimed warm-up prefill, undone: the SAME chunks at full length (bench_one_batch.py warms up with the batch it then measures) --
+    # it loads every prefill kernel's code object, sets the LDS attributes, and lets the caching allocator obtain the multi-GB
+    # activation buffers once.  (Round 4: with a 512-token warm-up the timed prefill made those first hipMallocs itself; one run of
+    # the round read 0.677 s where the runs around it read 0.46 s.)
+    for c0 in range(0, bs, args.prefill_chunk):
+        runner.extend([ids[i] for i in range(c0, min(bs, c0 + args.prefill_chunk))])
+    torch.cuda.synchronize()
     runner.clear()
     # the allocator hands out consecutive slots; a random permutation of the free list makes the gather non-contiguous
     alloc = runner.token_to_kv_pool_allocator
