@@ -42,6 +42,7 @@ def parse_args():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"], help="activation / KV dtype (AWQ checkpoints usually run f16)")
     ap.add_argument("--kv-cache-dtype", default="auto", choices=["auto", "fp8_e4m3"],
                     help="auto = the model dtype (the BASELINE configuration); fp8_e4m3 halves the KV stream (reported separately)")
+    ap.add_argument("--no-graph-metadata", action="store_true", help="measurement hook: keep the decode metadata launches outside the captured graph")
     ap.add_argument("--decode-attn-mode", type=int, default=-1, help="measurement hook: 0 / 1 = sgl_mi355_decode_attention_set_mode")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the measured configuration); gloo = rehearsal of the N > 1 path on fewer GPUs")
@@ -327,6 +328,8 @@ def main():
                                   max_kv_splits=args.max_kv_splits, kv_split_rule=args.kv_split_rule)
     if args.no_fused_decode:
         runner.model.fused_decode = False
+    if args.no_graph_metadata:
+        runner.graph_metadata = False
     kv_es = 1 if args.kv_cache_dtype == "fp8_e4m3" else 2
     tp = comm.get_tensor_model_parallel_world_size()
 

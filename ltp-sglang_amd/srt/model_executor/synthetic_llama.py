@@ -748,8 +748,15 @@ class SyntheticModelRunner:
                 self.model(buf.input_ids, buf.positions, fb)
         torch.cuda.current_stream().wait_stream(stream)
         graph = torch.cuda.CUDAGraph()
+        # The step's metadata launches (merge-counter reset, kv_indptr + split counts, kv_indices) read and write only the graph's
+        # static buffers, so they are captured WITH the step (round 4): three dependent launches inside the graph instead of three
+        # host launches between two replays.  Not for the cascade form (its metadata bakes in host-side lengths) or window layers.
+        buf.meta_in_graph = bool(getattr(self, "graph_metadata", True)) and int(shared_prefix_len) == 0 and not self.attn_backend._has_window()
         # thread_local: the RCCL watchdog thread of torch.distributed may touch the device while this thread captures (TP > 1)
         with torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
+            if buf.meta_in_graph:
+                self.attn_backend.init_forward_metadata_replay_cuda_graph(bs, buf.req_pool_indices, buf.seq_lens, bs, None,
+                                                                          ForwardMode.DECODE, None, None)
             buf.logits = self.model(buf.input_ids, buf.positions, fb)
         self._graphs[(bs, int(shared_prefix_len))] = (graph, buf)
         self.attn_backend.cascade_shared_prefix_len = 0
@@ -779,8 +786,9 @@ class SyntheticModelRunner:
                              buf.input_ids, buf.req_pool_indices, buf.seq_lens, buf.out_cache_loc, buf.positions)
             state.seq_lens_cpu = [s + 1 for s in state.seq_lens_cpu]
             seq_sum, seq_cpu = sum(state.seq_lens_cpu), None
-        self.attn_backend.init_forward_metadata_replay_cuda_graph(bs, buf.req_pool_indices, buf.seq_lens, seq_sum,
-                                                                  None, ForwardMode.DECODE, None, seq_cpu)
+        if not buf.meta_in_graph:
+            self.attn_backend.init_forward_metadata_replay_cuda_graph(bs, buf.req_pool_indices, buf.seq_lens, seq_sum,
+                                                                      None, ForwardMode.DECODE, None, seq_cpu)
         graph.replay()
         self.attn_backend.cascade_shared_prefix_len = 0
         return buf.logits
