@@ -16,56 +16,10 @@
 // registers with two xor-shuffles per row reduction -- the decode kernel's formulation with (head, position)
 // pairs in place of heads.  Workgroups of the same (request, kv head) are mapped to the same XCD so the K/V they
 // re-read stay in that XCD's L2.
-#include "common.h"
+#include "extend_params.h"
+#include <type_traits>
 
 namespace {
-
-struct ExtendParams {
-  const void* q;   // [T, Hq, D]
-  const void* ke;  // [T, Hkv, D]
-  const void* ve;  // [T, Hkv, D]
-  void* o;         // [T, Hq, D]
-  int64_t q_stride_t, ke_stride_t, ve_stride_t, o_stride_t;  // elements; heads contiguous (stride D)
-  const void* k_buf;
-  const void* v_buf;
-  int64_t k_stride_t, k_stride_h, v_stride_t, v_stride_h;
-  const int32_t* qo_indptr;   // [bs+1]
-  const int32_t* kv_indptr;   // [bs+1] prefix lengths cumsum
-  const int32_t* kv_indices;  // prefix slots
-  // alternative addressing (CPU op schema): prefix = req_to_token[req_pool_indices[b], :seq_lens[b]-ext]
-  const int32_t* req_to_token;
-  int64_t req_to_token_stride;
-  const int64_t* req_pool_indices;
-  const int64_t* seq_lens;
-  const int32_t* extend_seq_lens;
-  const int32_t* extend_start_loc;
-  int bs, hq, hkv, group, nqb, bq_log2, hchunks;
-  float sm_scale, logit_cap;
-  int is_causal;
-  int kv_fp8;              // the pool (prefix) rows are e4m3fn bytes; k_extend / v_extend stay in the q dtype
-  float k_scale, v_scale;  // K_true = K_fp8 * k_scale, V_true = V_fp8 * v_scale for the prefix part
-  // custom mask / sliding window (extend_attention.py:131-203 stage 1, :205-284 stage 2), MASKED instantiations only:
-  //   custom_mask u8, request b's block starts at mask_indptr[b] and is [ext_len, pre_len + ext_len] row-major; in the prefix
-  //   phase it applies unless skip_prefix_mask; in the extend phase it REPLACES the causal rule (:253-268);
-  //   sliding_window W > 0 masks prefix key j (index inside kv_indices) for query row i (index inside the extend part)
-  //   unless i <= j + W (:191-196) -- the backend hands in the last W + 1 prefix slots (triton_backend.py:927-955).
-  const uint8_t* custom_mask;
-  const int64_t* mask_indptr;
-  int skip_prefix_mask;
-  int sliding_window;
-  // Cascade (shared-prefix) decode, PREFIX pass (casc_bs > 0; sgl_mi355_decode_attention_cascade): the casc_bs decode queries
-  // q [casc_bs, Hq, D] are the "extend tokens" of bs = prefix splits virtual sequences that all start at query row 0; sequence
-  // b attends ONLY to the shared prefix rows kv_indices[b * casc_chunk, min((b + 1) * casc_chunk, casc_prefix_len)) (no extend
-  // keys), and instead of o the kernel writes the split partial O = acc / l (f32) and its natural-log LSE to the decode
-  // kernel's split slots: part_o [casc_bs][hq][max_kv_splits][D], part_lse [casc_bs][hq][max_kv_splits], slot casc_slot0 + b.
-  int casc_bs = 0, casc_prefix_len = 0, casc_chunk = 0, casc_slot0 = 0, max_kv_splits = 0;
-  float* part_o = nullptr;
-  float* part_lse = nullptr;
-  long long* tl = nullptr;   // SGL_EXT_TIMELINE builds only
-};
-
-constexpr int kKT = 64;  // kv tokens per tile
-constexpr float kLog2e = 1.4426950408889634f;
 
 __device__ __forceinline__ float softcap2(float s_scaled, float cap) {
   const float y = s_scaled / cap;
@@ -1294,7 +1248,10 @@ int launch_mfma(ExtendParams& p, int max_len_extend, hipStream_t st) {
     return SGL_MI355_EINVAL;
   }
   if constexpr (kDma) {
-    if (g_extend_dma >= 4 && p.casc_bs == 0 && !p.kv_fp8 && (p.group == 1 || p.group == 2 || p.group == 4 || p.group == 8)) {
+    if (g_extend_dma == 5 && extend_phased_eligible(p)) {
+      return launch_extend_phased(p, max_len_extend, std::is_same<T, __bf16>::value ? SGL_BF16 : SGL_F16, st);
+    }
+    if (g_extend_dma == 4 && p.casc_bs == 0 && !p.kv_fp8 && (p.group == 1 || p.group == 2 || p.group == 4 || p.group == 8)) {
       // 64 rows per wave, 256 (head, position) rows per workgroup, one wave per SIMD (extend_attn_w64_kernel)
       static bool w64_attr = false;
       if (!w64_attr) {
@@ -1377,7 +1334,7 @@ int sgl_mi355_internal_cascade_prefix(const void* q, int64_t q_stride_t, const v
 // measurement / test hook: 0 = always the register-staged kernel, 1 (default) = the LDS-DMA kernel where it applies with 4 or 8 waves
 // per workgroup by the mean-keys rule, 2 = always 8 waves, 3 = always 4 waves
 extern "C" int sgl_mi355_extend_attention_set_mode(int mode) {
-  g_extend_dma = mode < 0 ? 0 : (mode > 4 ? 4 : mode);
+  g_extend_dma = mode < 0 ? 0 : (mode > 5 ? 5 : mode);
   return SGL_MI355_OK;
 }
 // host-side knowledge the kernel arguments do not carry: the mean number of keys a query block of the NEXT calls attends to

@@ -127,8 +127,10 @@ def test_extend_lds_dma_kernel_equals_register_staged_kernel(dtype, hq, hkv, pre
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
 @pytest.mark.parametrize("hq,hkv,pre,ext", [(32, 8, [0, 0], [300, 77]), (8, 2, [130, 64, 0], [45, 200, 513]), (12, 12, [5], [260]),
                                             (16, 2, [70, 0], [129, 33]), (4, 2, [257, 31], [64, 1]), (8, 2, [1700], [300]),
-                                            (8, 1, [0, 3, 64], [1, 65, 256]), (2, 2, [0], [1000])])
-def test_extend_64_rows_per_wave_kernel_vs_oracle(dtype, hq, hkv, pre, ext, pkg):
+                                            (8, 1, [0, 3, 64], [1, 65, 256]), (2, 2, [0], [1000]), (14, 2, [3, 200], [300, 41]),
+                                            (3, 1, [0, 90], [520, 31])])
+@pytest.mark.parametrize("kmode", [4, 5])
+def test_extend_64_rows_per_wave_kernel_vs_oracle(dtype, hq, hkv, pre, ext, kmode, pkg):
     """extend_attn_w64_kernel (round 4: 256-row workgroups, 64 rows per wave on 32x32x16 MFMAs, one wave per SIMD; head groups
     1 / 2 / 4 / 8) against the float64 oracle at the attention tolerance, causal and not, over prefix + extend phases, ragged tiles and
     blocks, one-token requests; and against the 16x16x32 kernels (another summation order inside the MFMAs: a tolerance of a few
@@ -138,7 +140,7 @@ def test_extend_64_rows_per_wave_kernel_vs_oracle(dtype, hq, hkv, pre, ext, pkg)
     c = _cases.build_attn_case(case, seed=hq + len(pre))
     for causal in (True, False):
         try:
-            _cabi.check(_cabi.lib.sgl_mi355_extend_attention_set_mode(4))
+            _cabi.check(_cabi.lib.sgl_mi355_extend_attention_set_mode(kmode))
             new = _run(pkg, c, causal=causal)
             _cabi.check(_cabi.lib.sgl_mi355_extend_attention_set_mode(3))
             old = _run(pkg, c, causal=causal)
@@ -150,13 +152,14 @@ def test_extend_64_rows_per_wave_kernel_vs_oracle(dtype, hq, hkv, pre, ext, pkg)
         assert (new.double() - old.double()).abs().max().item() <= TOL_F64[c["dtype"]]
 
 
-def test_extend_64_rows_per_wave_kernel_random_ragged_batches(pkg):
+@pytest.mark.parametrize("kmode", [4, 5])
+def test_extend_64_rows_per_wave_kernel_random_ragged_batches(kmode, pkg):
     """Twelve seeded ragged batches (1-5 requests, prefix 0..300, extend 1..700, head groups 1 / 2 / 4 / 8) through the 64-rows-per-wave
     kernel against the float64 oracle."""
     from ltp_sglang_amd import _cabi
     rng = np.random.RandomState(77)
     try:
-        _cabi.check(_cabi.lib.sgl_mi355_extend_attention_set_mode(4))
+        _cabi.check(_cabi.lib.sgl_mi355_extend_attention_set_mode(kmode))
         for it in range(12):
             group = int(rng.choice([1, 2, 4, 8]))
             hkv = int(rng.choice([1, 2, 4]))
