@@ -176,6 +176,40 @@ def test_extend_64_rows_per_wave_kernel_random_ragged_batches(kmode, pkg):
         _cabi.lib.sgl_mi355_extend_attention_set_mode(1)
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("kmode", [3, 5])
+def test_extend_deferred_rescale_branch_is_taken_and_right(dtype, kmode, pkg):
+    """The 32x32x16 kernel (mode 5) takes its exponentials against a reference maximum that moves only when a score exceeds it by 2^30
+    (bf16) / 2^12 (f16): a rare, data-dependent branch that bounded random data never reaches after the first tile
+    (cdna_hip_programming.md rule 26).  Here the keys of chosen tiles are scaled so that the row maxima JUMP by hundreds of
+    exponent units at those tiles (prefix tile 2, extend tiles 1 and 5 -- in both directions: up, and back down to small scores), for
+    every row or only for half of the heads' rows; full tensor against the float64 oracle."""
+    from ltp_sglang_amd import _cabi
+    case = dict(name="jump", kind="extend", dtype=dtype, hq=8, hkv=2, d=128, pre=[200, 0, 70], ext=[450, 390, 64])
+    c = _cases.build_attn_case(case, seed=91)
+    kb = c["k_buffer"].float()
+    r2t, rpi = c["req_to_token"], c["req_pool_indices"]
+    pre, ext = c["extend_prefix_lens"], c["extend_seq_lens"]
+    for i in range(c["bs"]):
+        row = r2t[rpi[i]]
+        p_i, e_i = int(pre[i]), int(ext[i])
+        if p_i > 130:
+            kb[row[128:140].long()] *= 24.0                      # prefix tile 2: a jump up
+        kb[row[p_i + 64 : p_i + 70].long()] *= 60.0              # extend tile 1: a larger jump
+        if e_i > 330:
+            kb[row[p_i + 320 : p_i + 330].long(), 1:] *= 200.0   # extend tile 5, kv head 1 only: one half of the waves
+    c["k_buffer"] = kb.to(c["dtype"])
+    for causal in (True, False):
+        try:
+            _cabi.check(_cabi.lib.sgl_mi355_extend_attention_set_mode(kmode))
+            o = _run(pkg, c, causal=causal)
+        finally:
+            _cabi.lib.sgl_mi355_extend_attention_set_mode(1)
+        ref = _f64(c, causal=causal)
+        assert torch.isfinite(o.float()).all()
+        assert (o.double() - ref).abs().max().item() <= TOL_F64[c["dtype"]], (o.double() - ref).abs().max().item()
+
+
 def test_extend_long_sequence_properties(pkg):
     """seq 2048 without prefix at Llama-3-8B heads (BASELINE shape per request): compare 2 requests fully against
     the f64 oracle and check the causal first-row property o[0] == v[0]."""

@@ -12,7 +12,8 @@ mkdir -p "$OBJ" "$OUT"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 pids=()
 for src in "$SRC"/*.hip; do
-  $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -I"$SRC" "$@" -c "$src" -o "$OBJ/$(basename "${src%.hip}").o" &
+  EXTRA=""; [ "$(basename "$src")" = extend_attention_phased.hip ] && EXTRA="-fno-slp-vectorize"
+  $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -I"$SRC" $EXTRA "$@" -c "$src" -o "$OBJ/$(basename "${src%.hip}").o" &
   pids+=($!)
   if [ ${#pids[@]} -ge 6 ]; then wait "${pids[0]}"; pids=("${pids[@]:1}"); fi
 done

@@ -1,6 +1,6 @@
 """In-kernel timeline of the phased extend-attention kernel (needs a build with -DSGL_EXT_TIMELINE=<block>, selected through
-SGL_MI355_LIB): s_memtime stamps of one workgroup's eight waves over its first 24 tiles -- start and end (= before the barrier) of
-each of the four clusters; prints mean cycles per cluster and per barrier wait over tiles 4..20.  Read the SHARES, not the length:
+SGL_MI355_LIB): s_memtime stamps of one workgroup's eight waves over its first 24 tiles -- K requests + DMA issue | QK^T | decision | exponentials of key block 0 |
+PV k-steps 0, 1 beside the exponentials of block 1 | PV k-steps 2, 3 | vmcnt wait | barrier; mean cycles over tiles 4..20.  Read the SHARES, not the length:
 the stamps drain LDS reads the real kernel leaves in flight."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -31,7 +31,7 @@ f()
 torch.cuda.synchronize()
 fn(ctypes.c_void_p(0))
 tl = buf.cpu().view(8, 24, 8)
-names = ["C1", "bar", "C2", "bar", "C3", "bar", "C4", "bar"]
+names = ["w0-3: write+barrier+fetch", "QK", "decide+exp0", "w4-7: write+barrier", "PV+exp1", "w4-7: fetch", "-", "loop"]
 for w in range(8):
     x = tl[w]
     if int(x[4, 0]) == 0:
