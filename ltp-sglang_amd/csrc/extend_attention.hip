@@ -482,7 +482,7 @@ long long* g_ext_tl = nullptr;
 #else
 #define EXT_STAMP(k) do { } while (0)
 #endif
-int g_extend_dma = 1;  // sgl_mi355_extend_attention_set_mode: 0 = always the register-staged kernel, 1 = LDS-DMA kernel, 4 or 8 waves by the rule in launch_mfma, 2 / 3 = always 8 / 4 waves, 4 = the 64-rows-per-wave kernel (round 4) where the head group allows
+int g_extend_dma = 1;  // sgl_mi355_extend_attention_set_mode: 0 = always the register-staged kernel, 1 = default rule (the 8-wave 32x32x16 kernel of extend_attention_phased.hip where it applies and the grid is large enough, else the LDS-DMA kernel with 4 or 8 waves by the rule in launch_mfma), 2 / 3 = always the LDS-DMA kernel with 8 / 4 waves, 5 = always the 32x32x16 kernel where it applies
 int g_extend_kv_hint = 0;  // sgl_mi355_extend_attention_set_kv_hint: mean keys a query block attends to (0: unknown)
 
 // NW: waves per workgroup -- 4 (128 rows, two workgroups per CU) or 8 (256 rows = twice the query positions per K / V tile, one
@@ -768,363 +768,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void extend_attn_dma_kern
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// 64 query rows per wave (round 4; VERDICT r3 next-4a, the structure the round-3 post-mortem specified): a workgroup = 4 waves =
-// 256 (head, position) rows, ONE wave per SIMD on the 512-register budget, v_mfma_f32_32x32x16.  Per 64-key tile a wave runs 32 + 32
-// MFMAs of 32 cycles; a quarter of the LDS-DMA instructions per row of the 4-wave 128-row form.  Formulation: S^T = K Q^T (A = K
-// rows, B = Q^T): the 32x32 accumulator has the QUERY on the lane (col = lane & 31) and 16 keys in registers, key
-// (r & 3) + 8 (r >> 2) + 4 h of the 32-key block (h = lane >> 5) -- so registers 8 s .. 8 s + 7, converted pairwise, ARE the B
-// operand of k-step s of O^T += V^T P^T with the keys in the permuted order 16 s + 8 (j >> 2) + 4 h + (j & 3)
-// (cdna_hip_programming.md, "An accumulator tile as the next MFMA's operand"), and the V^T fragment takes the same order with two
-// ds_read_b64_tr_b16 (keys 16 s + 4 h .. + 3 and 16 s + 8 + 4 h .. + 3).  The row maximum is a chain over the lane's own 32 scores
-// and ONE v_permlane32_swap.  K image: the 16-byte-chunk ^ (row & 15) swizzle of the other kernels (conflict-free for the 32-row
-// ds_read_b128 pattern too); V image: 32-byte chunk ^ 2 (row & 3), which makes the four key rows x two d chunks a 32-lane half
-// reads one bank sweep.  Staging: LDS-DMA as in extend_attn_dma_kernel, 16 rows per wave.
-// Order of a tile: QK(q0) | max(q0), rescale?(q0) | QK(q1) beside exp(q0) | max(q1), rescale?(q1) | PV(q0) beside exp(q1) | PV(q1):
-// the two 32-row q blocks of a wave are independent, so the softmax VALU work of one sits beside the MFMAs of the other (one wave
-// per SIMD: nothing else fills the matrix pipe's shadow).
-// DEFERRED rescale: the exponentials are taken against m_i, which follows the true running maximum only when that has moved by
-// more than kDefer (P up to 2^kDefer: exact exponent arithmetic in bf16 / f16 / f32 alike, and o = acc / l does not depend on
-// the reference point); the 128 accumulator registers are then touched by VALU instructions once per few dozen tiles instead of
-// every tile -- they live in AGPRs, where every VALU touch is a copy out and back (the first version rescaled every tile: 1 000
-// v_accvgpr moves per tile, 501 TFLOP/s).
-// Arithmetic: the other kernels' online softmax up to that reference point and another summation order inside the MFMAs -- parity
-// is the oracle tolerance, not bit-identity with the 16x16x32 kernels.  group (q heads per kv head) in {1, 2, 4, 8}: a 32-row q
-// block lies inside one head.
-// ---------------------------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256, 1) void extend_attn_w64_kernel(const ExtendParams p) {
-  using Tr = ElemTraits<T>;
-  using vec8 = typename Tr::vec8;
-  constexpr int D = 128, ROWB = 256, QB = 2, KB = 2, KS = 8, DB = 4;
-  constexpr int TILE_B = kKT * ROWB;  // 16 KiB
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][K 16 KiB | V 16 KiB]
-
-  const int bid = blockIdx.x;
-  const int lo = bid & 7, rest = bid >> 3;
-  const int qb_idx = p.nqb - 1 - rest % p.nqb;
-  const int pair = (rest / p.nqb) * 8 + lo;
-  const int npairs = p.bs * p.hkv;
-  if (pair >= npairs) return;
-  const int b = pair / p.hkv;
-  const int kh = pair - b * p.hkv;
-
-  const int bq = 1 << p.bq_log2;              // query positions per workgroup = 256 / head slots
-  const int q0 = p.qo_indptr ? p.qo_indptr[b] : p.extend_start_loc[b];
-  const int ext_len = p.qo_indptr ? p.qo_indptr[b + 1] - q0 : p.extend_seq_lens[b];
-  const int qpos0 = qb_idx * bq;
-  if (qpos0 >= ext_len) return;
-  int pre_len;
-  const int32_t* idx_row;
-  if (p.kv_indptr) {
-    const int s0 = p.kv_indptr[b];
-    pre_len = p.kv_indptr[b + 1] - s0;
-    idx_row = p.kv_indices + s0;
-  } else {
-    pre_len = (int)p.seq_lens[b] - ext_len;
-    idx_row = p.req_to_token + p.req_pool_indices[b] * p.req_to_token_stride;
-  }
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int c = lane & 31, h = lane >> 5;     // MFMA column (query of the q block) and lane half
-#ifdef SGL_EXT_TIMELINE
-  long long* tl = (blockIdx.x == SGL_EXT_TIMELINE && lane == 0) ? p.tl : nullptr;
-#endif
-
-  // Q^T fragments: lane (c, h) holds Q[row c of q block qq][16 ks + 8 h .. + 7]
-  vec8 qf[QB][KS];
-  int qpos[QB];
-  bool qok[QB];
-#pragma unroll
-  for (int qq = 0; qq < QB; ++qq) {
-    const int t32 = 64 * w + 32 * qq;
-    const int hl = t32 >> p.bq_log2;          // head of the group this q block belongs to
-    qpos[qq] = qpos0 + (t32 & (bq - 1)) + c;
-    qok[qq] = hl < p.group && qpos[qq] < ext_len;
-    const T* qrow = (const T*)p.q + (int64_t)(q0 + min(qpos[qq], ext_len - 1)) * p.q_stride_t + (int64_t)(kh * p.group + min(hl, p.group - 1)) * D;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      if (qok[qq]) {
-        qf[qq][ks] = *(const vec8*)(qrow + 16 * ks + 8 * h);
-      } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) qf[qq][ks][j] = (T)0.0f;
-      }
-    }
-  }
-
-  const int npre_tiles = (pre_len + kKT - 1) / kKT;
-  const int ext_end = p.is_causal ? min(ext_len, qpos0 + bq) : ext_len;
-  const int ntiles = npre_tiles + (ext_end + kKT - 1) / kKT;   // >= 1
-
-  // ---- LDS-DMA staging: wave w fills rows 16 w .. 16 w + 15 of a tile, 4 rows (1 KiB) per instruction ----
-  constexpr int RPWV = kKT / 4, NIW = RPWV / 4;
-  const int srow = lane >> 4, spos = lane & 15;
-  const char* kpool = (const char*)p.k_buf + ((int64_t)kh * p.k_stride_h) * 2;
-  const char* vpool = (const char*)p.v_buf + ((int64_t)kh * p.v_stride_h) * 2;
-  const char* kext = (const char*)p.ke + ((int64_t)q0 * p.ke_stride_t + (int64_t)kh * D) * 2;
-  const char* vext = (const char*)p.ve + ((int64_t)q0 * p.ve_stride_t + (int64_t)kh * D) * 2;
-  const int64_t kpst = p.k_stride_t * 2, vpst = p.v_stride_t * 2, kest = p.ke_stride_t * 2, vest = p.ve_stride_t * 2;
-  const int32_t* idx_dummy = p.qo_indptr ? p.qo_indptr : p.extend_start_loc;
-  typedef __attribute__((address_space(3))) void* lptr_t;
-
-  auto load_idx = [&](int t, int (&idn)[NIW]) {
-    const bool pre = t < npre_tiles;
-#pragma unroll
-    for (int i = 0; i < NIW; ++i) {
-      const int r = t * kKT + RPWV * w + 4 * i + srow;
-      idn[i] = ext_load_i32(pre ? idx_row + min(r, pre_len - 1) : idx_dummy);
-    }
-  };
-  auto stage = [&](int t, const int (&idn)[NIW]) {
-    const bool pre = t < npre_tiles;
-    const int base = (t - npre_tiles) * kKT + RPWV * w + srow;
-    const unsigned kdst = (unsigned)(uintptr_t)(lptr_t)(smem + (t & 1) * 2 * TILE_B + (RPWV * w) * ROWB);
-    const unsigned vdst = kdst + TILE_B;
-#pragma unroll
-    for (int i = 0; i < NIW; ++i) {
-      const int rr = min(base + 4 * i, ext_len - 1);
-      const int r = (RPWV * w + 4 * i + srow) & 15;   // row of the tile, mod 16
-      const char* ks = (pre ? kpool + (int64_t)idn[i] * kpst : kext + (int64_t)rr * kest) + ((spos ^ r) << 4);
-      const char* vs = (pre ? vpool + (int64_t)idn[i] * vpst : vext + (int64_t)rr * vest) + (((((spos >> 1) ^ ((r & 3) << 1)) << 1) | (spos & 1)) << 4);
-      ext_dma16(ks, kdst + i * 4 * ROWB);
-      ext_dma16(vs, vdst + i * 4 * ROWB);
-    }
-  };
-  auto stage_ext = [&](int t) {
-    const int base = t * kKT + RPWV * w + srow;
-    const unsigned kdst = (unsigned)(uintptr_t)(lptr_t)(smem + (t & 1) * 2 * TILE_B + (RPWV * w) * ROWB);
-    const unsigned vdst = kdst + TILE_B;
-#pragma unroll
-    for (int i = 0; i < NIW; ++i) {
-      const int rr = min(base + 4 * i, ext_len - 1);
-      const int r = (RPWV * w + 4 * i + srow) & 15;
-      ext_dma16(kext + (int64_t)rr * kest + ((spos ^ r) << 4), kdst + i * 4 * ROWB);
-      ext_dma16(vext + (int64_t)rr * vest + (((((spos >> 1) ^ ((r & 3) << 1)) << 1) | (spos & 1)) << 4), vdst + i * 4 * ROWB);
-    }
-  };
-
-  float m_i[QB], l_i[QB];
-  f32x16_t acc[QB][DB];
-#pragma unroll
-  for (int qq = 0; qq < QB; ++qq) {
-    m_i[qq] = -INFINITY;
-    l_i[qq] = 0.f;
-#pragma unroll
-    for (int n = 0; n < DB; ++n)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[qq][n][r] = 0.f;
-  }
-  const float cs = p.sm_scale * kLog2e;
-  constexpr float kDefer = 6.0f;
-  const int gq = lane >> 4, a = lane & 15;   // 16-lane group: d half gq & 1, lane half gq >> 1 (= h); piece a & 3 of key row a >> 2
-
-  // ---- prologue: tile 0 landed, slots of tile 1 known ----
-  int idn[NIW];
-  {
-    int i0[NIW];
-    load_idx(0, i0);
-    load_idx(1, idn);
-#pragma unroll
-    for (int i = 0; i < NIW; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+v"(i0[i]), "+v"(idn[i])::"memory");
-    stage(0, i0);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  for (int t = 0; t < ntiles; ++t) {
-    EXT_STAMP(0);
-    int idn2[NIW];
-    if (npre_tiles > 0) {
-      load_idx(t + 2, idn2);
-      if (t + 1 < ntiles) stage(t + 1, idn);
-    } else {
-#pragma unroll
-      for (int i = 0; i < NIW; ++i) idn2[i] = 0;
-      if (t + 1 < ntiles) stage_ext(t + 1);
-    }
-    EXT_STAMP(1);
-    const char* kl = smem + (t & 1) * 2 * TILE_B;
-    const char* vl = kl + TILE_B;
-    const bool in_prefix = t < npre_tiles;
-    const int kbase = in_prefix ? t * kKT : (t - npre_tiles) * kKT;
-    const int klimit = in_prefix ? pre_len : ext_len;
-    // ragged last tile of a phase / causal diagonal: wave-uniform (the wave's first position decides)
-    const int wave_qmin = qpos0 + ((64 * w) & (bq - 1));
-    const bool causal = !in_prefix && p.is_causal;
-    const bool need_mask = (kbase + kKT > klimit) || (causal && kbase + kKT - 1 > wave_qmin);
-
-    // S^T of one q block: key block kk (32 keys), 8 k-steps of 16 d.  K fragments are re-read per q block and V^T fragments per PV
-    // pass (LDS has the headroom: 64 KiB per wave and tile against 2 048 cycles of MFMA; holding 16 + 16 fragments beside 128
-    // accumulator and 64 score registers spilled)
-    auto qk = [&](int qq, f32x16_t (&sq)[KB]) __attribute__((always_inline)) {
-      vec8 kf[KB][KS];   // both key blocks requested before the first MFMA: one exposed LDS round trip per call, not two
-#pragma unroll
-      for (int kk = 0; kk < KB; ++kk) {
-        const int row = 32 * kk + c;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) kf[kk][ks] = *(const vec8*)(kl + row * ROWB + (((2 * ks + h) ^ (row & 15)) << 4));
-      }
-      __builtin_amdgcn_sched_barrier(0);   // (left free, every read is sunk to just before its MFMA and waited for alone: 16 exposed LDS round trips)
-#pragma unroll
-      for (int kk = 0; kk < KB; ++kk)
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          if (ks == 0) {
-            f32x16_t z;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) z[r] = 0.f;
-            sq[kk] = Tr::mfma32(kf[kk][ks], qf[qq][ks], z);
-          } else {
-            sq[kk] = Tr::mfma32(kf[kk][ks], qf[qq][ks], sq[kk]);
-          }
-        }
-    };
-    // masking + row maximum (in exponent units) of one q block
-    auto row_max = [&](int qq, f32x16_t (&sq)[KB]) __attribute__((always_inline)) -> float {
-      if (need_mask) {
-        asm volatile("" ::: "memory");   // a real wave-uniform branch: if-converted, the 64 compare + select pairs ran on every tile
-        const int lim = min(klimit - 1, causal ? qpos[qq] : 0x7fffffff) - kbase - 4 * h;   // key index relative to 32 kk + crow(r, 0)
-#pragma unroll
-        for (int kk = 0; kk < KB; ++kk)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) sq[kk][r] = (32 * kk + (r & 3) + 8 * (r >> 2) <= lim) ? sq[kk][r] : -INFINITY;
-      }
-      float m = -INFINITY;
-#pragma unroll
-      for (int kk = 0; kk < KB; ++kk)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) m = fmaxf(m, sq[kk][r]);
-      return pair32_max(m) * cs;
-    };
-    auto rescale = [&](int qq, float m) __attribute__((always_inline)) {
-      if (__builtin_amdgcn_ballot_w64(m > m_i[qq] + kDefer) != 0) {   // wave-uniform: some row of the q block moved far enough
-        const float m_new = fmaxf(m_i[qq], m);
-        const float alpha = __builtin_amdgcn_exp2f(m_i[qq] - fmaxf(m_new, -1e30f));
-        l_i[qq] *= alpha;
-        m_i[qq] = m_new;
-        // The accumulators are pinned to AGPRs ("+a") and scaled through ONE temporary: written as plain C the branch made hipcc keep
-        // half of them in VGPRs for the whole loop (spills and 60 copies per tile in the hot blocks).  hipcc pads no hazards inside asm:
-        // the leading s_nops cover MFMA-write -> accvgpr_read, the trailing ones accvgpr_write -> MFMA SrcC (a cold path).
-        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-#pragma unroll
-        for (int n = 0; n < DB; ++n)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            float tmp;
-            asm volatile("v_accvgpr_read_b32 %1, %0\n\ts_nop 1\n\tv_mul_f32 %1, %1, %2\n\ts_nop 1\n\tv_accvgpr_write_b32 %0, %1"
-                         : "+a"(acc[qq][n][r]), "=&v"(tmp)
-                         : "v"(alpha));
-          }
-        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-      }
-    };
-    auto exps = [&](int qq, const f32x16_t (&sq)[KB], vec8 (&pq)[4]) __attribute__((always_inline)) {
-      const float m_safe = fmaxf(m_i[qq], -1e30f);
-      float lsum = 0.f;
-#pragma unroll
-      for (int kk = 0; kk < KB; ++kk)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sq[kk][r], cs, -m_safe));
-          lsum += pv;
-          pq[2 * kk + (r >> 3)][r & 7] = Tr::from_f32(pv);   // registers 8 sI .. 8 sI + 7 = the B operand of PV k-step 2 kk + sI
-        }
-      l_i[qq] += lsum;
-    };
-    // O^T += V^T P^T of one q block: d block n (32 d) x 4 k-steps of 16 keys in the accumulator's key order
-    auto vread = [&](int n, vec8 (&vf)[4]) __attribute__((always_inline)) {
-#pragma unroll
-      for (int sI = 0; sI < 4; ++sI) {
-        const int chunk = 2 * n + (gq & 1);
-        s16x4_t t0, t1;
-        {
-          const int row = 16 * sI + 4 * h + (a >> 2);
-          t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (s16x4_t __attribute__((address_space(3)))*)(vl + row * ROWB + ((chunk ^ ((row & 3) << 1)) << 5) + ((a & 3) << 3)));
-        }
-        {
-          const int row = 16 * sI + 8 + 4 * h + (a >> 2);
-          t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (s16x4_t __attribute__((address_space(3)))*)(vl + row * ROWB + ((chunk ^ ((row & 3) << 1)) << 5) + ((a & 3) << 3)));
-        }
-        vf[sI] = __builtin_bit_cast(vec8, __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7));
-      }
-    };
-    // d block n + 1's fragments are requested before d block n's MFMAs (two register sets), the scheduler held to that order
-    auto pv = [&](int qq, const vec8 (&pq)[4]) __attribute__((always_inline)) {
-      vec8 vfa[4], vfb[4];
-      vread(0, vfa);
-#pragma unroll
-      for (int n = 0; n < DB; n += 2) {
-        vread(n + 1, vfb);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int sI = 0; sI < 4; ++sI) acc[qq][n] = Tr::mfma32(vfa[sI], pq[sI], acc[qq][n]);
-        if (n + 2 < DB) vread(n + 2, vfa);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int sI = 0; sI < 4; ++sI) acc[qq][n + 1] = Tr::mfma32(vfb[sI], pq[sI], acc[qq][n + 1]);
-      }
-    };
-
-    f32x16_t s0[KB], s1[KB];
-    vec8 pf0[4], pf1[4];
-    qk(0, s0);
-    const float mx0 = row_max(0, s0);
-    rescale(0, mx0);
-    EXT_STAMP(2);
-    qk(1, s1);          // matrix pipe
-    exps(0, s0, pf0);   // beside it: VALU.  Pinned: left alone, hipcc sinks the exponentials below the next branch, next to PV
-#pragma unroll
-    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(pf0[i]));
-    // 16 MFMAs of 32 cycles with ~8 single-issue instructions in each one's shadow
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
-    }
-    const float mx1 = row_max(1, s1);
-    rescale(1, mx1);
-    EXT_STAMP(3);
-    pv(0, pf0);         // matrix pipe
-    exps(1, s1, pf1);   // beside it: VALU
-#pragma unroll
-    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(pf1[i]));
-    pv(1, pf1);
-    EXT_STAMP(4);
-
-    // tile t + 1 has landed and the slots of tile t + 2 are known
-#pragma unroll
-    for (int i = 0; i < NIW; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+v"(idn2[i])::"memory");
-#pragma unroll
-    for (int i = 0; i < NIW; ++i) idn[i] = idn2[i];
-    __syncthreads();
-    EXT_STAMP(5);
-  }
-
-  // ---- o = acc / l: lane (c, h) holds query c of the q block, d = 32 n + (r & 3) + 8 (r >> 2) + 4 h ----
-#pragma unroll
-  for (int qq = 0; qq < QB; ++qq) {
-    const float l = pair32_sum(l_i[qq]);
-    if (qok[qq]) {
-      const int hl = (64 * w + 32 * qq) >> p.bq_log2;
-      const float inv = l > 0.f ? 1.0f / l : 0.f;
-      T* orow = (T*)p.o + (int64_t)(q0 + qpos[qq]) * p.o_stride_t + (int64_t)(kh * p.group + hl) * D;
-#pragma unroll
-      for (int n = 0; n < DB; ++n)
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          typename Tr::vec4 ov;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) ov[r] = Tr::from_f32(acc[qq][n][4 * g4 + r] * inv);
-          *(typename Tr::vec4*)(orow + 32 * n + 8 * g4 + 4 * h) = ov;
-        }
-    }
-  }
-}
-
 // Any-head-dim fallback: one wave per (query token, q head); correctness path for odd head sizes.
 template <typename T>
 __global__ __launch_bounds__(64) void extend_attn_generic(const ExtendParams p, int d_qk, int dv, int total_q) {
@@ -1248,31 +891,15 @@ int launch_mfma(ExtendParams& p, int max_len_extend, hipStream_t st) {
     return SGL_MI355_EINVAL;
   }
   if constexpr (kDma) {
-    if (g_extend_dma == 5 && extend_phased_eligible(p)) {
-      return launch_extend_phased(p, max_len_extend, std::is_same<T, __bf16>::value ? SGL_BF16 : SGL_F16, st);
-    }
-    if (g_extend_dma == 4 && p.casc_bs == 0 && !p.kv_fp8 && (p.group == 1 || p.group == 2 || p.group == 4 || p.group == 8)) {
-      // 64 rows per wave, 256 (head, position) rows per workgroup, one wave per SIMD (extend_attn_w64_kernel)
-      static bool w64_attr = false;
-      if (!w64_attr) {
-        (void)hipFuncSetAttribute((const void*)extend_attn_w64_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        w64_attr = true;
-      }
-      const int bqw = 256 / p.group;
-      int lgw = 0;
-      while ((1 << lgw) < bqw) ++lgw;
-      p.bq_log2 = lgw;
-      p.hchunks = 1;
-      p.nqb = (max_len_extend + bqw - 1) / bqw;
-      const int64_t nbw = (int64_t)((p.bs * p.hkv + 7) / 8) * p.nqb * 8;
-      if (nbw <= 0) return SGL_MI355_OK;
-      if (nbw >= (1ll << 31)) {
-        snprintf(g_sgl_mi355_err, sizeof(g_sgl_mi355_err), "extend_attention: grid too large");
-        return SGL_MI355_EINVAL;
-      }
-      hipLaunchKernelGGL((extend_attn_w64_kernel<T>), dim3((unsigned)nbw), dim3(256), smem, st, p);
-      SGL_HIP_LAUNCH_CHECK();
-      return SGL_MI355_OK;
+    // The 8-wave 32x32x16 kernel (extend_attention_phased.hip; 256-row workgroups, one per CU) where it applies and the launch still
+    // has a workgroup for most CUs: same box, 4-wave LDS-DMA kernel -> this one: 32 x 2048 1 493 -> 1 384 us, 8 x 2048 441 -> 426,
+    // radix hit 16 x (1536 + 512) 333 -> 318, 2 x 8192 1 219 -> 1 148 (profiles/round5_ab_extend_phased.json)
+    if ((g_extend_dma == 1 || g_extend_dma == 5) && extend_phased_eligible(p)) {
+      int slots = 1;
+      while (slots < p.group) slots <<= 1;
+      const int64_t nbp = (int64_t)((p.bs * p.hkv + 7) / 8) * ((max_len_extend + 256 / slots - 1) / (256 / slots)) * 8;
+      if (g_extend_dma == 5 || nbp >= 192)
+        return launch_extend_phased(p, max_len_extend, std::is_same<T, __bf16>::value ? SGL_BF16 : SGL_F16, st);
     }
     if (g_extend_dma && p.casc_bs == 0 && !p.kv_fp8) {
       // 8 waves (twice the query positions per K / V tile, half the tile traffic) pay where a query block walks many keys: same
@@ -1331,10 +958,11 @@ int sgl_mi355_internal_cascade_prefix(const void* q, int64_t q_stride_t, const v
   return dtype == SGL_BF16 ? launch_all<__bf16>(p, head_dim, head_dim, batch, batch, st) : launch_all<_Float16>(p, head_dim, head_dim, batch, batch, st);
 }
 
-// measurement / test hook: 0 = always the register-staged kernel, 1 (default) = the LDS-DMA kernel where it applies with 4 or 8 waves
-// per workgroup by the mean-keys rule, 2 = always 8 waves, 3 = always 4 waves
+// measurement / test hook: 0 = always the register-staged kernel, 1 (default) = the 8-wave 32x32x16 kernel where it applies and the grid
+// has >= 192 workgroups, else the LDS-DMA kernel with 4 or 8 waves per workgroup by the mean-keys rule, 2 / 3 = always the LDS-DMA kernel
+// with 8 / 4 waves, 5 = always the 32x32x16 kernel where it applies (4 was round 4's 64-rows-per-wave kernel: removed, 0.6 x the default)
 extern "C" int sgl_mi355_extend_attention_set_mode(int mode) {
-  g_extend_dma = mode < 0 ? 0 : (mode > 5 ? 5 : mode);
+  g_extend_dma = mode < 0 ? 0 : (mode > 5 ? 5 : (mode == 4 ? 1 : mode));
   return SGL_MI355_OK;
 }
 // host-side knowledge the kernel arguments do not carry: the mean number of keys a query block of the NEXT calls attends to

@@ -111,7 +111,8 @@ def test_extend_lds_dma_kernel_equals_register_staged_kernel(dtype, hq, hkv, pre
             _cabi.lib.sgl_mi355_extend_attention_set_mode(1)
         assert torch.equal(outs[2], outs[0]) and torch.equal(outs[3], outs[0])
         assert (outs[0].double() - _f64(c, causal=causal)).abs().max().item() <= TOL_F64[c["dtype"]]
-    # the default rule (4 or 8 waves by the mean number of keys per query block: the caller's hint, else extend / 2)
+    # the default rule: these grids are small (< 192 workgroups of 256 rows), so it stays with the LDS-DMA kernel, 4 or 8 waves by the
+    # mean number of keys per query block (the caller's hint, else extend / 2)
     try:
         for hint in (0, 100, 5000):
             _cabi.check(_cabi.lib.sgl_mi355_extend_attention_set_kv_hint(hint))
@@ -129,12 +130,12 @@ def test_extend_lds_dma_kernel_equals_register_staged_kernel(dtype, hq, hkv, pre
                                             (16, 2, [70, 0], [129, 33]), (4, 2, [257, 31], [64, 1]), (8, 2, [1700], [300]),
                                             (8, 1, [0, 3, 64], [1, 65, 256]), (2, 2, [0], [1000]), (14, 2, [3, 200], [300, 41]),
                                             (3, 1, [0, 90], [520, 31])])
-@pytest.mark.parametrize("kmode", [4, 5])
-def test_extend_64_rows_per_wave_kernel_vs_oracle(dtype, hq, hkv, pre, ext, kmode, pkg):
-    """extend_attn_w64_kernel (round 4: 256-row workgroups, 64 rows per wave on 32x32x16 MFMAs, one wave per SIMD; head groups
-    1 / 2 / 4 / 8) against the float64 oracle at the attention tolerance, causal and not, over prefix + extend phases, ragged tiles and
-    blocks, one-token requests; and against the 16x16x32 kernels (another summation order inside the MFMAs: a tolerance of a few
-    output ulps, not bit-identity)."""
+@pytest.mark.parametrize("kmode", [5])
+def test_extend_32x32_kernel_vs_oracle(dtype, hq, hkv, pre, ext, kmode, pkg):
+    """extend_attn_phased_kernel (round 5: 256-row workgroups, 8 waves x 32 rows on 32x32x16 MFMAs, deferred reference maximum; head
+    groups 1 .. 8 incl. 3 and 7) against the float64 oracle at the attention tolerance, causal and not, over prefix + extend phases,
+    ragged tiles and blocks, one-token requests; and against the 16x16x32 kernels (another summation order inside the MFMAs and another
+    reference point of the exponentials: the oracle tolerance, not bit-identity)."""
     from ltp_sglang_amd import _cabi
     case = dict(name="w64", kind="extend", dtype=dtype, hq=hq, hkv=hkv, d=128, pre=pre, ext=ext)
     c = _cases.build_attn_case(case, seed=hq + len(pre))
@@ -152,9 +153,9 @@ def test_extend_64_rows_per_wave_kernel_vs_oracle(dtype, hq, hkv, pre, ext, kmod
         assert (new.double() - old.double()).abs().max().item() <= TOL_F64[c["dtype"]]
 
 
-@pytest.mark.parametrize("kmode", [4, 5])
-def test_extend_64_rows_per_wave_kernel_random_ragged_batches(kmode, pkg):
-    """Twelve seeded ragged batches (1-5 requests, prefix 0..300, extend 1..700, head groups 1 / 2 / 4 / 8) through the 64-rows-per-wave
+@pytest.mark.parametrize("kmode", [5])
+def test_extend_32x32_kernel_random_ragged_batches(kmode, pkg):
+    """Twelve seeded ragged batches (1-5 requests, prefix 0..300, extend 1..700, head groups 1 / 2 / 4 / 8) through the 8-wave 32x32x16
     kernel against the float64 oracle."""
     from ltp_sglang_amd import _cabi
     rng = np.random.RandomState(77)
