@@ -196,6 +196,11 @@ int sgl_mi355_per_token_quant_fp8(const void* input, int64_t input_stride, void*
  * Dynamic mode (is_static == 0) atomically maxes into *output_s, which the caller zero-initialises. */
 int sgl_mi355_per_tensor_quant_fp8(const void* input, void* output_q, float* output_s, int64_t num_elements,
                                    int is_static, int in_dtype, void* stream);
+/* input_to_float8, python/sglang/srt/layers/quantization/fp8_utils.py:310-326 (weights that arrive unquantised: w8a8_fp8.py:129,
+ * fp8.py:375): amax = max |x| clamped at 1e-12, scale = 448 / amax, q = sat(x * scale); *output_scale_inv = 1 / scale.  The reference's
+ * arithmetic order (sgl_per_tensor_quant_fp8 multiplies by 1 / (amax / 448) instead).  amax_scratch: one float of device memory. */
+int sgl_mi355_input_to_float8(const void* input, void* output_q, float* output_scale_inv, float* amax_scratch,
+                              int64_t num_elements, int in_dtype, void* stream);
 /* sgl_per_token_group_quant_fp8, sgl-kernel/csrc/gemm/per_token_group_quant_8bit.cu; python gemm.py:100-112
  * (row-major float scales; scale_ue8m0 / column-major layouts are DeepSeek-only and out of scope) */
 int sgl_mi355_per_token_group_quant_fp8(const void* input, void* output_q, float* output_s, int64_t num_elements,

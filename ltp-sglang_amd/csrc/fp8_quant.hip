@@ -134,6 +134,46 @@ __global__ __launch_bounds__(256) void per_tensor_quant_kernel(const T* __restri
   for (int64_t i = nvec * 8 + gid; i < n; i += stride) out_q[i] = cvt1_fp8(clamp448((float)in[i] * inv));
 }
 
+// input_to_float8 (python/sglang/srt/layers/quantization/fp8_utils.py:310-326; weights that arrive unquantised: w8a8_fp8.py:129,
+// fp8.py:375): amax = max |x| clamped at 1e-12, scale = 448 / amax, q = sat(x * scale) (RNE), returns 1 / scale.  The reference's
+// arithmetic order, not the per-tensor kernel's (x * (1 / (amax / 448))): the two differ in the last bit of the factor.
+template <typename T>
+__global__ __launch_bounds__(256) void raw_absmax_kernel(const T* __restrict__ in, float* __restrict__ out_amax, int64_t n) {
+  __shared__ float red[4];
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t nvec = n / 8;
+  float amax = 0.f;
+  for (int64_t i = gid; i < nvec; i += stride) {
+    float f[8];
+    load8(in + i * 8, f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(f[j]));
+  }
+  for (int64_t i = nvec * 8 + gid; i < n; i += stride) amax = fmaxf(amax, fabsf((float)in[i]));
+  amax = wave_reduce_max(amax);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax((unsigned int*)out_amax, __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
+}
+template <typename T>
+__global__ __launch_bounds__(256) void input_to_float8_kernel(const T* __restrict__ in, uint8_t* __restrict__ out_q, const float* __restrict__ amax_p,
+                                                              float* __restrict__ out_s, int64_t n) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const float scale = kFp8Max / fmaxf(*amax_p, 1e-12f);
+  if (gid == 0) *out_s = 1.0f / scale;
+  const int64_t nvec = n / 8;
+  for (int64_t i = gid; i < nvec; i += stride) {
+    float f[8];
+    load8(in + i * 8, f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = clamp448(f[j] * scale);
+    *(u32x2_t*)(out_q + i * 8) = pack8_fp8(f);
+  }
+  for (int64_t i = nvec * 8 + gid; i < n; i += stride) out_q[i] = cvt1_fp8(clamp448((float)in[i] * scale));
+}
+
 // 16 lanes per group (reference: threads_per_group = 16), 4 groups per wave.
 template <typename T>
 __global__ __launch_bounds__(256) void per_token_group_quant_kernel(const T* __restrict__ in, uint8_t* __restrict__ out_q,
@@ -286,6 +326,34 @@ extern "C" int sgl_mi355_per_tensor_quant_fp8(const void* input, void* output_q,
       hipLaunchKernelGGL((per_tensor_absmax_kernel<_Float16>), dim3(blocks), dim3(256), 0, st, (const _Float16*)input, output_s, num_elements);
     hipLaunchKernelGGL((per_tensor_quant_kernel<_Float16>), dim3(blocks), dim3(256), 0, st, (const _Float16*)input,
                        (uint8_t*)output_q, output_s, num_elements);
+  }
+  SGL_HIP_LAUNCH_CHECK();
+  return SGL_MI355_OK;
+}
+
+extern "C" int sgl_mi355_input_to_float8(const void* input, void* output_q, float* output_scale_inv, float* amax_scratch,
+                                         int64_t num_elements, int in_dtype, void* stream) {
+  SGL_CHECK(num_elements >= 0, "input_to_float8: negative size");
+  SGL_CHECK(output_scale_inv && amax_scratch, "input_to_float8: null scale pointer");
+  if (num_elements == 0) return SGL_MI355_OK;
+  SGL_CHECK(input && output_q, "input_to_float8: null pointer");
+  SGL_CHECK(((uintptr_t)input % 16) == 0 && ((uintptr_t)output_q % 8) == 0, "input_to_float8: misaligned tensor");
+  SGL_CHECK(in_dtype == SGL_BF16 || in_dtype == SGL_F16, "input_to_float8: input must be bf16 or f16");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t blocks64 = (num_elements / 8 + 255) / 256;
+  const unsigned blocks = (unsigned)(blocks64 < 1 ? 1 : (blocks64 > 2048 ? 2048 : blocks64));
+  if (hipMemsetAsync(amax_scratch, 0, sizeof(float), st) != hipSuccess) {
+    snprintf(g_sgl_mi355_err, sizeof(g_sgl_mi355_err), "input_to_float8: hipMemsetAsync failed");
+    return SGL_MI355_EHIP;
+  }
+  if (in_dtype == SGL_BF16) {
+    hipLaunchKernelGGL((raw_absmax_kernel<__bf16>), dim3(blocks), dim3(256), 0, st, (const __bf16*)input, amax_scratch, num_elements);
+    hipLaunchKernelGGL((input_to_float8_kernel<__bf16>), dim3(blocks), dim3(256), 0, st, (const __bf16*)input, (uint8_t*)output_q,
+                       amax_scratch, output_scale_inv, num_elements);
+  } else {
+    hipLaunchKernelGGL((raw_absmax_kernel<_Float16>), dim3(blocks), dim3(256), 0, st, (const _Float16*)input, amax_scratch, num_elements);
+    hipLaunchKernelGGL((input_to_float8_kernel<_Float16>), dim3(blocks), dim3(256), 0, st, (const _Float16*)input, (uint8_t*)output_q,
+                       amax_scratch, output_scale_inv, num_elements);
   }
   SGL_HIP_LAUNCH_CHECK();
   return SGL_MI355_OK;

@@ -286,6 +286,19 @@ def sgl_per_tensor_quant_fp8(input: torch.Tensor, output_q: torch.Tensor, output
                                              dtype_code(input.dtype), current_stream()))
 
 
+def input_to_float8(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """fp8_utils.py:310-326 on the device: (x_q e4m3fn like x, 1 / scale as a 0-dim f32 tensor); bf16 / f16 input (f32: cast first, as
+    checkpoints hold 16-bit weights)."""
+    _cuda(x)
+    xc = x.contiguous()
+    if xc.dtype == torch.float32:
+        xc = xc.to(torch.bfloat16)
+    x_q = torch.empty_like(xc, dtype=torch.float8_e4m3fn)
+    s = torch.empty(2, device=x.device, dtype=torch.float32)   # [1 / scale, amax scratch]
+    check(lib.sgl_mi355_input_to_float8(ptr(xc), ptr(x_q), ptr(s), ptr(s[1:]), xc.numel(), dtype_code(xc.dtype), current_stream()))
+    return x_q, s[0]
+
+
 def sgl_per_token_group_quant_fp8(input, output_q, output_s, group_size, eps, fp8_min, fp8_max, scale_ue8m0) -> None:
     """gemm.py:100-112 (row-major float scales only)."""
     _cuda(input, output_q, output_s)

@@ -55,3 +55,17 @@ def per_token_group_quant_fp8(x: torch.Tensor, group_size: int, eps: float = 1e-
     x_s = torch.empty(x.shape[:-1] + (x.shape[-1] // group_size,), device=x.device, dtype=torch.float32)
     sgl_per_token_group_quant_fp8(x, x_q, x_s, group_size, eps, fp8_min, fp8_max, False)
     return x_q, x_s
+
+
+def static_quant_fp8(x: torch.Tensor, x_s: torch.Tensor, repeat_scale: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Static per-tensor quantisation with a given scale (fp8_kernel.py:437-490): x_q = sat(x * (1 / x_s)) as e4m3fn, returned with the
+    scale -- broadcast to one per row ([M, 1] f32) when ``repeat_scale``.  x: ndim >= 2, contiguous; x_s: one element."""
+    assert x.is_contiguous(), "`x` is not contiguous"
+    assert x_s.numel() == 1, "only supports per-tensor scale"
+    x_q = torch.empty_like(x, device=x.device, dtype=fp8_dtype)
+    scale = x_s.reshape(1).to(torch.float32)
+    sgl_per_tensor_quant_fp8(x, x_q, scale, is_static=True)
+    if repeat_scale:
+        m = x.numel() // x.shape[-1]
+        return x_q, scale.expand(m).reshape(m, 1).contiguous()
+    return x_q, x_s

@@ -3,12 +3,12 @@ to the two cases of the hot path, both served by the HIP fp8 GEMM with the fused
   * per-token dynamic activation x per-channel weight (W8A8Fp8LinearMethod, w8a8_fp8.py:177-190);
   * per-tensor activation (static or dynamic) x per-tensor weight (Fp8LinearMethod, fp8.py:444-501).
 The reference's HIP branch un-fuses this into torch._scaled_mm + two multiplies (:479-507); here it is one kernel."""
-from typing import Optional
+from typing import Optional, Tuple
 
 import torch
 
 from ....sgl_kernel import fp8_scaled_mm
-from .fp8_kernel import scaled_fp8_quant, sglang_per_token_quant_fp8
+from .fp8_kernel import fp8_dtype, scaled_fp8_quant, sglang_per_token_quant_fp8, static_quant_fp8  # noqa: F401 (static_quant_fp8: fp8_utils.py:23)
 
 
 def apply_fp8_linear(input: torch.Tensor, weight: torch.Tensor, weight_scale: torch.Tensor,
@@ -34,3 +34,12 @@ def apply_fp8_linear(input: torch.Tensor, weight: torch.Tensor, weight_scale: to
         sb = sb.expand(n).contiguous()
     out = fp8_scaled_mm(qinput, weight, sa, sb, out_dtype=input.dtype, bias=bias)
     return out.view(*output_shape)
+
+
+def input_to_float8(x: torch.Tensor, dtype: torch.dtype = fp8_dtype) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Tensor-wise quantisation of a tensor that arrives unquantised (fp8_utils.py:310-326; w8a8_fp8.py:129, fp8.py:375):
+    amax = max |x| clamped at 1e-12, scale = fp8_max / amax, x_q = sat(x * scale); returns (x_q, 1 / scale as a 0-dim f32 tensor)."""
+    from ....sgl_kernel.gemm import input_to_float8 as _hip_input_to_float8
+    if dtype != fp8_dtype:
+        raise RuntimeError(f"input_to_float8: only {fp8_dtype} on gfx950 (got {dtype})")
+    return _hip_input_to_float8(x)

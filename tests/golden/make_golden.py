@@ -576,6 +576,8 @@ def gen_interface():
         "triton_ops": {**functions("python/sglang/srt/layers/attention/triton_ops/decode_attention.py", {"decode_attention_fwd"}),
                        **functions("python/sglang/srt/layers/attention/triton_ops/extend_attention.py", {"extend_attention_fwd"})},
         "apply_fp8_linear": functions("python/sglang/srt/layers/quantization/fp8_utils.py", {"apply_fp8_linear"})["apply_fp8_linear"],
+        "fp8_helpers": {**functions("python/sglang/srt/layers/quantization/fp8_kernel.py", {"static_quant_fp8"}),
+                        **functions("python/sglang/srt/layers/quantization/fp8_utils.py", {"input_to_float8"})},
         "cpu_op_schemas": schemas,
     }
     with open(os.path.join(HERE, "interface.json"), "w") as f:

@@ -32,7 +32,8 @@ def _norm_default(d):
     if d is None:
         return None
     d = d.replace('"', "'")
-    return {"AttentionType.DECODER": "<AttentionType.DECODER: 'decoder'>"}.get(d, d)
+    # (fp8_dtype: the module constant of fp8_kernel.py:72-85 -- float8_e4m3fn on every target but gfx94x, and on gfx950)
+    return {"AttentionType.DECODER": "<AttentionType.DECODER: 'decoder'>", "fp8_dtype": "torch.float8_e4m3fn"}.get(d, d)
 
 
 def _check(ref_params, fn, where):
@@ -98,6 +99,11 @@ def test_sgl_kernel_op_signatures(pkg):
             assert hasattr(sgl_kernel, name), f"sgl_kernel.{name} is missing"
             _check(ref_params, getattr(sgl_kernel, name), f"sgl_kernel.{name}")
     _check(SNAP["apply_fp8_linear"], apply_fp8_linear, "apply_fp8_linear")
+    # a19's named helpers (fp8_kernel.py:437, fp8_utils.py:310; called by w8a8_fp8.py:129, fp8.py:375, fp8_utils.py:658)
+    from ltp_sglang_amd.srt.layers.quantization import fp8_kernel, fp8_utils
+    _check(SNAP["fp8_helpers"]["static_quant_fp8"], fp8_kernel.static_quant_fp8, "static_quant_fp8")
+    _check(SNAP["fp8_helpers"]["input_to_float8"], fp8_utils.input_to_float8, "input_to_float8")
+    assert fp8_utils.static_quant_fp8 is fp8_kernel.static_quant_fp8   # (fp8_utils.py:23 imports it)
 
 
 @gpu_free

@@ -1413,3 +1413,45 @@ def test_torch_ops_namespace_reaches_the_hip_kernels(sk, golden):
     torch.ops.sgl_kernel.merge_state_v2.default(a, sa, b, sb, vm, sm)
     ref_v, ref_s = sk.merge_state(a, sa, b, sb)
     assert torch.equal(vm, ref_v) and torch.equal(sm, ref_s)
+
+
+# ---------------------------------------------------------------- a19: static_quant_fp8 / input_to_float8 (fp8_kernel.py:437, fp8_utils.py:310)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(5, 128), (3, 7, 64), (1, 8), (64, 4104)])
+def test_static_quant_fp8_bytes_equal_the_reference_formula(dtype, shape, pkg):
+    """static_quant_fp8(x, x_s, repeat_scale) (fp8_kernel.py:395-490): y_q = clamp(y * (1 / y_s), -448, 448) -> e4m3fn; the scale is
+    returned as given, or broadcast to [M, 1] f32.  Byte-exact against that formula evaluated with torch on the CPU."""
+    from ltp_sglang_amd.srt.layers.quantization.fp8_kernel import static_quant_fp8
+    g = torch.Generator().manual_seed(7)
+    x = (torch.randn(shape, generator=g) * 3).to(dtype)
+    x.view(-1)[:4] = torch.tensor([1000.0, -1000.0, 0.0, 0.4375], dtype=dtype)   # saturation both ways, zero, a tie
+    x_s = torch.tensor([0.37], dtype=torch.float32)
+    want = (x.float() * (1.0 / x_s)).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+    for repeat in (False, True):
+        q, s = static_quant_fp8(x.to(DEV), x_s.to(DEV), repeat)
+        assert q.dtype == torch.float8_e4m3fn and q.shape == x.shape
+        assert torch.equal(q.cpu().view(torch.uint8), want.view(torch.uint8))
+        if repeat:
+            m = x.numel() // x.shape[-1]
+            assert s.shape == (m, 1) and s.dtype == torch.float32 and torch.equal(s.cpu(), x_s.expand(m).reshape(m, 1))
+        else:
+            assert s.numel() == 1 and float(s) == float(x_s)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape,scale", [((4096, 512), 1.0), ((33, 72), 250.0), ((8, 8), 1e-3), ((2, 16), 0.0)])
+def test_input_to_float8_bytes_equal_the_reference_formula(dtype, shape, scale, pkg):
+    """input_to_float8(x) (fp8_utils.py:310-326): amax clamped at 1e-12, scale = 448 / amax, q = clamp(x * scale) -> e4m3fn, returns
+    (q, 1 / scale).  Byte-exact against that formula on the CPU, the all-zero tensor included (amax clamp)."""
+    from ltp_sglang_amd.srt.layers.quantization.fp8_utils import input_to_float8
+    g = torch.Generator().manual_seed(11)
+    x = (torch.randn(shape, generator=g) * scale).to(dtype)
+    mn, mx = x.aminmax()
+    amax = torch.maximum(mn.abs(), mx.abs()).float().clamp(min=1e-12)
+    sc = 448.0 / amax
+    want_q = (x.float() * sc).clamp(min=-448.0, max=448.0).to(torch.float8_e4m3fn)
+    want_s = sc.float().reciprocal()
+    q, s = input_to_float8(x.to(DEV))
+    assert q.dtype == torch.float8_e4m3fn and q.shape == x.shape and q.is_contiguous()
+    assert torch.equal(q.cpu().view(torch.uint8), want_q.view(torch.uint8))
+    assert s.dtype == torch.float32 and s.dim() == 0 and float(s) == float(want_s)
