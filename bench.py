@@ -64,10 +64,78 @@ def parse_args():
     ap.add_argument("--all-reduce", default="auto", choices=["auto", "rccl", "p2p"],
                     help="N > 1: auto = the one-shot P2P all-reduce over IPC-mapped peer buffers when its start-up self-check against "
                          "RCCL passes, else RCCL; rccl / p2p force one")
+    ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3, 4, 5],
+                    help="BASELINE.json configs[N - 1] as the survey defines it (one driver-runnable command per configuration, "
+                         "bench_one_batch.py:527-546): 1 = the CPU plumbing case (oracle, no GPU); 2 = Llama-3-8B bf16 32 x 2048; "
+                         "3 = Llama-3-8B w8a8 batch 64, 1536 shared + 512 private tokens through the radix hit path and cascade decode; "
+                         "4 = Qwen2-7B int4 AWQ f16 32 x 1024; 5 = rank 0's shard of Llama-3-70B fp8 TP 8 (one process, collectives = "
+                         "same-size copies), batch 128, ragged lengths U(512, 4096).  0 = the flags as given (default: the headline).")
+    ap.add_argument("--seq-dist", default="uniform", choices=["uniform", "ragged"],
+                    help="ragged: per-request lengths drawn uniformly from [--seq-min, --seq-len] with a fixed seed, as "
+                         "bench_serving.py:1013 sample_random_requests draws them for every throughput run")
+    ap.add_argument("--seq-min", type=int, default=0, help="ragged: shortest request (default: --seq-len / 4)")
+    ap.add_argument("--shared-prefix", type=int, default=0,
+                    help="P > 0: every request = one common prefix of P tokens + (--seq-len - P) private tokens; the prefill goes through "
+                         "the radix cache (request 0 in full, the others extend over the cached prefix), decode uses cascade attention")
+    ap.add_argument("--spawn-timeout", type=float, default=1500.0, help="--gpus N without a launcher: wall-clock limit of the whole job (s)")
     ap.add_argument("--emulate-tp", type=int, default=0,
                     help="ONE process builds rank 0's shard of a tp-N model and replaces each collective by a same-size device copy: "
                          "per-rank compute ms/step without communication (TP-readiness measurement on a 1-GPU box; not the metric)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    preset = {2: dict(model="llama3-8b", quant="none", batch=32, seq_len=2048),
+              3: dict(model="llama3-8b", quant="w8a8_fp8", batch=64, seq_len=2048, shared_prefix=1536),
+              4: dict(model="qwen2-7b", quant="awq", batch=32, seq_len=1024, dtype="f16"),
+              5: dict(model="llama3-70b", quant="w8a8_fp8", batch=128, seq_len=4096, seq_min=512, seq_dist="ragged", emulate_tp=8)}.get(args.config)
+    for k, v in (preset or {}).items():
+        setattr(args, k, v)
+    if args.seq_dist == "ragged" and args.seq_min <= 0:
+        args.seq_min = max(1, args.seq_len // 4)
+    if args.shared_prefix and not (0 < args.shared_prefix < args.seq_len and args.seq_dist == "uniform"):
+        ap.error("--shared-prefix P needs 0 < P < --seq-len and uniform lengths")
+    return args
+
+
+def config1_cpu_plumbing(args):
+    """BASELINE configs[0]: greedy decode, batch 1, torch-native attention backend on the CPU -- the reference's own CPU-runnable case
+    (plumbing, no GPU).  Here: the oracle's restatement of that stack (oracle/model.py, torch-native attention) on a small Llama-shaped
+    network, a few greedy steps on the host cores; the parity of this path against the reference's goldens is tests/test_oracle_model.py."""
+    from oracle.model import OracleLlama
+    from types import SimpleNamespace
+
+    cores = min(len(os.sched_getaffinity(0)), 16)
+    torch.set_num_threads(cores)
+    cfg = SimpleNamespace(hidden_size=768, num_attention_heads=12, num_key_value_heads=12, head_dim=64, num_hidden_layers=12,
+                          intermediate_size=3072, vocab_size=50272, max_position_embeddings=2048, rope_theta=10000.0, rms_norm_eps=1e-5)
+    g = torch.Generator().manual_seed(0)
+
+    def w(n, k):
+        return ((torch.randn(n, k, generator=g) * 0.02).bfloat16(), None)
+
+    hq, d, hid, inter = cfg.num_attention_heads, cfg.head_dim, cfg.hidden_size, cfg.intermediate_size
+    weights = {"embed": (torch.randn(cfg.vocab_size, hid, generator=g) * 0.02).bfloat16(), "lm_head": (torch.randn(cfg.vocab_size, hid, generator=g) * 0.02).bfloat16(),
+               "norm": torch.ones(hid).bfloat16(),
+               "layers": [{"ln1": torch.ones(hid).bfloat16(), "ln2": torch.ones(hid).bfloat16(),
+                           "qkv": w(3 * hq * d, hid) + (None,), "o": w(hid, hq * d), "gate_up": w(2 * inter, hid), "down": w(hid, inter)}
+                          for _ in range(cfg.num_hidden_layers)]}
+    prompt, steps = 128, max(1, min(args.steps, 16))
+    m = OracleLlama(cfg, weights, torch.bfloat16, False, prompt + steps + 2)
+    r2t = torch.arange(1, prompt + steps + 2, dtype=torch.int32).view(1, -1)
+    rpi, ids = torch.zeros(1, dtype=torch.int64), torch.randint(0, 10000, (prompt,), generator=g)
+    seq = torch.tensor([prompt], dtype=torch.int64)
+    logits = m.forward(ids, torch.arange(prompt), r2t, rpi, seq, r2t[0, :prompt].long(), torch.zeros(1, dtype=torch.int32), torch.tensor([prompt], dtype=torch.int32))
+    nxt = logits[-1:].float().argmax(-1)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        seq = seq + 1
+        logits = m.forward(nxt, seq - 1, r2t, rpi, seq, r2t[0, seq[0] - 1].view(1).long())
+        nxt = logits[-1:].float().argmax(-1)
+    dt = (time.perf_counter() - t0) / steps
+    print(json.dumps({"metric": "decode tokens/sec, OPT-125m-sized network, greedy, batch 1, torch-native attention on the CPU (BASELINE configs[0]: plumbing, no GPU)",
+                      "value": 1.0 / dt, "unit": "tokens/s", "n_gpus": 0, "steps": steps, "warmup": 0, "ms_per_step": dt * 1e3, "higher_is_better": True,
+                      "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                      "config": {"workload": "OPT-125m-sized (12 layers, hidden 768, 12 heads x 64) greedy decode, batch 1, prompt 128, oracle/model.py on the host",
+                                 "baseline_config": 1, "global_batch": 1, "seq_len": prompt, "parallelism": "cpu"},
+                      "roofline": None, "cpu_baseline": {"value": 1.0 / dt, "unit": "tokens/s", "cores": cores, "kind": "port", "sample": "the measurement itself"}}))
 
 
 def cpu_baseline_sample(cfg, batch, seq_len, layers):
@@ -160,42 +228,82 @@ def _traffic_profile():
 def spawn_ranks(args):
     """`bench.py --gpus N` without a launcher (WORLD_SIZE unset): start the N ranks here -- one child process per GPU with RANK /
     LOCAL_RANK / WORLD_SIZE / MASTER_* set, the reference's bench_one_batch.py:527-546 (one process per tp_rank) -- relay rank 0's
-    stdout (the JSON line), and exit non-zero as soon as any rank does.  This parent never touches a GPU (no HIP call, no exec of a
-    process that has initialised one): the children are fresh interpreters."""
+    stdout (the JSON line), and exit non-zero as soon as any rank does.  This parent never touches a GPU (no HIP call, no torch.cuda
+    call, no exec of a process that has initialised one): the children are fresh interpreters in their own sessions, and every exit
+    path of the parent -- a failed rank, SIGTERM / SIGINT from a driver's timeout, the wall-clock limit, an exception -- ends them."""
+    import glob
+    import signal
     import socket
     import subprocess
 
     n = args.gpus
-    if args.dist_backend == "nccl" and torch.cuda.device_count() < n:   # (device_count() does not initialise the GPU on this image)
-        raise SystemExit(f"[bench] --gpus {n} over RCCL needs {n} visible GPUs, found {torch.cuda.device_count()} "
-                         f"(--dist-backend gloo rehearses the N > 1 path on fewer)")
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
+    # A profiler's preloaded library has initialised the GPU in THIS process already: starting N children from it is the exec hop the
+    # GPU pool forbids (and the counters would be per process anyway).  Profile one rank: `rocprofv3 ... -- python3 bench.py --gpus 1`.
+    if any(k.startswith(("ROCPROFILER_", "ROCPROF_", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        raise SystemExit("[bench] refusing to start the ranks of --gpus N under a profiler (its preloaded library has initialised the GPU "
+                         "in this process); profile a --gpus 1 run, or launch the ranks with torch.distributed.run")
+    if args.dist_backend == "nccl":
+        # GPUs from the KFD topology (no HIP / torch.cuda call in the parent): nodes with a non-zero simd_count
+        gpus = 0
+        for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+            try:
+                with open(f) as fh:
+                    gpus += any(ln.split()[0] == "simd_count" and int(ln.split()[1]) > 0 for ln in fh if ln.strip())
+            except OSError:
+                pass
+        if 0 < gpus < n:   # (0: topology not readable here -- let the ranks fail fast themselves)
+            raise SystemExit(f"[bench] --gpus {n} over RCCL needs {n} visible GPUs, the KFD topology lists {gpus} "
+                             f"(--dist-backend gloo rehearses the N > 1 path on fewer)")
+    with socket.socket() as sk:   # (bind-then-close can lose the port to another process in between: the ranks then fail at rendezvous
+        sk.bind(("127.0.0.1", 0))   #  and the job exits non-zero -- rerun; a launcher-provided MASTER_PORT avoids it)
         port = sk.getsockname()[1]
     procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL and the P2P all-reduce both need it on this driver
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else sys.stderr))   # only rank 0 owns stdout
+
+    def end_children(sig=signal.SIGTERM):
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, sig)   # the child's own session: itself and anything it started
+                except (ProcessLookupError, PermissionError):
+                    pass
+
+    def on_signal(signum, frame):
+        end_children()
+        raise SystemExit(128 + signum)
+
+    old = {sg: signal.signal(sg, on_signal) for sg in (signal.SIGTERM, signal.SIGINT)}
     rc = 0
-    live = list(procs)
-    while live and rc == 0:
-        time.sleep(0.2)
-        for p in list(live):
-            code = p.poll()
-            if code is not None:
-                live.remove(p)
-                if code != 0:
-                    rc = code if code > 0 else 1
-    for p in live:   # a rank failed: its peers would wait in a collective forever
-        p.terminate()
-    for p in live:
-        try:
-            p.wait(timeout=20)
-        except subprocess.TimeoutExpired:
-            p.kill()
+    try:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL and the P2P all-reduce both need it on this driver
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, start_new_session=True,
+                                          stdout=None if r == 0 else sys.stderr))   # only rank 0 owns stdout
+        deadline = time.monotonic() + args.spawn_timeout
+        live = list(procs)
+        while live and rc == 0:
+            time.sleep(0.2)
+            for p in list(live):
+                code = p.poll()
+                if code is not None:
+                    live.remove(p)
+                    if code != 0:
+                        rc = code if code > 0 else 1
+            if time.monotonic() > deadline:
+                print(f"[bench] the ranks did not finish within --spawn-timeout {args.spawn_timeout:.0f} s", file=sys.stderr)
+                rc = 124
+    finally:
+        end_children()   # a rank failed, the limit passed or this process is leaving: peers would wait in a collective forever
+        t_end = time.monotonic() + 20
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                pass
+        end_children(signal.SIGKILL)
+        for sg, h in old.items():
+            signal.signal(sg, h)
     if rc:
         print(f"[bench] a rank exited with code {rc}; the job is void", file=sys.stderr)
     raise SystemExit(rc)
@@ -203,6 +311,8 @@ def spawn_ranks(args):
 
 def main():
     args = parse_args()
+    if args.config == 1:
+        return config1_cpu_plumbing(args)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         spawn_ranks(args)   # does not return
     phases, t_phase = {}, time.perf_counter()
@@ -321,8 +431,15 @@ def main():
     quant = None if args.quant == "none" else args.quant
     bs, seq = args.batch, args.seq_len
     total_steps = args.steps + args.warmup + 4
-    runner = SyntheticModelRunner(cfg, quant, max_running_requests=bs, context_len=seq + total_steps + 8,
-                                  max_total_tokens=bs * (seq + total_steps) + 64, device=dev, seed=0,
+    import numpy as np
+
+    # per-request prompt lengths: uniform, or drawn like bench_serving.py:1013 draws them (seeded; every rank draws the same)
+    lens = ([seq] * bs if args.seq_dist == "uniform" else
+            [int(x) for x in np.random.RandomState(5).randint(args.seq_min, seq + 1, bs)])
+    P = args.shared_prefix            # tokens of the common prefix (0: none)
+    kv_tokens = P + sum(n - P for n in lens)   # distinct cached tokens after the prefill
+    runner = SyntheticModelRunner(cfg, quant, max_running_requests=bs, context_len=max(lens) + total_steps + 8,
+                                  max_total_tokens=kv_tokens + (2 * seq if P else 0) + bs * total_steps + 64, device=dev, seed=0,
                                   dtype=torch.float16 if args.dtype == "f16" else torch.bfloat16,
                                   kv_cache_dtype=torch.float8_e4m3fn if args.kv_cache_dtype == "fp8_e4m3" else None,
                                   max_kv_splits=args.max_kv_splits, kv_split_rule=args.kv_split_rule)
@@ -342,17 +459,49 @@ def main():
 
     phase("setup")
     # ---- prefill: fills the KV pool (random token ids as bench_one_batch.py:215) and measures prefill TFLOP/s ----
-    import numpy as np
-
     # (ids below 10 000 as bench_one_batch.py:215 draws them, and below the vocabulary: `--model tiny` has 2 048 rows -- round 4
     # found its lookups reading 8 MB past the embedding table, garbage that ended in a GPU fault one step later)
-    ids = torch.from_numpy(np.random.RandomState(0).randint(0, min(10000, cfg.vocab_size), (bs, seq))).to(dev)
-    # untimed warm-up prefill, undone: the SAME chunks at full length (bench_one_batch.py warms up with the batch it then measures) --
+    rs = np.random.RandomState(0)
+    vmax = min(10000, cfg.vocab_size)
+    if P:
+        common = rs.randint(0, vmax, P)
+        prompts = [torch.from_numpy(np.concatenate([common, rs.randint(0, vmax, n - P)])).to(dev) for n in lens]
+    else:
+        prompts = [torch.from_numpy(rs.randint(0, vmax, n)).to(dev) for n in lens]
+
+    def prefill_all():
+        """The whole batch's prompts -> KV pool; returns (states, last-token logits) in request order.  With a shared prefix: the
+        RadixAttention hit path -- request 0 in full, its slots inserted into the radix tree, every other request matched against the
+        tree and extended over the cached prefix (scheduler flow of schedule_batch.py / radix_cache.py: match_prefix -> extend)."""
+        states, logits = [], []
+        if not P:
+            for c0 in range(0, bs, args.prefill_chunk):
+                lg, st = runner.extend(prompts[c0:c0 + args.prefill_chunk])
+                states.append(st)
+                logits.append(lg)
+            return states, logits
+        from ltp_sglang_amd.srt.mem_cache.radix_cache import RadixCache
+
+        cache = RadixCache(runner.req_to_token_pool, runner.token_to_kv_pool_allocator, page_size=1)
+        lg, st = runner.extend([prompts[0]])
+        cache.insert(prompts[0].tolist(), runner.req_to_token_pool.req_to_token[st.req_pool_indices[0], : lens[0]].to(torch.int64))
+        states.append(st)
+        logits.append(lg)
+        for c0 in range(1, bs, args.prefill_chunk):
+            chunk = prompts[c0:c0 + args.prefill_chunk]
+            hits = [cache.match_prefix(p_.tolist()).device_indices for p_ in chunk]
+            if not all(int(h.numel()) == P for h in hits):
+                raise SystemExit(f"[bench] rank {rank}: the radix cache matched {[int(h.numel()) for h in hits][:4]}... tokens, expected the {P}-token prefix")
+            lg, st = runner.extend([p_[P:] for p_ in chunk], prefix_indices=[h.to(dev) for h in hits])
+            states.append(st)
+            logits.append(lg)
+        return states, logits
+
+    # untimed warm-up prefill, undone: the SAME calls at full length (bench_one_batch.py warms up with the batch it then measures) --
     # it loads every prefill kernel's code object, sets the LDS attributes, and lets the caching allocator obtain the multi-GB
     # activation buffers once.  (Round 4: with a 512-token warm-up the timed prefill made those first hipMallocs itself; one run of
     # the round read 0.677 s where the runs around it read 0.46 s.)
-    for c0 in range(0, bs, args.prefill_chunk):
-        runner.extend([ids[i] for i in range(c0, min(bs, c0 + args.prefill_chunk))])
+    prefill_all()
     torch.cuda.synchronize()
     runner.clear()
     # the allocator hands out consecutive slots; a random permutation of the free list makes the gather non-contiguous
@@ -362,11 +511,7 @@ def main():
     barrier()
     phase("prefill_warmup")
     t0 = time.perf_counter()
-    states, last_logits = [], []
-    for c0 in range(0, bs, args.prefill_chunk):
-        logits, st = runner.extend([ids[i] for i in range(c0, min(bs, c0 + args.prefill_chunk))])
-        states.append(st)
-        last_logits.append(logits)
+    states, last_logits = prefill_all()
     barrier()
     prefill_s = time.perf_counter() - t0
     phase("prefill")
@@ -383,7 +528,12 @@ def main():
     hq_s, hkv_s = hq // tp, max(1, hkv // tp)
     ranks_run = 1 if args.emulate_tp > 1 else world
     lin_params = ranks_run * L * ((hq_s * d + 2 * hkv_s * d) * hid + hq_s * d * hid + 3 * (inter // tp) * hid)
-    prefill_flops = (2.0 * lin_params * bs * seq + ranks_run * (L * bs * (4.0 * seq * seq * hq_s * d) / 2 + 2.0 * (V // tp) * hid * bs))
+    # what the timed prefill executes: the linears over the NEW tokens of every call, causal attention of the new tokens over
+    # (cached prefix + themselves), the lm_head on each request's last token
+    new_tok = [lens[0]] + [n - P for n in lens[1:]] if P else list(lens)
+    pre_tok = [0] + [P] * (bs - 1) if P else [0] * bs
+    attn_flops = sum(4.0 * hq_s * d * (nw * pr + nw * nw / 2.0) for nw, pr in zip(new_tok, pre_tok))
+    prefill_flops = 2.0 * lin_params * sum(new_tok) + ranks_run * (L * attn_flops + 2.0 * (V // tp) * hid * bs)
     first_logits = torch.cat(last_logits)
     if not bool(torch.isfinite(first_logits.float()).all()):   # outside the timed regions; a throughput over NaNs is not a measurement
         raise SystemExit(f"[bench] rank {rank}: the prefill produced non-finite logits")
@@ -400,7 +550,7 @@ def main():
     if use_graph:
         why = ""
         try:
-            runner.capture_decode_graph(bs)
+            runner.capture_decode_graph(bs, shared_prefix_len=P)
         except Exception as e:
             why = f"{type(e).__name__}: {e}"
             use_graph = False
@@ -422,7 +572,8 @@ def main():
             # a launch-bound eager number must never be recorded as the metric by accident: every rank leaves (they all agree)
             raise SystemExit(3)
     phase("capture")
-    step_fn = runner.decode_graph if use_graph else runner.decode
+    base_fn = runner.decode_graph if use_graph else runner.decode
+    step_fn = (lambda st_, ids_: base_fn(st_, ids_, shared_prefix_len=P)) if P else base_fn
     for _ in range(args.warmup):
         next_ids = K_argmax(step_fn(state, next_ids))
     barrier()
@@ -466,7 +617,13 @@ def main():
         for l in range(L):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            if in_launch_merge:
+            if md.cascade_prefix_indices is not None:
+                # the launch pair the captured step runs over a shared prefix: prefix once for all requests + private suffixes, merged
+                K.decode_attention_cascade(qd, pool.get_key_buffer(l), pool.get_value_buffer(l), md.cascade_prefix_indices,
+                                           md.cascade_prefix_splits, md.kv_indptr, md.kv_indices, md.attn_logits, md.attn_lse,
+                                           md.num_kv_splits, be.max_kv_splits, d ** -0.5, be._merge_counter_buf(qd), 0.0, kscale, vscale,
+                                           want_o=not fp8_lin, want_quant=fp8_lin)
+            elif in_launch_merge:
                 # the launch the captured step runs: stage 1 + the stage-2 merge + per-token fp8 quant of the merged rows by each
                 # request's last workgroup (r3's probe timed stage 1 alone, a cheaper launch than the step's)
                 K.decode_attention_merge_quant(qd, pool.get_key_buffer(l), pool.get_value_buffer(l), md.kv_indptr, md.kv_indices,
@@ -481,7 +638,9 @@ def main():
     torch.cuda.synchronize()
     attn_ms = sorted(a.elapsed_time(b) for a, b in evs[L:])  # first sweep = warm-up
     attn_ms = sum(attn_ms) / len(attn_ms)
-    kv_bytes = float(sum(state.seq_lens_cpu)) * hkv_r * d * 2 * kv_es  # K and V rows of every cached token
+    # algorithmic bytes: K and V rows of every DISTINCT cached token (a shared prefix is counted once: what a perfect kernel reads)
+    kv_rows = float(sum(state.seq_lens_cpu)) - (bs - 1) * P
+    kv_bytes = kv_rows * hkv_r * d * 2 * kv_es
     achieved = kv_bytes / (attn_ms * 1e-3) / 1e9
 
     phase("roofline_probe")
@@ -500,23 +659,29 @@ def main():
             traffic_sha = pmc.get("git_sha")
     tok_s = bs * args.steps / elapsed
     weights_bytes = lin_params * (1 if quant in ("w8a8_fp8", "fp8") else (0.5 if quant == "awq" else 2)) + ranks_run * (V // tp) * hid * 2
-    step_bytes = weights_bytes + ranks_run * bs * (seq + args.warmup + args.steps / 2) * L * 2 * hkv_s * d * kv_es
+    step_bytes = weights_bytes + ranks_run * (kv_tokens + bs * (args.warmup + args.steps / 2)) * L * 2 * hkv_s * d * kv_es
     out = {
         "metric": ("decode tokens/sec (whole job) + prefill TFLOPS, Llama-3-8B fp8 batch=32 seq=2048"
-                   if (args.model, args.quant, bs, seq, args.kv_cache_dtype) == ("llama3-8b", "w8a8_fp8", 32, 2048, "auto") else
-                   f"decode tokens/sec (whole job) + prefill TFLOPS, {args.model} {args.quant} batch={bs} seq={seq} kv={args.kv_cache_dtype}")
+                   if (args.model, args.quant, bs, seq, args.kv_cache_dtype, args.seq_dist, P) == ("llama3-8b", "w8a8_fp8", 32, 2048, "auto", "uniform", 0) else
+                   f"decode tokens/sec (whole job) + prefill TFLOPS, {args.model} {args.quant} batch={bs} seq={seq} kv={args.kv_cache_dtype}"
+                   + (f" ragged U({args.seq_min},{seq})" if args.seq_dist == "ragged" else "") + (f" shared prefix {P}" if P else ""))
                   + ("" if use_graph else " [EAGER launches, no HIP graph: launch-bound, not the metric]"),
         "value": tok_s, "unit": "tokens/s", "n_gpus": args.gpus, "world_size_observed": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "fp8_e4m3 weights+activations (f32 accumulate), bf16 KV/attention" if quant in ("w8a8_fp8", "fp8") else str(quant or "bf16"),
         "data": "synthetic",
-        "config": {"workload": f"{args.model} {args.quant} decode, batch {bs} x context {seq} (+{args.warmup}+{args.steps} steps), "
-                               f"KV pool filled by a real {bs}x{seq} prefill", "global_batch": bs, "seq_len": seq,
+        "config": {"workload": f"{args.model} {args.quant} decode, batch {bs} x context "
+                               + (f"U({args.seq_min}, {seq}) (seeded; mean {sum(lens) / bs:.0f})" if args.seq_dist == "ragged" else f"{seq}")
+                               + (f" = {P} shared (one radix node, cascade attention) + {seq - P} private" if P else "")
+                               + f" (+{args.warmup}+{args.steps} steps), KV pool filled by a real prefill of the same prompts"
+                               + (" through the radix hit path" if P else ""),
+                   "baseline_config": args.config or None, "global_batch": bs, "seq_len": seq, "seq_dist": args.seq_dist,
+                   "seq_lens": {"min": min(lens), "mean": sum(lens) / bs, "max": max(lens)}, "shared_prefix": P,
                    "parallelism": f"tp{tp}" + (" (EMULATED: rank 0's shard in one process, collectives = same-size device copies)" if args.emulate_tp > 1 else ""),
                    "all_reduce": ar_kind, "hip_graph": bool(use_graph), "layers": L, "kv_cache_dtype": args.kv_cache_dtype,
                    "act_dtype": args.dtype},
-        "prefill": {"tflops": prefill_flops / prefill_s / 1e12, "seconds": prefill_s, "tokens": bs * seq,
-                    "tokens_per_s": bs * seq / prefill_s, "flops": prefill_flops,
+        "prefill": {"tflops": prefill_flops / prefill_s / 1e12, "seconds": prefill_s, "tokens": sum(new_tok), "prompt_tokens": sum(lens),
+                    "tokens_per_s": sum(new_tok) / prefill_s, "prompt_tokens_per_s": sum(lens) / prefill_s, "flops": prefill_flops,
                     "requests_per_extend_call": min(bs, args.prefill_chunk)},
         "step_roofline": {"algorithmic_bytes_per_step": step_bytes, "hbm_peak_GBps": 8000.0,
                           "ranks_counted": ranks_run,
@@ -526,7 +691,11 @@ def main():
                      "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                      "traffic_source": traffic_src, "traffic_profile_git_sha": traffic_sha, "launch_us": attn_ms * 1e3, "algorithmic_bytes_per_launch": kv_bytes},
     }
-    if not args.no_cpu_baseline and args.model != "tiny" and world == 1 and args.emulate_tp <= 1:  # rank 0 at N = 1 only
+    # what the split rule made of the batch (SURVEY 7 hard-part (d): split-KV balance under raggedness)
+    sp = md.num_kv_splits[:bs].cpu().tolist()
+    out["kv_splits"] = {"rule": args.kv_split_rule, "max_kv_splits": args.max_kv_splits,
+                        "histogram": {str(v): sp.count(v) for v in sorted(set(sp))}, "workgroup_units": int(sum(sp)) * hkv_r}
+    if not args.no_cpu_baseline and args.model != "tiny" and world == 1 and args.emulate_tp <= 1 and args.config in (0,):  # rank 0 at N = 1 only; the headline run
         out["cpu_baseline"] = cpu_baseline_sample(cfg, bs, seq, L)
     phase("cpu_baseline")
     out["phases_s"] = phases

@@ -135,7 +135,8 @@ __global__ __launch_bounds__(256) void per_tensor_quant_kernel(const T* __restri
 }
 
 // input_to_float8 (python/sglang/srt/layers/quantization/fp8_utils.py:310-326; weights that arrive unquantised: w8a8_fp8.py:129,
-// fp8.py:375): amax = max |x| clamped at 1e-12, scale = 448 / amax, q = sat(x * scale) (RNE), returns 1 / scale.  The reference's
+// fp8.py:375): amax = max |x| clamped at 1e-12, scale = 448 / amax (evaluated as torch does: (1 / amax) * 448), q = sat(x * scale) (RNE),
+// returns 1 / scale.  The reference's
 // arithmetic order, not the per-tensor kernel's (x * (1 / (amax / 448))): the two differ in the last bit of the factor.
 template <typename T>
 __global__ __launch_bounds__(256) void raw_absmax_kernel(const T* __restrict__ in, float* __restrict__ out_amax, int64_t n) {
@@ -161,7 +162,8 @@ __global__ __launch_bounds__(256) void input_to_float8_kernel(const T* __restric
                                                               float* __restrict__ out_s, int64_t n) {
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  const float scale = kFp8Max / fmaxf(*amax_p, 1e-12f);
+  // `fp_max / amax` with a Python float on the left is Tensor.__rtruediv__ = amax.reciprocal() * fp_max in torch: two roundings
+  const float scale = (1.0f / fmaxf(*amax_p, 1e-12f)) * kFp8Max;
   if (gid == 0) *out_s = 1.0f / scale;
   const int64_t nvec = n / 8;
   for (int64_t i = gid; i < nvec; i += stride) {
