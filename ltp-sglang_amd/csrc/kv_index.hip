@@ -159,27 +159,9 @@ __global__ __launch_bounds__(1024) void decode_meta_kernel(int32_t* kv_indptr, i
     int64_t T = (tot * units + target_wgs - 1) / target_wgs;
     T = (T + 31) / 32 * 32;
     if (T < 64) T = 64;
-    // (round 5) RAGGED batches: sum_i ceil(len_i / T) exceeds tot / T, the overflow starts a second, mostly empty round of workgroups
-    // and the launch takes up to two split lengths (BASELINE config 5's shard, batch 128 x U(512, 4096): 309 units on 256 CUs, the
-    // launch at 0.41 of the HBM roofline against 0.62 at equal lengths).  Lengthen T until the units fit ONE round (a few passes:
-    // every pass is one block-wide sum); batches of equal lengths already fit and keep their T.
-    for (int pass = 0; pass < 4; ++pass) {
-      int64_t cnt = 0;
-      for (int i = tid; i < num_seq; i += 1024) {
-        const int64_t ns = (ld_idx(seq_lens, i, sl64) + T - 1) / T;
-        cnt += ns < 1 ? 1 : (ns > max_kv_splits ? max_kv_splits : ns);
-      }
-#pragma unroll
-      for (int m = 32; m >= 1; m >>= 1) cnt += __shfl_xor(cnt, m, WAVE);
-      __syncthreads();
-      if ((tid & 63) == 0) scan[tid >> 6] = cnt;
-      __syncthreads();
-      cnt = 0;
-      for (int w = 0; w < 16; ++w) cnt += scan[w];
-      if (cnt * units <= target_wgs) break;   // (block-uniform)
-      T = (T * cnt * units + target_wgs - 1) / target_wgs;
-      T = (T + 31) / 32 * 32;
-    }
+    // (round 5, measured and NOT kept: lengthening T for ragged batches until sum_i ceil(len_i / T) units fit one round -- BASELINE
+    // config 5's shard, batch 128 x U(512, 4096), one kv head: 309 -> 255 units, attention launch 44.5 -> 46.4 us: the launch time
+    // follows the longest unit, which grew with T; profiles/round5_configs.json)
     for (int i = tid; i < num_seq; i += 1024) {
       const int64_t len = ld_idx(seq_lens, i, sl64);
       int ns = (int)((len + T - 1) / T);

@@ -509,29 +509,3 @@ def test_backend_cascade_metadata_and_forward(pkg):
     with pytest.raises(ValueError, match="longer than the shared prefix"):
         backend.init_forward_metadata_cascade(fb, int(P["seq"].min()))
 
-
-def test_balance_rule_fits_ragged_batches_into_one_round(pkg):
-    """decode_metadata mode 2 (the MI355X balance rule; the reference's heuristic is mode 0 and golden-pinned): for RAGGED lengths the
-    split length is lengthened until sum_i ceil(len_i / T) x (kv heads x head chunks) fits the resident-workgroup target -- round 4's
-    rule sized T for the total only and BASELINE config 5's shard (batch 128, U(512, 4096), one kv head) launched 309 units on 256
-    CUs.  Properties: every request gets >= 1 split, the cumsum is exact, the units fit, and equal-length batches keep the splits
-    round 4 gave them (bs 32 x 2048, 8 kv heads: 2 each)."""
-    from ltp_sglang_amd import sgl_kernel as K
-    rng = np.random.RandomState(5)
-    cores = 256
-    for bs, hq, hkv, lo, hi in ((128, 8, 1, 512, 4096), (128, 64, 8, 512, 4096), (37, 32, 8, 1, 700), (300, 8, 1, 100, 9000)):
-        lens = torch.from_numpy(rng.randint(lo, hi + 1, bs)).to(torch.int64)
-        indptr = torch.zeros(bs + 1, dtype=torch.int32, device=DEV)
-        splits = torch.zeros(bs, dtype=torch.int32, device=DEV)
-        K.decode_metadata(indptr, splits, lens.to(DEV), 1, hq, hkv, 16, cores, 2)
-        torch.cuda.synchronize()
-        sp = splits.cpu().long()
-        assert torch.equal(indptr.cpu()[1:].long(), torch.cumsum(lens, 0)) and int(sp.min()) >= 1 and int(sp.max()) <= 16
-        units = hkv * ((hq // hkv + 15) // 16)
-        target = (1 if 2 * units * bs <= cores else 2) * cores
-        if int(sp.max()) < 16 and bs * units <= target:   # (the cap, or more requests than residents, can make a fit impossible)
-            assert int(sp.sum()) * units <= target, (bs, hq, hkv, int(sp.sum()) * units, target)
-    lens = torch.full((32,), 2048, dtype=torch.int64)
-    splits = torch.zeros(32, dtype=torch.int32, device=DEV)
-    K.decode_metadata(torch.zeros(33, dtype=torch.int32, device=DEV), splits, lens.to(DEV), 1, 32, 8, 16, cores, 2)
-    assert splits.cpu().tolist() == [2] * 32
