@@ -301,9 +301,10 @@ int sgl_mi355_fp8_gemm_silu_mul(const void* x, int64_t x_stride_elems, const voi
                                 void* act, int64_t act_stride_elems, const float* scales_x,
                                 const float* scales_w_interleaved, int M, int N, int K, int out_dtype, int tile_rows, void* stream);
 /* Per-device initialisation for the M > 64 form of the SiluAndMul fusion above (SiluAndMul.forward_native, activation.py:60-63,
- * evaluated through a table that is bit-identical to it by construction): enqueues the table fill on `stream` of the current
- * device and returns without synchronising; call once per device outside stream capture and order later work after it.  The
- * M > 64 form returns SGL_MI355_EINVAL until it has been called on the device. */
+ * evaluated through a table that is bit-identical to it by construction): runs the table fill on `stream` of the current device
+ * and waits for it -- when it returns the table is ready for every stream of the device.  Call once per device, outside stream
+ * capture (REQUIRED call order since round 4: the M > 64 form returns SGL_MI355_EINVAL until it has been called on the device;
+ * round 3 filled the table inside the first launch).  Idempotent. */
 int sgl_mi355_silu_table_init(void* stream);
 /* qkv_proj (fp8_scaled_mm) + neox RoPE (rotary_embedding.py:49-72) + set_kv_buffer (memory_pool.py:401-407) in one launch
  * (models/llama.py:180-191); rows interleaved inside every q/k head so rotation pairs share a 16-row tile. */

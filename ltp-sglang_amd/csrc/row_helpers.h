@@ -43,17 +43,20 @@ __device__ __forceinline__ u32x2_t pack8_fp8(const float (&f)[8]) {
 
 __device__ __forceinline__ float clamp448(float v) { return fmaxf(fminf(v, kFp8Max), -kFp8Max); }
 
+// (block_sum / block_max / quant_row / merge_quant_row: the FIRST 256 threads of the workgroup do the work -- red: 4 floats -- and any
+// further waves (the decode kernel's 512-thread form) only pass the barriers: round 4 let them recompute and re-store the rows of
+// waves 0-3, correct by accident and twice the merge traffic on the launch's critical path)
 __device__ __forceinline__ float block_sum(float v, float* red) {
   v = wave_reduce_sum(v);
   __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  if ((threadIdx.x & 63) == 0 && threadIdx.x < 256) red[threadIdx.x >> 6] = v;
   __syncthreads();
   return red[0] + red[1] + red[2] + red[3];
 }
 __device__ __forceinline__ float block_max(float v, float* red) {
   v = wave_reduce_max(v);
   __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  if ((threadIdx.x & 63) == 0 && threadIdx.x < 256) red[threadIdx.x >> 6] = v;
   __syncthreads();
   return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
@@ -61,10 +64,11 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 // per-token fp8 quantisation of the row held in vals (already rounded to T), exactly per_token_quant_fp8.cu
 template <int MAXV>
 __device__ __forceinline__ void quant_row(const float (&vals)[MAXV][8], int nvec, uint8_t* qrow, float* srow, float* red) {
+  const bool on = threadIdx.x < 256;
   float amax = 0.f;
 #pragma unroll
   for (int it = 0; it < MAXV; ++it)
-    if ((int)threadIdx.x + it * 256 < nvec)
+    if (on && (int)threadIdx.x + it * 256 < nvec)
 #pragma unroll
       for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(vals[it][j]));
   amax = block_max(amax, red);
@@ -74,7 +78,7 @@ __device__ __forceinline__ void quant_row(const float (&vals)[MAXV][8], int nvec
 #pragma unroll
   for (int it = 0; it < MAXV; ++it) {
     const int i = threadIdx.x + it * 256;
-    if (i < nvec) {
+    if (on && i < nvec) {
       float f[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) f[j] = clamp448(vals[it][j] * inv);
@@ -84,7 +88,7 @@ __device__ __forceinline__ void quant_row(const float (&vals)[MAXV][8], int nvec
 }
 
 
-// One 256-thread workgroup: merge the split partials of every head of request b (decode stage 2,
+// One workgroup (its first 256 threads): merge the split partials of every head of request b (decode stage 2,
 // decode_attention.py:492-552), round to T, optionally store, optionally per-token fp8 quantise.  `red`: 4 floats of LDS.
 template <typename T, int MAXV>
 __device__ __forceinline__ void merge_quant_row(int b, const float* attn_logits, const float* attn_lse, int seq_len, int nsplit,
@@ -97,10 +101,11 @@ __device__ __forceinline__ void merge_quant_row(int b, const float* attn_logits,
   auto live = [&](int sI) -> bool { return sI < total && (sI * per < seq_len || (sI == 0 && split0_always)); };
   const int row_elems = hq * dv, nvec = row_elems / 8;
   float vals[MAXV][8];
+  const bool on = threadIdx.x < 256;
 #pragma unroll
   for (int it = 0; it < MAXV; ++it) {
     const int i = threadIdx.x + it * 256;
-    if (i < nvec) {
+    if (on && i < nvec) {
       const int e0 = i * 8, h = e0 / dv, d0 = e0 - h * dv;
       const int64_t slot0 = ((int64_t)b * hq + h) * max_kv_splits;
       LseMerge mg;

@@ -791,7 +791,7 @@ extern "C" int sgl_mi355_gemm_silu_mul(const void* x, int64_t x_stride_elems, co
                             in_dtype, out_dtype, tile_rows, stream, nullptr);
 }
 
-// The same with per-launch scratch (round 4): `sched` = 16 int32 words of device memory that no other launch in flight uses (one
+// The same with per-launch scratch (round 4): `sched` = 8 int32 words (one per XCD) of device memory that no other launch in flight uses (one
 // buffer per stream is enough: launches of a stream are ordered).  With it the M > 64 form runs the persistent 256 x 256 kernel on a
 // DYNAMIC per-XCD tile schedule (workgroups that finish early take more tiles; the launcher zeroes the words with a memset node, the
 // kernel leaves them dirty) -- the same bits as without; NULL or M <= 64: exactly sgl_mi355_gemm_silu_mul.

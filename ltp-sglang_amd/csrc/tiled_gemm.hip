@@ -1169,6 +1169,9 @@ int launch(GemmParams& p, hipStream_t st, float* workspace = nullptr, int64_t wo
 }
 
 // split-K ranges of the streaming 128x128 tile for this shape (1: none) and the slices per range
+// floats of a caller's workspace that may hold split-K slabs: all but the ticket ring in its last 512 words (gemm_entry)
+inline int64_t slab_capacity(int64_t workspace_floats) { return workspace_floats >= 4096 ? workspace_floats - 512 : workspace_floats; }
+
 inline int splits128s(int M, int N, int kbytes, bool have_workspace, int64_t workspace_floats, int* kt_per) {
   const int tiles = ((M + S_BM - 1) / S_BM) * ((N + S_BN - 1) / S_BN), nk = kbytes / BKB, cus = tg_cus();
   int splits = 1;
@@ -1299,6 +1302,9 @@ int run(const void* x, int64_t xs, const void* w, int64_t ws, void* y, int64_t y
   int* sched = (workspace != nullptr && workspace_floats >= 4096)
                    ? (int*)(workspace + workspace_floats - 512) + 8 * (sched_slot.fetch_add(1, std::memory_order_relaxed) & 63u)
                    : nullptr;
+  // split-K slabs are sized against the workspace WITHOUT those 512 words (round 4 sized them against all of it: a slab set that
+  // filled the buffer overlapped the ticket words, and a later persistent launch's memset would have zeroed live partial sums)
+  workspace_floats = slab_capacity(workspace_floats);
   if (in_dtype == SGL_FP8_E4M3) {
     // both LDS-DMA kernels want whole 128-byte K slices
     const bool can256 = p.kbytes % BKB == 0 && p.kbytes >= BKB && (int64_t)N * p.w_stride < 0xFFFFFFF0ll &&
@@ -1345,13 +1351,14 @@ __global__ __launch_bounds__(256) void silu_lut_fill_kernel() {
   for (int i = threadIdx.x + 256 * blockIdx.x; i < kSiluLut; i += 256 * gridDim.x) g_silu_lut[i] = silu_lut_entry(i);
 }
 constexpr int kMaxSiluDevices = 64;
-std::atomic<bool> g_silu_table_ready[kMaxSiluDevices];   // set by sgl_mi355_silu_table_init once the fill has been ENQUEUED
+std::atomic<bool> g_silu_table_ready[kMaxSiluDevices];   // set by sgl_mi355_silu_table_init once the fill has COMPLETED
 
 }  // namespace
 
-// Per-device initialisation of the SiluAndMul epilogue's table (csrc/silu_lut.h): enqueues the fill kernel on `stream` of the
-// CURRENT device and returns -- no host synchronisation.  The caller orders later work after it (the Python wrapper waits for the
-// device once).  Idempotent; refused under stream capture (a captured fill would run at replay, not now).
+// Per-device initialisation of the SiluAndMul epilogue's table (csrc/silu_lut.h): runs the fill kernel on `stream` of the CURRENT
+// device and WAITS for it (a one-off outside any capture) -- the table is ready for every stream of the device when this returns.
+// (Round 4 set the flag when the fill was enqueued: a C-ABI caller on another stream could pass the readiness check and read a
+// partly filled table)  Idempotent; refused under stream capture (a captured fill would run at replay, not now).
 extern "C" int sgl_mi355_silu_table_init(void* stream) {
   hipStream_t st = (hipStream_t)stream;
   int dev = -1;
@@ -1359,8 +1366,13 @@ extern "C" int sgl_mi355_silu_table_init(void* stream) {
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   SGL_CHECK(hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone,
             "silu_table_init: must not be called while the stream is capturing");
+  if (g_silu_table_ready[dev].load(std::memory_order_acquire)) return SGL_MI355_OK;
   hipLaunchKernelGGL(silu_lut_fill_kernel, dim3(4), dim3(256), 0, st);
   SGL_HIP_LAUNCH_CHECK();
+  if (hipStreamSynchronize(st) != hipSuccess) {
+    snprintf(g_sgl_mi355_err, sizeof(g_sgl_mi355_err), "silu_table_init: the fill kernel did not complete");
+    return SGL_MI355_EHIP;
+  }
   g_silu_table_ready[dev].store(true, std::memory_order_release);
   return SGL_MI355_OK;
 }
@@ -1431,12 +1443,13 @@ extern "C" int sgl_mi355_fp8_gemm(const void* x, int64_t x_stride_elems, const v
 // 128-byte slices, the old 128x128 kernel), 1 = streaming 128x128 tile, 2 = 256x128 tile.
 extern "C" int sgl_mi355_fp8_gemm_tile_choice(int M, int N, int K, int64_t workspace_floats) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
-  return (int)choose_tile(M, N, K, K, K, true, workspace_floats);
+  return (int)choose_tile(M, N, K, K, K, true, slab_capacity(workspace_floats));
 }
 
 // How many f32 [M, N] slabs sgl_mi355_fp8_gemm sums for this shape when given `workspace_floats` of scratch (1: it runs as one
 // k-range; > 1 only where takes128s() picks the streaming tile and its tiles are fewer than CUs).  Contiguous rows assumed.
 extern "C" int sgl_mi355_fp8_gemm_num_slabs(int M, int N, int K, int64_t workspace_floats) {
+  workspace_floats = slab_capacity(workspace_floats);
   if (M <= 0 || N <= 0 || K <= 0 || !takes128s(M, N, K, K, K, true, workspace_floats)) return 1;
   int kt_per = 0;
   return splits128s(M, N, K, true, workspace_floats, &kt_per);
@@ -1450,6 +1463,7 @@ extern "C" int sgl_mi355_fp8_gemm_slabs(const void* x, int64_t x_stride_elems, c
   SGL_CHECK(x && w && slabs && M > 0 && N > 0 && K > 0, "fp8_gemm_slabs: bad arguments");
   SGL_CHECK(K % 16 == 0 && x_stride_elems % 16 == 0 && w_stride_elems % 16 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0,
             "fp8_gemm_slabs: rows must be 16-byte aligned (K=%d)", K);
+  workspace_floats = slab_capacity(workspace_floats);
   SGL_CHECK(takes128s(M, N, K, x_stride_elems, w_stride_elems, true, workspace_floats), "fp8_gemm_slabs: M=%d N=%d K=%d is not a streaming-tile shape", M, N, K);
   GemmParams p;
   p.x = (const char*)x; p.x_stride = x_stride_elems;

@@ -24,11 +24,12 @@ def _workspace(device, need: int):
     one is parked in ``_RETIRED`` for the life of the process instead of being returned to the caching allocator (where
     another tensor would receive its memory while an old graph still writes split-K partials into it)."""
     buf = _WORKSPACES.get(device)
+    need = int(need) + 512   # the ticket slots are never part of a slab set (ADVICE r4: a set that filled the buffer overlapped them)
     if buf is None or buf.numel() < need:
         if buf is not None:
             _RETIRED.append(buf)
         # (the last 512 words are the persistent tile kernel's ticket slots, zeroed by its launcher before every launch)
-        buf = torch.zeros(max(int(need), WORKSPACE_FLOATS), dtype=torch.float32, device=device)
+        buf = torch.zeros(max(need, WORKSPACE_FLOATS), dtype=torch.float32, device=device)
         _WORKSPACES[device] = buf
     return buf, buf.numel()
 

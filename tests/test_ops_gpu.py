@@ -669,8 +669,8 @@ def test_fp8_scaled_mm_persistent_256_kernel_bits_equal_one_tile_per_workgroup(m
 
 @pytest.mark.parametrize("m,n,k", [(8192, 4096, 512), (4100, 8200, 384), (4352, 7936, 9216)])
 def test_persistent_256_kernel_dynamic_tile_schedule_same_bits(m, n, k, sk):
-    """Round 4: the persistent kernel draws its tiles after the first from per-XCD ticket counters (the last 16 words of the caller's
-    workspace, zeroed by the launcher's memset node) instead of the static stride: which workgroup computes a tile changes, the
+    """Round 4: the persistent kernel draws its tiles after the first from per-XCD ticket counters (one of the 64 eight-word slots in the last 512
+    words of the caller's workspace, zeroed by the launcher's memset node) instead of the static stride: which workgroup computes a tile changes, the
     tile's arithmetic does not -- same bits as the static schedule (force_tile 4000) for fp8 and 16-bit operands, launches back to
     back on one stream (the counters are re-zeroed between them), under capture and replay, and with K > 8 KiB (mode 4002)."""
     from ltp_sglang_amd import _cabi
