@@ -454,9 +454,11 @@ extern "C" int sgl_mi355_fp8_mlp_block_supported(int M, int hidden, int inter) {
   if (M < 1 || M > 32 || hidden < 512 || hidden > kMlpRange || hidden % 16 != 0) return 0;
   if (inter < 64 || inter % 16 != 0) return 0;
   const int ntiles1 = inter / 8;
-  if (ntiles1 < G || ntiles1 > kMlpMaxT1 * G) return 0;
+  // (round 5) fewer gate_up tiles than CUs -- a tensor-parallel shard: Llama-3-8B at TP 8 has inter 1 792 = 224 tiles -- run on that
+  // many workgroups (one tile each); at least 64 so that the down_proj phase keeps a quarter of the chip streaming
+  if (ntiles1 < 64 || ntiles1 > kMlpMaxT1 * G) return 0;
   const int kranges = (inter + kMlpRange - 1) / kMlpRange;
-  if (kranges > G) return 0;
+  if (kranges > (ntiles1 < G ? ntiles1 : G)) return 0;
   if ((int64_t)2 * inter * hidden >= 0xFFFFFFF0ll) return 0;
   return 1;
 }
@@ -478,7 +480,7 @@ extern "C" int sgl_mi355_fp8_mlp_block(const void* x, void* residual, const void
   SGL_CHECK(dtype == SGL_BF16 || dtype == SGL_F16, "fp8_mlp_block: dtype must be bf16 or f16");
   SGL_CHECK(sgl_mi355_fp8_mlp_block_supported(M, hidden, inter),
             "fp8_mlp_block: unsupported shape M=%d hidden=%d inter=%d (needs M <= 32, hidden a multiple of 16 and <= 4096, "
-            "CUs <= inter / 8 <= 16 CUs)", M, hidden, inter);
+            "64 <= inter / 8 <= 16 CUs)", M, hidden, inter);
   SGL_CHECK(((uintptr_t)x % 16) == 0 && ((uintptr_t)residual % 16) == 0 && ((uintptr_t)ln_weight % 16) == 0 &&
                 ((uintptr_t)w_gate_up_interleaved % 16) == 0 && ((uintptr_t)w_down % 16) == 0 && ((uintptr_t)xq_scratch % 16) == 0 &&
                 ((uintptr_t)actq_scratch % 16) == 0 && ((uintptr_t)pmax_scratch % 128) == 0 && ((uintptr_t)sync % 128) == 0,
@@ -497,7 +499,7 @@ extern "C" int sgl_mi355_fp8_mlp_block(const void* x, void* residual, const void
   p.slabs = out_slabs; p.act_scales = act_scales; p.xq = (uint8_t*)xq_scratch; p.xs = xs_scratch; p.actq = (uint8_t*)actq_scratch;
   p.pmax = (uint32_t*)pmax_scratch; p.sync = (uint32_t*)sync; p.tl = timeline;
   p.M = M; p.H = hidden; p.I = inter;
-  const int G = mlp_cus();
+  const int G = inter / 8 < mlp_cus() ? inter / 8 : mlp_cus();   // one workgroup per CU, or per gate_up tile where those are fewer
   p.ntiles1 = inter / 8;
   p.ntiles2 = hidden / 16;
   p.kranges = (inter + kMlpRange - 1) / kMlpRange;

@@ -58,7 +58,8 @@ def _run_block(sk, m, hidden, inter, dtype, seed, layers=2, layer=1, timeline=Fa
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("m,hidden,inter", [(32, 4096, 14336), (7, 4096, 14336), (16, 4096, 14336), (32, 1024, 2560), (19, 2048, 6144)])
+@pytest.mark.parametrize("m,hidden,inter", [(32, 4096, 14336), (7, 4096, 14336), (16, 4096, 14336), (32, 1024, 2560), (19, 2048, 6144),
+                                            (32, 4096, 1792), (9, 4096, 1024)])   # the last two: fewer gate_up tiles than CUs (the Llama-3-8B shard at TP 8)
 def test_mlp_block_vs_oracle(m, hidden, inter, dtype, sk):
     if not sk.fp8_mlp_block_supported(m, hidden, inter):
         pytest.skip("shape not taken on this device (CU count)")
@@ -130,7 +131,8 @@ def test_mlp_block_repeated_launches_and_layers(sk):
 def test_mlp_block_rejects_unsupported_shapes(sk):
     assert not sk.fp8_mlp_block_supported(33, 4096, 14336)
     assert not sk.fp8_mlp_block_supported(32, 8192, 28672)      # two k-ranges of gate_up: the four-launch path
-    assert not sk.fp8_mlp_block_supported(32, 4096, 1024)       # fewer gate_up tiles than CUs
+    assert sk.fp8_mlp_block_supported(32, 4096, 1024)           # fewer gate_up tiles than CUs: one workgroup per tile (round 5)
+    assert not sk.fp8_mlp_block_supported(32, 4096, 256)        # fewer than 64 tiles
     scratch = sk.Fp8MlpBlockScratch(32, 4096, 14336, 1, DEV)
     x = torch.zeros(32, 4096, dtype=torch.bfloat16, device=DEV)
     w1 = torch.zeros(2 * 14336, 4096, dtype=torch.uint8, device=DEV)

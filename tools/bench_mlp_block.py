@@ -41,6 +41,9 @@ def main():
     m, hidden, inter, copies = 32, 4096, 14336, 8
     if "--m" in sys.argv:
         m = int(sys.argv[sys.argv.index("--m") + 1])
+    if "--inter" in sys.argv:   # e.g. 1792: the Llama-3-8B shard at TP 8
+        inter = int(sys.argv[sys.argv.index("--inter") + 1])
+        copies = 32 if inter <= 4096 else copies   # keep the weight sets beyond the caches: 32 x 22 MB
     dt = torch.bfloat16
     g = torch.Generator(device=DEV).manual_seed(0)
     x = (torch.randn(m, hidden, device=DEV, generator=g) * 0.7).to(dt)
@@ -79,7 +82,7 @@ def main():
     tb = graph_time(block) / copies
     assert int(scratch.error_codes().abs().sum()) == 0, scratch.error_codes().tolist()
     mb = (2 * inter * hidden + hidden * inter) / 1e6
-    print(f"M={m}: four launches {t4:6.1f} us   persistent block {tb:6.1f} us   ({mb:.0f} MB of weights: {mb / tb / 1e3 * 1e3:.0f} GB/s -> "
+    print(f"M={m} hidden={hidden} inter={inter}: four launches {t4:6.1f} us   persistent block {tb:6.1f} us   ({mb:.0f} MB of weights: {mb / tb / 1e3 * 1e3:.0f} GB/s -> "
           f"{mb / tb * 1e6 / 1e12:.2f} TB/s; at 8 TB/s {mb / 8e6 * 1e6 / 1e6:.1f} us)")
 
     if "--timeline" in sys.argv:
