@@ -12,9 +12,10 @@ typedef __attribute__((ext_vector_type(4))) float f4v;
 #define REP4(x) x x x x
 #define REP16(x) REP4(REP4(x))
 
-// MODE 0: 32x32x16, VGPR accumulators, NCH chains;  MODE 1: 32x32x16, AGPR accumulators (asm-owned a[0:63]);  MODE 2: 16x16x32 VGPR
+// MODE 0: 32x32x16, VGPR accumulators, NCH chains;  MODE 1: 32x32x16, AGPR accumulators (asm-owned a[0:63]);  MODE 2: 16x16x32 VGPR;
+// MODE 3: v_mfma_scale_f32_16x16x128_f8f6f4 on e4m3 operands (the prefill GEMMs' instruction), 32 independent accumulator tiles
 template <int MODE, int NCH>
-__global__ void k(const bf8* in, float* out, long long* clk, int iters) {
+__global__ __launch_bounds__(512, 2) void k(const bf8* in, float* out, long long* clk, int iters) {
   bf8 a = in[threadIdx.x], b = in[threadIdx.x + 512];
   long long t0, t1;
   if constexpr (MODE == 0) {
@@ -41,6 +42,22 @@ __global__ void k(const bf8* in, float* out, long long* clk, int iters) {
     float x;
     asm volatile("v_accvgpr_read_b32 %0, a3" : "=v"(x));
     out[blockIdx.x * blockDim.x + threadIdx.x] = x;
+  } else if constexpr (MODE == 3) {
+    typedef int i8v __attribute__((ext_vector_type(8)));
+    const i8v av = {(int)in[threadIdx.x][0], (int)in[threadIdx.x][1] * 77, (int)in[threadIdx.x][2] * 13, (int)in[threadIdx.x][3], (int)0x3a41c23fu, (int)0x45b8373cu, (int)(threadIdx.x * 0x01010101u ^ 0x38b4c13du), (int)0x3c3c3c3cu};
+    const i8v bv = {(int)0x3839b8c0u, (int)(threadIdx.x * 0x00010203u ^ 0x41b23940u), (int)0x37c2b93eu, (int)0x3d3a4438u, (int)0x40b0c138u, (int)0x39394142u, (int)0xb8c0373du, (int)0x3e41b9c2u};
+    f4v c[32];
+    for (int i = 0; i < 32; ++i) c[i] = f4v{0, 0, 0, 0};
+    t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) c[(j * 2) & 31] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bv, c[(j * 2) & 31], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+    }
+    asm volatile("s_nop 15\n s_nop 15" ::: "memory");
+    t1 = __builtin_amdgcn_s_memtime();
+    float sum = 0;
+    for (int i = 0; i < 32; ++i) sum += c[i][i & 3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = sum;
   } else {
     f4v c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
     t0 = __builtin_amdgcn_s_memtime();
@@ -70,8 +87,8 @@ void run(const char* name, int threads, const bf8* in, float* out, long long* cl
   std::vector<long long> h(nw);
   hipMemcpy(h.data(), clk, nw * sizeof(long long), hipMemcpyDeviceToHost);
   std::sort(h.begin(), h.end());
-  const double n = iters * 16.0;
-  const double flop = (MODE == 2 ? 16.0 * 16 * 32 * 2 : 32.0 * 32 * 16 * 2) * n * nw;
+  const double n = iters * 16.0 * (MODE == 3 ? 1 : NCH);
+  const double flop = (MODE == 3 ? 16.0 * 16 * 128 * 2 : MODE == 2 ? 16.0 * 16 * 32 * 2 : 32.0 * 32 * 16 * 2) * n * nw;
   printf("%-44s %d waves/SIMD: %6.1f cycles per MFMA and wave (median), %7.1f TFLOP/s, %.2f GHz\n", name, threads / 256, h[nw / 2] / n, flop / ms / 1e9,
          h[nw / 2] / (ms * 1e6));
 }
@@ -93,6 +110,7 @@ int main() {
     run<2, 1>("16x16x32 VGPR acc, 1 chain", threads, in, out, clk);
     run<2, 2>("16x16x32 VGPR acc, 2 chains", threads, in, out, clk);
     run<2, 4>("16x16x32 VGPR acc, 4 chains", threads, in, out, clk);
+    run<3, 1>("16x16x128 f8f6f4 (e4m3), 16 accumulators", threads, in, out, clk);
   }
   return 0;
 }
