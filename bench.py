@@ -59,7 +59,8 @@ def parse_args():
     ap.add_argument("--skinny-hook", type=int, default=0, help="measurement hook: value passed to sgl_mi355_skinny_gemm_force_generic "
                     "(2 = 8-row tiles one tile ahead, the round-3 form; 3 = all tiles of a workgroup up front, the default; 4 / 5 = slab-mode "
                     "launches with one / two tiles in flight per wave)")
-    ap.add_argument("--kv-split-rule", type=int, default=2, help="0 = the reference's heuristic, 1 = max splits everywhere, 2 = the MI355X balance rule")
+    ap.add_argument("--kv-split-rule", type=int, default=2, help="0 = the reference's heuristic, 1 = max splits everywhere, 2 = the MI355X balance rule, 3 = rule 2's units as a list sorted longest first, on a grid without never-live workgroups")
+    ap.add_argument("--kv-sched-rounds-pct", type=int, default=150, help="rule 3: units sized for this many percent of one round of resident workgroups")
     ap.add_argument("--max-kv-splits", type=int, default=16, help="triton_attention_num_kv_splits (16 = the reference's HIP default)")
     ap.add_argument("--all-reduce", default="auto", choices=["auto", "rccl", "p2p"],
                     help="N > 1: auto = the one-shot P2P all-reduce over IPC-mapped peer buffers when its start-up self-check against "
@@ -442,7 +443,8 @@ def main():
                                   max_total_tokens=kv_tokens + (2 * seq if P else 0) + bs * total_steps + 64, device=dev, seed=0,
                                   dtype=torch.float16 if args.dtype == "f16" else torch.bfloat16,
                                   kv_cache_dtype=torch.float8_e4m3fn if args.kv_cache_dtype == "fp8_e4m3" else None,
-                                  max_kv_splits=args.max_kv_splits, kv_split_rule=args.kv_split_rule)
+                                  max_kv_splits=args.max_kv_splits, kv_split_rule=args.kv_split_rule,
+                                  kv_sched_rounds_pct=args.kv_sched_rounds_pct)
     if args.no_fused_decode:
         runner.model.fused_decode = False
     if args.no_graph_metadata:
@@ -628,7 +630,8 @@ def main():
                 # request's last workgroup (r3's probe timed stage 1 alone, a cheaper launch than the step's)
                 K.decode_attention_merge_quant(qd, pool.get_key_buffer(l), pool.get_value_buffer(l), md.kv_indptr, md.kv_indices,
                                                md.attn_logits, md.attn_lse, md.num_kv_splits, be.max_kv_splits, d ** -0.5,
-                                               be._merge_counter_buf(qd), 0.0, kscale, vscale, want_o=not fp8_lin, want_quant=fp8_lin)
+                                               be._merge_counter_buf(qd), 0.0, kscale, vscale, want_o=not fp8_lin, want_quant=fp8_lin,
+                                               sched=md.sched)
             else:
                 # o = None: stage 1 only (the split partials)
                 K.decode_attention_fwd(qd, pool.get_key_buffer(l), pool.get_value_buffer(l), None, md.kv_indptr, md.kv_indices,
@@ -695,6 +698,9 @@ def main():
     sp = md.num_kv_splits[:bs].cpu().tolist()
     out["kv_splits"] = {"rule": args.kv_split_rule, "max_kv_splits": args.max_kv_splits,
                         "histogram": {str(v): sp.count(v) for v in sorted(set(sp))}, "workgroup_units": int(sum(sp)) * hkv_r}
+    if md.sched is not None:   # sorted unit list: {T, units, total tokens, capacity}
+        hdr = md.sched[:4].cpu().tolist()
+        out["kv_splits"].update({"split_tokens": hdr[0], "list_units": hdr[1], "list_capacity": hdr[3], "rounds_pct": args.kv_sched_rounds_pct})
     if not args.no_cpu_baseline and args.model != "tiny" and world == 1 and args.emulate_tp <= 1 and args.config in (0,):  # rank 0 at N = 1 only; the headline run
         out["cpu_baseline"] = cpu_baseline_sample(cfg, bs, seq, L)
     phase("cpu_baseline")

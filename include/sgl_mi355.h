@@ -70,6 +70,17 @@ int sgl_mi355_decode_attention_merge_quant(const void* q, int64_t q_stride_t, co
                                            int num_q_heads, int num_kv_heads, int head_dim, int v_head_dim, float sm_scale,
                                            float logit_cap, int dtype, int kv_dtype, float k_scale, float v_scale,
                                            int32_t* merge_counters, void* out_o, void* out_q, float* out_s, void* stream);
+/* sgl_mi355_decode_attention_merge_quant with each workgroup's (request, split) unit read from the sorted list
+ * sgl_mi355_decode_schedule wrote for this batch (sched, sched_units = its capacity; num_kv_splits from the same call): the same
+ * splits, arithmetic and outputs bit for bit -- another dispatch order (longest unit first, so short units fill the slots long ones
+ * leave: BASELINE config 5's ragged batch) and a grid of (kv heads x head chunks, sched_units) without never-live workgroups. */
+int sgl_mi355_decode_attention_scheduled(const void* q, int64_t q_stride_t, const void* k_buffer, const void* v_buffer,
+                                         int64_t k_stride_t, int64_t k_stride_h, int64_t v_stride_t, int64_t v_stride_h,
+                                         const int32_t* kv_indptr, const int32_t* kv_indices, float* attn_logits, float* attn_lse,
+                                         const int32_t* num_kv_splits, int max_kv_splits, const int32_t* sched, int sched_units,
+                                         int batch, int num_q_heads, int num_kv_heads, int head_dim, int v_head_dim, float sm_scale,
+                                         float logit_cap, int dtype, int kv_dtype, float k_scale, float v_scale,
+                                         int32_t* merge_counters, void* out_o, void* out_q, float* out_s, void* stream);
 
 /* merge_state / merge_state_v2 (sgl-kernel/csrc/attention/merge_attn_states.cu:32-105; python attention.py:12-52): LSE-weighted
  * merge of two attention partials v [n, h, d] (bf16 / f16 / f32) with s f32 [n, h]; s_merged may be NULL. */
@@ -178,6 +189,18 @@ int sgl_mi355_move_kv_cache(const void* data_ptrs, const int64_t* data_strides, 
 int sgl_mi355_decode_metadata(int32_t* kv_indptr, int32_t* num_kv_splits, const void* seq_lens, int seq_is64,
                               int num_seq, int num_group, int num_head, int num_kv_head, int max_kv_splits,
                               int device_core_count, int static_splits, void* stream);
+
+/* Sorted unit list of a decode batch (replaces get_num_kv_splits_triton, triton_backend.py:876-924, for the launch
+ * sgl_mi355_decode_attention_scheduled): kv_indptr[1:bs+1] = cumsum(seq_lens); num_kv_splits[b] = clamp(ceil(len / T), 1,
+ * max_kv_splits) with T = the 32-token multiple of total / (resident workgroups x rounds_pct / 100 per kv head x head chunk), >= 64;
+ * sched = {T, units, total, capacity} + per (request, split) unit {request, split | splits << 16, kv_indptr[request], length},
+ * sorted by the unit's token count, longest first (split boundaries as decode_attention.py:90-94 makes them).
+ * sgl_mi355_decode_schedule_units: the list's capacity = the attention launch's grid y (0: geometry not served, use
+ * sgl_mi355_decode_metadata); sched holds 4 + 4 x capacity int32 words, 16-byte aligned. */
+int sgl_mi355_decode_schedule_units(int num_seq, int num_head, int num_kv_head, int rounds_pct);
+int sgl_mi355_decode_schedule(int32_t* kv_indptr, int32_t* num_kv_splits, int32_t* sched, int sched_units, const void* seq_lens,
+                              int seq_is64, int num_seq, int num_head, int num_kv_head, int max_kv_splits, int rounds_pct,
+                              void* stream);
 
 /* alloc_extend_kernel / alloc_decode_kernel of PagedTokenToKVPoolAllocator, mem_cache/allocator.py:275-395:
  * page-aligned slot assignment; ret_values[0] = (new pages << 32 | extend tokens) resp. new pages. */

@@ -69,6 +69,13 @@ struct DecodeParams {
   //                prefix partials is its initial (m, l, acc) -- the math of merge_state, merge_attn_states.cu, applied before
   //                instead of after), so the in-launch merge sees suffix slots only.
   int prefix_len, prefix_splits;
+  // Flat unit list (round 5, SCHED kernels; csrc/kv_index.hip decode_schedule_kernel): the (request, split) units of the launch as a
+  // list sorted by length, longest first -- grid y walks the list, so the dispatcher starts the long units first and fills the
+  // chip's slots with short ones as they free up (ragged batches), and the grid carries no never-live workgroups.
+  // sched: {T, units, total tokens, capacity}, then per unit {request, split | splits << 16, kv_indptr[request], its length}.
+  // sched_chunks = grid y = the capacity the host sized the list for.
+  const int32_t* sched;
+  int sched_chunks;
 #ifdef SGL_DEC_TIMELINE
   long long* tl;   // tools/debug/dec_timeline.py: s_memrealtime stamps [workgroup (linear)][wave][8]
 #endif
@@ -176,8 +183,12 @@ __device__ __forceinline__ void cvt16_fp8(const u32x4_t& in, u32x4_t& lo, u32x4_
 // KVB: bytes per pool element (1 = e4m3 KV cache, converted on the way into LDS).  CASC = 2: the SUFFIX pass of the cascade
 // (shared-prefix) decode, a form of MODE 0 whose split 0 starts from the prefix state (DecodeParams::prefix_*) -- its own
 // instantiation, so the extra code stays out of the ordinary one.
-template <typename T, int D, int NW, int MODE, int KVB = 2, int CASC = 0>
-__global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void decode_attn_stage1(const DecodeParams p) {
+// decode_piece: one (request, kv head x head chunk, split [start, end)) by the NW waves of a workgroup (MODE 0) or by one wave (MODE 1).
+template <typename T, int D, int NW, int MODE, int KVB, int CASC, bool SCHED>
+__device__ __forceinline__ void decode_piece(const DecodeParams& p, char* smem, const int b, const int split, const int nsplit,
+                                             const int seq_len, const int32_t* idx_row, const int start, const int end,
+                                             const bool continues_prefix, const int kh, const int hc, const int nh, const int hchunks,
+                                             const int tid) {
   using Tr = ElemTraits<T>;
   using vec8 = typename Tr::vec8;
   constexpr int ROWB = D * 2;
@@ -195,45 +206,8 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void decode_attn_stage1(c
   constexpr int VCH = ROWB / 32;
   constexpr int VMASK = (VCH < 8 ? VCH : 8) - 1;
 
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  static_assert(CASC == 0 || (CASC == 2 && MODE == 0), "the cascade suffix pass is a MODE 0 form");
-  DEC_STAMP(0);
-  const int hchunks = (p.group + 15) >> 4;
-  int khc, split;
-  if constexpr (MODE == 0) {
-    khc = blockIdx.x;
-    split = blockIdx.z;  // slowest grid dimension: workgroups of splits a request does not use are dispatched LAST
-  } else {
-    const int unit = blockIdx.x * NW + w;  // wave-uniform
-    khc = unit % (p.hkv * hchunks);
-    split = unit / (p.hkv * hchunks);
-  }
-  const int kh = khc / hchunks;
-  const int hc = khc - kh * hchunks;
-  const int b = blockIdx.y;
-  const int nh = min(16, p.group - hc * 16);
-
-  const int32_t* idx_row;
-  int seq_len;
-  request_range(p, b, idx_row, seq_len);
-  const int nsplit = max(1, min(p.num_kv_splits[b], p.max_kv_splits - (CASC == 2 ? p.prefix_splits : 0)));
-  if (split >= nsplit) return;  // MODE 1: a whole-wave exit; the kernel has no barrier in that mode
-  DEC_STAMP(1);
-  const int per = split_len(seq_len, nsplit);
-  const int start = split * per;
-  const int end = min(start + per, seq_len);
-  const bool continues_prefix = CASC == 2 && split == 0;   // carries the prefix state even if the private part is empty
-  if (start >= end && !continues_prefix) {
-    if constexpr (MODE == 0) {  // an empty split still counts as arrived for the in-launch merge (uniform per workgroup)
-      if (p.merge_cnt) arrive_and_merge<T, CASC == 2>(p, b, seq_len, nsplit, hchunks, smem);
-    }
-    return;
-  }
-
   const int a = lane & 15;  // MFMA n index: q head within the chunk
   const int g = lane >> 4;  // MFMA k/m group
   const int c16 = lane % GLPR;  // 16-byte chunk of the pool row / row within a load instruction, of this lane
@@ -244,19 +218,20 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void decode_attn_stage1(c
 
   // Q fragments: B operand of S^T = K Q^T, lane (a,g) holds Q[h0+a][32*ks + 8*g .. +8]
   vec8 qf[KS];
-  {
+  auto load_q = [&](int bb, vec8 (&dst)[KS]) {
     const int va = hc * 16 + min(a, nh - 1);
-    const T* qrow = (const T*)p.q + (int64_t)b * p.q_stride_t + (int64_t)(kh * p.group + va) * D;
+    const T* qrow = (const T*)p.q + (int64_t)bb * p.q_stride_t + (int64_t)(kh * p.group + va) * D;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       if (a < nh) {
-        qf[ks] = *(const vec8*)(qrow + 32 * ks + 8 * g);
+        dst[ks] = *(const vec8*)(qrow + 32 * ks + 8 * g);
       } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) qf[ks][j] = (T)0.0f;
+        for (int j = 0; j < 8; ++j) dst[ks][j] = (T)0.0f;
       }
     }
-  }
+  };
+  load_q(b, qf);
 
   const char* kbase = (const char*)p.k_buf + ((int64_t)kh * p.k_stride_h) * KVB + c16 * 16;
   const char* vbase = (const char*)p.v_buf + ((int64_t)kh * p.v_stride_h) * KVB + c16 * 16;
@@ -302,21 +277,23 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void decode_attn_stage1(c
 
   u32x4_t kreg[GNI], vreg[GNI];
 
-  auto load_idx = [&](int t) -> int {
-    const int tok = start + t * kTile + (lane & 31);
-    return (t < ntiles && tok < end) ? idx_row[tok] : 0;
+  auto load_idx_of = [&](const int32_t* ir, int st, int en, int nt, int t) -> int {
+    const int tok = st + t * kTile + (lane & 31);
+    return (t < nt && tok < en) ? ir[tok] : 0;
   };
-  auto issue = [&](int idxreg) {
+  auto load_idx = [&](int t) -> int { return load_idx_of(idx_row, start, end, ntiles, t); };
+  auto issue_to = [&](u32x4_t (&kd)[GNI], u32x4_t (&vd)[GNI], int idxreg) {
 #pragma unroll
     for (int i = 0; i < GNI; ++i) {
       const int id = __shfl(idxreg, i * GRPI + rsub, WAVE);
       // NON-TEMPORAL loads: every K/V row is read once per decode step, so keeping it in L2 / the Infinity Cache only
       // evicts what the step re-reads (activations, split partials) and lengthens the miss path.  Same-box A/B at the
       // BASELINE shape (round 2): stage 1 55.0 -> 50.3 us per launch (4.9 -> 5.4 TB/s), decode step 4.55 -> 4.39 ms.
-      kreg[i] = __builtin_nontemporal_load((const u32x4_t*)(kbase + (int64_t)id * kst));
-      vreg[i] = __builtin_nontemporal_load((const u32x4_t*)(vbase + (int64_t)id * vst));
+      kd[i] = __builtin_nontemporal_load((const u32x4_t*)(kbase + (int64_t)id * kst));
+      vd[i] = __builtin_nontemporal_load((const u32x4_t*)(vbase + (int64_t)id * vst));
     }
   };
+  auto issue = [&](int idxreg) { issue_to(kreg, vreg, idxreg); };
 
   constexpr int TS = (MODE == 0) ? NW : 1;  // tile stride of this wave
   int tile = (MODE == 0) ? w : 0;
@@ -502,6 +479,74 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void decode_attn_stage1(c
   DEC_STAMP(6);
 }
 
+
+// SCHED (a MODE 0 form, round 5): the (request, split) unit of the workgroup comes from the sorted unit list (DecodeParams::sched)
+// instead of (blockIdx.y, blockIdx.z) -- the same splits of the same requests, in another dispatch order and without the grid's
+// never-live part; everything after the mapping is the unscheduled kernel.
+template <typename T, int D, int NW, int MODE, int KVB = 2, int CASC = 0, bool SCHED = false>
+__global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void decode_attn_stage1(const DecodeParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  static_assert(CASC == 0 || (CASC == 2 && MODE == 0), "the cascade suffix pass is a MODE 0 form");
+  static_assert(!SCHED || (MODE == 0 && CASC == 0), "the scheduled form is a plain MODE 0 form");
+  DEC_STAMP(0);
+  const int hchunks = (p.group + 15) >> 4;
+  if constexpr (SCHED) {
+    const int khc = blockIdx.x;
+    const int kh = khc / hchunks;
+    const int hc = khc - kh * hchunks;
+    const int nh = min(16, p.group - hc * 16);
+    if ((int)blockIdx.y >= p.sched[1]) return;
+    const int4 ent = *(const int4*)(p.sched + 4 + 4 * blockIdx.y);   // {request, split | splits << 16, kv_indptr[request], its length}
+    const int b = ent.x, split = ent.y & 0xffff, nsplit = ent.y >> 16, seq_len = ent.w;
+    DEC_STAMP(1);
+    const int per = split_len(seq_len, nsplit);
+    const int start = split * per;
+    const int end = min(start + per, seq_len);
+    if (start >= end) {   // (a request without keys, or a split past its end: counts as arrived)
+      if (p.merge_cnt) arrive_and_merge<T, false>(p, b, seq_len, nsplit, hchunks, smem);
+      return;
+    }
+    decode_piece<T, D, NW, MODE, KVB, CASC, true>(p, smem, b, split, nsplit, seq_len, p.kv_indices + ent.z, start, end, false, kh, hc, nh, hchunks, tid);
+    return;
+  } else {
+  int khc, split;
+  if constexpr (MODE == 0) {
+    khc = blockIdx.x;
+    split = blockIdx.z;  // slowest grid dimension: workgroups of splits a request does not use are dispatched LAST
+  } else {
+    const int unit = blockIdx.x * NW + w;  // wave-uniform
+    khc = unit % (p.hkv * hchunks);
+    split = unit / (p.hkv * hchunks);
+  }
+  const int kh = khc / hchunks;
+  const int hc = khc - kh * hchunks;
+  const int b = blockIdx.y;
+  const int nh = min(16, p.group - hc * 16);
+
+  const int32_t* idx_row;
+  int seq_len;
+  request_range(p, b, idx_row, seq_len);
+  const int nsplit = max(1, min(p.num_kv_splits[b], p.max_kv_splits - (CASC == 2 ? p.prefix_splits : 0)));
+  if (split >= nsplit) return;  // MODE 1: a whole-wave exit; the kernel has no barrier in that mode
+  DEC_STAMP(1);
+  const int per = split_len(seq_len, nsplit);
+  const int start = split * per;
+  const int end = min(start + per, seq_len);
+  const bool continues_prefix = CASC == 2 && split == 0;   // carries the prefix state even if the private part is empty
+  if (start >= end && !continues_prefix) {
+    if constexpr (MODE == 0) {  // an empty split still counts as arrived for the in-launch merge (uniform per workgroup)
+      if (p.merge_cnt) arrive_and_merge<T, CASC == 2>(p, b, seq_len, nsplit, hchunks, smem);
+    }
+    return;
+  }
+  decode_piece<T, D, NW, MODE, KVB, CASC, false>(p, smem, b, split, nsplit, seq_len, idx_row, start, end, continues_prefix, kh, hc, nh, hchunks, tid);
+  }
+}
+
 // Any-head-dim fallback (D, Dv <= 256, not multiples of 32 allowed): one wave per
 // (request, q head, split).  Correctness path for the reference's odd test shapes
 // (test_triton_attention_kernels.py: D in {96, 80, 13}); not a performance path.
@@ -611,6 +656,17 @@ int decode_cus() {
   return cus;
 }
 
+// The unit list's geometry, shared with csrc/kv_index.hip (sgl_mi355_decode_schedule): eight waves (one workgroup per CU) when the
+// launch has at most one (request, kv head x head chunk) unit per two CUs, as the unscheduled form decides; target = the units per
+// (kv head x head chunk) that fill the chip's resident workgroups `rounds_pct` / 100 times; the list holds at most target + batch
+// units (every request's last split is a remainder), the grid's y.
+bool decode_sched_eight_waves(int bs, int khc) { return g_decode_mode == 3 || (g_decode_mode != 2 && 2ll * khc * bs <= decode_cus()); }
+int decode_sched_target(int bs, int khc, int rounds_pct) {
+  const long long slots = (decode_sched_eight_waves(bs, khc) ? 1 : 2) * (long long)decode_cus();
+  const long long t = (slots * rounds_pct / 100 + khc - 1) / khc;
+  return (int)(t < 1 ? 1 : t);
+}
+
 template <typename T, int D, int KVB>
 int launch_mfma(const DecodeParams& p, hipStream_t st) {
   const int hchunks = (p.group + 15) / 16;
@@ -624,6 +680,27 @@ int launch_mfma(const DecodeParams& p, hipStream_t st) {
     }
     dim3 grid(p.hkv * hchunks, p.bs, p.max_kv_splits - p.prefix_splits);
     hipLaunchKernelGGL((decode_attn_stage1<T, D, NW, 0, KVB, 2>), grid, dim3(NW * 64), smem, st, p);
+  } else if (p.sched != nullptr) {   // equal-chunk schedule: the same four / eight wave rule, grid y = the schedule's chunk capacity
+    const dim3 grid(p.hkv * hchunks, p.sched_chunks, 1);
+    if (decode_sched_eight_waves(p.bs, p.hkv * hchunks)) {
+      constexpr int NW = 8;
+      constexpr int smem = NW * 2 * kTile * D * 2;
+      static bool attr_set = false;
+      if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)decode_attn_stage1<T, D, NW, 0, KVB, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_set = true;
+      }
+      hipLaunchKernelGGL((decode_attn_stage1<T, D, NW, 0, KVB, 0, true>), grid, dim3(NW * 64), smem, st, p);
+    } else {
+      constexpr int NW = 4;
+      constexpr int smem = NW * 2 * kTile * D * 2;
+      static bool attr_set = false;
+      if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)decode_attn_stage1<T, D, NW, 0, KVB, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_set = true;
+      }
+      hipLaunchKernelGGL((decode_attn_stage1<T, D, NW, 0, KVB, 0, true>), grid, dim3(NW * 64), smem, st, p);
+    }
   } else if (g_decode_mode == 3 || (g_decode_mode == 0 && 2ll * p.hkv * hchunks * p.bs <= decode_cus())) {
     constexpr int NW = 8;
     constexpr int smem = NW * 2 * kTile * D * 2;   // 128 KiB at D = 128: one workgroup per CU
@@ -703,7 +780,7 @@ static int decode_entry(
     const int64_t* seq_lens, float* attn_logits, float* attn_lse, const int32_t* num_kv_splits, int max_kv_splits,
     int batch, int num_q_heads, int num_kv_heads, int head_dim, int v_head_dim, float sm_scale, float logit_cap,
     int dtype, int kv_dtype, float k_scale, float v_scale, int32_t* merge_cnt, void* mq_o, void* mq_q, float* mq_s,
-    void* stream, int prefix_len = 0, int prefix_splits = 0) {
+    void* stream, int prefix_len = 0, int prefix_splits = 0, const int32_t* sched = nullptr, int sched_capacity = 0) {
   SGL_CHECK(batch >= 0, "decode_attention: negative batch %d", batch);
   if (batch == 0) return SGL_MI355_OK;
   SGL_CHECK(q && k_buffer && v_buffer, "decode_attention: null tensor pointer");  // o == NULL: split partials only
@@ -748,6 +825,13 @@ static int decode_entry(
   p.k_scale = kv8 ? k_scale : 1.0f; p.v_scale = kv8 ? v_scale : 1.0f;
   p.merge_cnt = merge_cnt; p.mq_o = mq_o; p.mq_q = mq_q; p.mq_s = mq_s;
   p.prefix_len = prefix_len; p.prefix_splits = prefix_splits;
+  p.sched = sched; p.sched_chunks = 0;
+  if (sched != nullptr) {
+    SGL_CHECK(merge_cnt != nullptr && kv_indptr != nullptr && kv_indices != nullptr && prefix_splits == 0 &&
+                  ((uintptr_t)sched % 16) == 0 && sched_capacity >= 1 && sched_capacity <= 65535,
+              "decode_attention_scheduled: needs kv_indptr / kv_indices, merge counters, a 16-byte aligned unit list and 1 <= capacity <= 65535");
+    p.sched_chunks = sched_capacity;
+  }
   if (prefix_splits > 0) {
     SGL_CHECK(head_dim == v_head_dim && (head_dim == 128 || head_dim == 64) && g_decode_mode != 1,
               "decode_attention_cascade: needs the MFMA kernel (head_dim 64 / 128) in its workgroup-per-split mode");
@@ -792,6 +876,27 @@ extern "C" int sgl_mi355_decode_attention_merge_quant(
                       kv_indices, nullptr, 0, nullptr, nullptr, attn_logits, attn_lse, num_kv_splits, max_kv_splits, batch,
                       num_q_heads, num_kv_heads, head_dim, v_head_dim, sm_scale, logit_cap, dtype, kv_dtype, k_scale, v_scale,
                       merge_counters, out_o, out_q, out_s, stream);
+}
+
+// sgl_mi355_decode_attention_merge_quant with the workgroups' (request, split) units taken from the sorted list
+// sgl_mi355_decode_schedule wrote (sched; csrc/kv_index.hip) -- num_kv_splits from the same call.  Same splits, same arithmetic, same
+// outputs bit for bit; another dispatch order (longest unit first) and a grid of (kv heads x head chunks, sched_units).
+extern "C" int sgl_mi355_decode_attention_scheduled(
+    const void* q, int64_t q_stride_t, const void* k_buffer, const void* v_buffer, int64_t k_stride_t,
+    int64_t k_stride_h, int64_t v_stride_t, int64_t v_stride_h, const int32_t* kv_indptr, const int32_t* kv_indices,
+    float* attn_logits, float* attn_lse, const int32_t* num_kv_splits, int max_kv_splits, const int32_t* sched, int sched_units,
+    int batch, int num_q_heads, int num_kv_heads, int head_dim, int v_head_dim, float sm_scale, float logit_cap, int dtype,
+    int kv_dtype, float k_scale, float v_scale, int32_t* merge_counters, void* out_o, void* out_q, float* out_s, void* stream) {
+  SGL_CHECK(merge_counters != nullptr && kv_indptr != nullptr && sched != nullptr, "decode_attention_scheduled: null pointer");
+  return decode_entry(q, q_stride_t, k_buffer, v_buffer, k_stride_t, k_stride_h, v_stride_t, v_stride_h, nullptr, 0, kv_indptr,
+                      kv_indices, nullptr, 0, nullptr, nullptr, attn_logits, attn_lse, num_kv_splits, max_kv_splits, batch,
+                      num_q_heads, num_kv_heads, head_dim, v_head_dim, sm_scale, logit_cap, dtype, kv_dtype, k_scale, v_scale,
+                      merge_counters, out_o, out_q, out_s, stream, 0, 0, sched, sched_units);
+}
+
+// host side of the unit list's geometry for csrc/kv_index.hip
+int sgl_mi355_internal_decode_sched_target(int batch, int num_q_heads, int num_kv_heads, int rounds_pct) {
+  return decode_sched_target(batch, num_kv_heads * ((num_q_heads / num_kv_heads + 15) / 16), rounds_pct);
 }
 
 // Cascade shared-prefix decode: every request of the batch shares its first prefix_len slots (one radix-tree

@@ -425,6 +425,162 @@ extern "C" int sgl_mi355_decode_metadata(int32_t* kv_indptr, int32_t* num_kv_spl
   return SGL_MI355_OK;
 }
 
+namespace {
+
+// Sorted unit list of a decode batch (round 5; consumer: decode_attention.hip, SCHED kernels).  The reference launches a grid of
+// (batch, heads, max_kv_splits) programs of which each request uses its first num_kv_splits[b] (decode_attention.py:677-728): over
+// ragged lengths the longest split decides when the launch ends, and most of the grid exits at once.  Here the same (request, split)
+// units -- split boundaries exactly as the reference's kernel computes them from (length, num_kv_splits[b]) -- become a LIST, sorted by
+// length, longest first: the hardware dispatcher hands out workgroups in list order, so long units start first and short ones fill the
+// slots that free up (longest-processing-time-first), and the grid is as long as the list.
+//   T = 32-token multiple of ceil(total / target), at least 64;  num_kv_splits[b] = clamp(ceil(len / T), 1, max_kv_splits);
+//   sched = {T, units, total, capacity} then per unit {request, split | splits << 16, kv_indptr[request], its length}.
+// One workgroup; kv_indptr is written by the same launch (cumsum as decode_meta_kernel).  capacity <= 4096 (the sort runs in LDS).
+constexpr int kSchedMaxUnits = 4096;
+__global__ __launch_bounds__(1024) void decode_schedule_kernel(int32_t* kv_indptr, int32_t* num_kv_splits, int32_t* sched,
+                                                               const void* seq_lens, int sl64, int num_seq, int max_kv_splits,
+                                                               int target_even, int target_ragged, int capacity) {
+  __shared__ int64_t scan[1024];
+  __shared__ uint64_t keys[kSchedMaxUnits];   // length << 32 | (0xffff - split) << 16 | (0xffff - request): sorted descending
+  __shared__ int32_t smax[16], smin[16];
+  const int tid = threadIdx.x;
+  int64_t carry = 0;
+  int32_t mx = 0, mn = 0x7fffffff;
+  if (tid == 0) kv_indptr[0] = 0;
+  for (int base = 0; base < num_seq; base += 1024) {
+    const int i = base + tid;
+    const int64_t v = i < num_seq ? ld_idx(seq_lens, i, sl64) : 0;
+    if (i < num_seq) { mx = max(mx, (int32_t)v); mn = min(mn, (int32_t)v); }
+    scan[tid] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      const int64_t add = tid >= off ? scan[tid - off] : 0;
+      __syncthreads();
+      scan[tid] += add;
+      __syncthreads();
+    }
+    if (i < num_seq) kv_indptr[i + 1] = (int32_t)(carry + scan[tid]);
+    carry += scan[1023];
+    __syncthreads();
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    mx = max(mx, __shfl_xor(mx, m, WAVE));
+    mn = min(mn, __shfl_xor(mn, m, WAVE));
+  }
+  if ((tid & 63) == 0) { smax[tid >> 6] = mx; smin[tid >> 6] = mn; }
+  __syncthreads();
+  for (int w = 0; w < 16; ++w) { mx = max(mx, smax[w]); mn = min(mn, smin[w]); }
+  // lengths within 25 % of each other (the reference's own test, triton_backend.py:895-897): one round of equal units, the rule the
+  // whole-step A/Bs of rounds 2-4 chose; ragged: smaller units (target_ragged of them), which the sorted dispatch packs
+  const bool even = (int64_t)mx * 8 < (int64_t)mn * 10;
+  const int target = even ? target_even : target_ragged;
+  const int64_t tot = carry;
+  int64_t T = (tot + target - 1) / target;
+  T = (T + 31) / 32 * 32;
+  if (T < 64) T = 64;
+  // splits per request and their exclusive prefix sum = each request's first slot of the unsorted list
+  int64_t ucarry = 0;
+  for (int base = 0; base < num_seq; base += 1024) {
+    const int i = base + tid;
+    int ns = 0, len = 0;
+    if (i < num_seq) {
+      len = (int)ld_idx(seq_lens, i, sl64);
+      ns = (int)((len + T - 1) / T);
+      ns = ns < 1 ? 1 : (ns > max_kv_splits ? max_kv_splits : ns);
+      num_kv_splits[i] = ns;
+    }
+    scan[tid] = ns;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      const int64_t add = tid >= off ? scan[tid - off] : 0;
+      __syncthreads();
+      scan[tid] += add;
+      __syncthreads();
+    }
+    if (i < num_seq) {
+      const int u0 = (int)(ucarry + scan[tid]) - ns;
+      const int per0 = (len + ns - 1) / ns;
+      const int per = (per0 + 31) / 32 * 32;   // (decode_attention.py:90-94, split_len in decode_attention.hip)
+      for (int j = 0; j < ns; ++j) {
+        if (u0 + j < kSchedMaxUnits) {
+          int l = len - j * per;
+          l = l < 0 ? 0 : (l > per ? per : l);
+          keys[u0 + j] = ((uint64_t)(uint32_t)l << 32) | ((uint64_t)(0xffffu - (uint32_t)j) << 16) | (uint64_t)(0xffffu - (uint32_t)i);
+        }
+      }
+    }
+    ucarry += scan[1023];
+    __syncthreads();
+  }
+  int units = (int)ucarry;   // <= target + num_seq <= capacity by the choice of T (every request's last split is a remainder)
+  units = units > capacity ? capacity : units;
+  int n2 = 1;
+  while (n2 < units) n2 <<= 1;
+  for (int u = units + tid; u < n2; u += 1024) keys[u] = 0;
+  __syncthreads();
+  for (int k = 2; k <= n2; k <<= 1) {       // bitonic sort, descending: longest unit first; equal lengths in the grid's own order
+    for (int j = k >> 1; j > 0; j >>= 1) {  // (split index slowest, request fastest)
+      for (int x = tid; x < n2; x += 1024) {
+        const int y = x ^ j;
+        if (y > x) {
+          const uint64_t a = keys[x], b2 = keys[y];
+          const bool desc = (x & k) == 0;
+          if (desc ? a < b2 : a > b2) { keys[x] = b2; keys[y] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (tid == 0) {
+    sched[0] = (int32_t)T; sched[1] = units; sched[2] = (int32_t)tot; sched[3] = capacity;
+  }
+  for (int x = tid; x < units; x += 1024) {
+    const uint64_t key = keys[x];
+    const int b = (int)(0xffffu - (uint32_t)(key & 0xffffu)), j = (int)(0xffffu - (uint32_t)((key >> 16) & 0xffffu));
+    const int s0 = kv_indptr[b];
+    sched[4 + 4 * x] = b;
+    sched[5 + 4 * x] = j | (num_kv_splits[b] << 16);
+    sched[6 + 4 * x] = s0;
+    sched[7 + 4 * x] = kv_indptr[b + 1] - s0;
+  }
+}
+
+}  // namespace
+
+int sgl_mi355_internal_decode_sched_target(int batch, int num_q_heads, int num_kv_heads, int rounds_pct);   // decode_attention.hip
+
+// Capacity (units, = the attention launch's grid y) of the list for a batch of this geometry: resident workgroups x rounds_pct / 100
+// per (kv head x head chunk) -- the ragged target; a batch of near-equal lengths is cut for ONE round -- + one remainder unit per
+// request.  0: not available (more than 4096 units, or batch > 65535).
+extern "C" int sgl_mi355_decode_schedule_units(int num_seq, int num_head, int num_kv_head, int rounds_pct) {
+  if (num_seq <= 0 || num_seq > 65535 || num_kv_head <= 0 || num_head < num_kv_head || num_head % num_kv_head || rounds_pct < 25 || rounds_pct > 1600)
+    return 0;
+  const int pct = rounds_pct < 100 ? 100 : rounds_pct;   // (the even target is 100)
+  const long long cap = (long long)sgl_mi355_internal_decode_sched_target(num_seq, num_head, num_kv_head, pct) + num_seq;
+  return cap > kSchedMaxUnits ? 0 : (int)cap;
+}
+
+// kv_indptr, num_kv_splits and the sorted unit list of a decode batch in one launch (the kernel above); the consumer is
+// sgl_mi355_decode_attention_scheduled.  sched: int32, 16-byte aligned, 4 + 4 x sgl_mi355_decode_schedule_units(...) words.
+extern "C" int sgl_mi355_decode_schedule(int32_t* kv_indptr, int32_t* num_kv_splits, int32_t* sched, int sched_units,
+                                         const void* seq_lens, int seq_is64, int num_seq, int num_head, int num_kv_head,
+                                         int max_kv_splits, int rounds_pct, void* stream) {
+  SGL_CHECK(num_seq >= 0, "decode_schedule: negative batch");
+  if (num_seq == 0) return SGL_MI355_OK;
+  SGL_CHECK(kv_indptr && num_kv_splits && sched && seq_lens, "decode_schedule: null pointer");
+  SGL_CHECK(max_kv_splits >= 1 && max_kv_splits <= 32767, "decode_schedule: max_kv_splits=%d outside [1, 32767]", max_kv_splits);
+  const int cap = sgl_mi355_decode_schedule_units(num_seq, num_head, num_kv_head, rounds_pct);
+  SGL_CHECK(cap > 0, "decode_schedule: no unit list for this geometry (batch %d, heads %d / %d, rounds_pct %d): more than %d units or bad arguments",
+            num_seq, num_head, num_kv_head, rounds_pct, kSchedMaxUnits);
+  SGL_CHECK(sched_units == cap && ((uintptr_t)sched % 16) == 0, "decode_schedule: the unit list needs %d units (got %d), 16-byte aligned", cap, sched_units);
+  hipLaunchKernelGGL(decode_schedule_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, kv_indptr, num_kv_splits, sched, seq_lens,
+                     seq_is64, num_seq, max_kv_splits, sgl_mi355_internal_decode_sched_target(num_seq, num_head, num_kv_head, 100),
+                     sgl_mi355_internal_decode_sched_target(num_seq, num_head, num_kv_head, rounds_pct), cap);
+  SGL_HIP_LAUNCH_CHECK();
+  return SGL_MI355_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Paged allocator index kernels (page_size > 1): bit-exact with alloc_extend_kernel / alloc_decode_kernel of
 // python/sglang/srt/mem_cache/allocator.py:275-395.  A request first fills the tail of its last partial page

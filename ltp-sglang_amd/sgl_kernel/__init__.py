@@ -60,6 +60,8 @@ from .kvcache import (
     create_kv_indices,
     decode_metadata,
     decode_prepare,
+    decode_schedule,
+    decode_schedule_units,
     get_last_loc,
     move_kv_cache,
     set_kv_buffer,

@@ -188,9 +188,12 @@ def extend_attention(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer,
 
 
 def decode_attention_merge_quant(q, k_buffer, v_buffer, kv_indptr, kv_indices, attn_logits, attn_lse, num_kv_splits, max_kv_splits,
-                                 sm_scale, merge_counters, logit_cap=0.0, k_scale=1.0, v_scale=1.0, want_o=False, want_quant=True):
+                                 sm_scale, merge_counters, logit_cap=0.0, k_scale=1.0, v_scale=1.0, want_o=False, want_quant=True,
+                                 sched=None):
     """decode_attention_fwd + the stage-2 merge + sgl_per_token_quant_fp8 of the merged rows in ONE launch (the last workgroup
     of each request to finish does the merge).  merge_counters: int32 [>= bs], zero on entry, left zero.
+    sched: the sorted unit list ``decode_schedule`` wrote for this batch (with kv_indptr and num_kv_splits from the same call): the
+    same splits and results bit for bit, dispatched longest unit first on a grid without never-live workgroups.
     Returns (o or None, o_q fp8 [bs, Hq*Dv] or None, o_scale f32 [bs, 1] or None)."""
     _require_cuda(q, k_buffer, v_buffer, kv_indptr, kv_indices, attn_logits, attn_lse, num_kv_splits, merge_counters)
     bs, hq, d = q.shape
@@ -202,6 +205,15 @@ def decode_attention_merge_quant(q, k_buffer, v_buffer, kv_indptr, kv_indices, a
     o = torch.empty((bs, hq * dv), dtype=q.dtype, device=q.device) if want_o else None
     oq = torch.empty((bs, hq * dv), dtype=torch.float8_e4m3fn, device=q.device) if want_quant else None
     osc = torch.empty((bs, 1), dtype=torch.float32, device=q.device) if want_quant else None
+    if sched is not None:
+        _require_cuda(sched)
+        assert sched.dtype == torch.int32 and sched.is_contiguous()
+        check(lib.sgl_mi355_decode_attention_scheduled(
+            ptr(q), q.stride(0), ptr(k_buffer), ptr(v_buffer), kst, ksh, vst, vsh, ptr(kv_indptr), ptr(kv_indices), ptr(attn_logits),
+            ptr(attn_lse), ptr(num_kv_splits), int(max_kv_splits), ptr(sched), (sched.numel() - 4) // 4, bs, hq, hkv, d, dv, float(sm_scale), float(logit_cap),
+            dtype_code(q.dtype), dtype_code(k_buffer.dtype), float(k_scale), float(v_scale), ptr(merge_counters), ptr(o), ptr(oq),
+            ptr(osc), current_stream()))
+        return o, oq, osc
     check(lib.sgl_mi355_decode_attention_merge_quant(
         ptr(q), q.stride(0), ptr(k_buffer), ptr(v_buffer), kst, ksh, vst, vsh, ptr(kv_indptr), ptr(kv_indices), ptr(attn_logits),
         ptr(attn_lse), ptr(num_kv_splits), int(max_kv_splits), bs, hq, hkv, d, dv, float(sm_scale), float(logit_cap),

@@ -96,6 +96,23 @@ def move_kv_cache(data_ptrs, data_strides, max_stride_bytes: int, tgt_loc, src_l
                                           is64(t), ptr(s), is64(s), t.numel(), current_stream()))
 
 
+def decode_schedule_units(num_seq, num_head, num_kv_head, rounds_pct=150) -> int:
+    """Capacity of the sorted unit list ``decode_schedule`` writes for a batch of this geometry (= the attention launch's grid y);
+    the buffer holds 4 + 4 x capacity int32 words.  0: this geometry is not served (fall back to ``decode_metadata``)."""
+    return int(lib.sgl_mi355_decode_schedule_units(int(num_seq), int(num_head), int(num_kv_head), int(rounds_pct)))
+
+
+def decode_schedule(kv_indptr, num_kv_splits, sched, seq_lens, num_head, num_kv_head, max_kv_splits, rounds_pct=150) -> None:
+    """kv_indptr[1:bs+1] = cumsum(seq_lens), num_kv_splits (the balance rule: one round of resident workgroups when the lengths are
+    within 25 % of each other, ``rounds_pct`` / 100 rounds otherwise) and
+    the batch's (request, split) units as a list sorted longest first (sched, int32 [4 + 4 x decode_schedule_units(...)]), one launch.
+    Consumer: ``decode_attention_merge_quant(..., sched=sched)``."""
+    assert sched.dtype == torch.int32 and sched.is_contiguous() and kv_indptr.dtype == torch.int32 and num_kv_splits.dtype == torch.int32
+    check(lib.sgl_mi355_decode_schedule(ptr(kv_indptr), ptr(num_kv_splits), ptr(sched), (sched.numel() - 4) // 4, ptr(seq_lens),
+                                        is64(seq_lens), seq_lens.numel(), int(num_head), int(num_kv_head), int(max_kv_splits),
+                                        int(rounds_pct), current_stream()))
+
+
 def decode_metadata(kv_indptr, num_kv_splits, seq_lens, num_group, num_head, num_kv_head, max_kv_splits,
                     device_core_count, static_splits=False) -> None:
     """kv_indptr[1:bs+1] = cumsum(seq_lens) and num_kv_splits, one launch.  static_splits: 0/False = the reference's

@@ -37,6 +37,8 @@ class ForwardMetadata:
     # kv_indptr / kv_indices / num_kv_splits then describe the private suffixes only
     cascade_prefix_indices: Optional[torch.Tensor] = None
     cascade_prefix_splits: int = 0
+    # sorted (request, split) unit list of the decode launch (kv_split_rule 3; sgl_kernel.decode_schedule)
+    sched: Optional[torch.Tensor] = None
 
 
 def _rows(t):
@@ -72,9 +74,16 @@ class HipAttnBackend(AttentionBackend):
         if not skip_prefill:
             self.mask_indptr = torch.zeros((max_bs + 1,), dtype=torch.int64, device=self.device)   # triton_backend.py:97-99
         self.max_kv_splits = getattr(args, "triton_attention_num_kv_splits", None) or default_max_kv_splits()
-        # 0 = reference heuristic, 1 = static, 2 = MI355X balance rule (default; split counts are not parity-critical)
+        # 0 = reference heuristic, 1 = static, 2 = MI355X balance rule (default; split counts are not parity-critical), 3 = rule 2's
+        # splits as a unit list sorted longest first (ragged batches; where it does not apply -- window layers, cascade, head dims
+        # outside {64, 128}, more than 4096 units -- rule 2)
         self.static_kv_splits = 1 if getattr(args, "static_kv_splits", False) else int(getattr(args, "kv_split_rule", 2))
+        self.kv_split_rule = self.static_kv_splits
+        if self.static_kv_splits == 3:
+            self.static_kv_splits = 2
+        self.kv_sched_rounds_pct = int(getattr(args, "kv_sched_rounds_pct", 150))
         self.v_head_dim = model_runner.token_to_kv_pool.get_value_buffer(0).shape[-1]
+        self.qk_head_dim = model_runner.token_to_kv_pool.get_key_buffer(0).shape[-1]
         self.max_context_len = cfg.context_len
         gpu_id = getattr(model_runner, "gpu_id", 0)
         self.device_core_count = lib.sgl_mi355_device_cu_count(int(gpu_id))  # 256 on MI355X
@@ -103,7 +112,13 @@ class HipAttnBackend(AttentionBackend):
         K.create_kv_indices(self.req_to_token, req_pool_indices, window_lens, indptr, lens - window_lens, kv_indices)
         return indptr, kv_indices, (num_kv_splits if want_splits else None)
 
-    def _decode_metadata(self, bs, req_pool_indices, seq_lens, seq_lens_sum, kv_indices=None, scratch=None, window_bufs=None):
+    def _use_schedule(self) -> bool:
+        qk = self.qk_head_dim
+        return (self.kv_split_rule == 3 and self.merge_in_launch and not self._has_window()
+                and self.v_head_dim in (64, 128) and qk == self.v_head_dim and self.num_head * self.v_head_dim <= 16384)
+
+    def _decode_metadata(self, bs, req_pool_indices, seq_lens, seq_lens_sum, kv_indices=None, scratch=None, window_bufs=None,
+                         sched_buf=None):
         kv_indptr = self.kv_indptr[: bs + 1]
         if scratch is None:
             num_kv_splits = torch.empty((bs,), dtype=torch.int32, device=self.device)
@@ -115,13 +130,22 @@ class HipAttnBackend(AttentionBackend):
         # (an aborted launch or a foreign write would otherwise disable the merge of that request for good)
         if self._merge_counters is not None:
             self._merge_counters.zero_()
-        # one launch: kv_indptr[1:bs+1] = cumsum(seq_lens) and the per-request split heuristic
-        K.decode_metadata(kv_indptr, num_kv_splits, seq_lens, 1, self.num_head, self.num_kv_head, self.max_kv_splits,
-                          self.device_core_count, self.static_kv_splits)
+        sched = None
+        units = K.decode_schedule_units(bs, self.num_head, self.num_kv_head, self.kv_sched_rounds_pct) if self._use_schedule() else 0
+        if units > 0:
+            # one launch: kv_indptr, the split counts and the (request, split) units sorted longest first
+            words = 4 + 4 * units
+            sched = sched_buf[:words] if sched_buf is not None else torch.empty((words,), dtype=torch.int32, device=self.device)
+            K.decode_schedule(kv_indptr, num_kv_splits, sched, seq_lens, self.num_head, self.num_kv_head, self.max_kv_splits,
+                              self.kv_sched_rounds_pct)
+        else:
+            # one launch: kv_indptr[1:bs+1] = cumsum(seq_lens) and the per-request split heuristic
+            K.decode_metadata(kv_indptr, num_kv_splits, seq_lens, 1, self.num_head, self.num_kv_head, self.max_kv_splits,
+                              self.device_core_count, self.static_kv_splits)
         if kv_indices is None:
             kv_indices = torch.empty(seq_lens_sum, dtype=torch.int32, device=self.device)
         K.create_kv_indices(self.req_to_token, req_pool_indices, seq_lens, kv_indptr, None, kv_indices)
-        md = ForwardMetadata(attn_logits, attn_lse, None, num_kv_splits, kv_indptr, kv_indices, None)
+        md = ForwardMetadata(attn_logits, attn_lse, None, num_kv_splits, kv_indptr, kv_indices, None, sched=sched)
         if self._has_window():
             wi, ws = window_bufs if window_bufs is not None else (None, None)
             md.window_kv_indptr, md.window_kv_indices, md.window_num_kv_splits = self._window_metadata(
@@ -253,6 +277,7 @@ class HipAttnBackend(AttentionBackend):
             num_kv_splits=torch.full((max_num_tokens,), self.max_kv_splits, dtype=torch.int32, device=self.device),
         )
         self._graph["cascade_prefix"] = torch.zeros((self.max_context_len,), dtype=torch.int32, device=self.device)
+        self._graph["sched"] = torch.zeros((4 + 4 * 4096,), dtype=torch.int32, device=self.device)   # (the capacity's upper bound)
         if self._has_window():   # triton_backend.py:371-392
             self._graph["window_kv_indices"] = torch.zeros((max_num_tokens * (self.sliding_window_size + 1),), dtype=torch.int32, device=self.device)
             self._graph["window_num_kv_splits"] = torch.full((max_num_tokens,), self.max_kv_splits, dtype=torch.int32, device=self.device)
@@ -269,7 +294,7 @@ class HipAttnBackend(AttentionBackend):
                                                            g["kv_indices"], scratch, g["cascade_prefix"])
             return
         wb = (g["window_kv_indices"], g["window_num_kv_splits"][:bs]) if self._has_window() else None
-        self.forward_metadata = self._decode_metadata(bs, req_pool_indices, seq_lens, 0, g["kv_indices"], scratch, wb)
+        self.forward_metadata = self._decode_metadata(bs, req_pool_indices, seq_lens, 0, g["kv_indices"], scratch, wb, g["sched"])
 
     def init_forward_metadata_replay_cuda_graph(self, bs, req_pool_indices, seq_lens, seq_lens_sum, encoder_lens,
                                                 forward_mode, spec_info, seq_lens_cpu):
@@ -285,7 +310,7 @@ class HipAttnBackend(AttentionBackend):
             return
         wb = (g["window_kv_indices"], g["window_num_kv_splits"][:bs]) if self._has_window() else None
         self.forward_metadata = self._decode_metadata(bs, req_pool_indices[:bs], seq_lens[:bs], seq_lens_sum,
-                                                      g["kv_indices"], scratch, wb)
+                                                      g["kv_indices"], scratch, wb, g["sched"])
 
     def get_cuda_graph_seq_len_fill_value(self):
         return 1
@@ -340,7 +365,9 @@ class HipAttnBackend(AttentionBackend):
                 forward_batch.token_to_kv_pool.get_value_buffer(layer.layer_id),
                 kv_indptr, kv_indices, md.attn_logits, md.attn_lse, num_kv_splits, self.max_kv_splits, layer.scaling,
                 self._merge_counter_buf(q), layer.logit_cap, layer.k_scale_float or 1.0, layer.v_scale_float or 1.0,
-                want_o=True, want_quant=False)[0]
+                want_o=True, want_quant=False, sched=md.sched)[0]
+        if md.sched is not None:
+            raise RuntimeError("HipAttnBackend: the sorted unit list (kv_split_rule 3) needs the in-launch merge path")
         o = q.new_empty((q.shape[0], layer.tp_q_head_num * layer.v_head_dim))
         K.decode_attention_fwd(
             q.view(-1, layer.tp_q_head_num, layer.qk_head_dim),
@@ -374,6 +401,8 @@ class HipAttnBackend(AttentionBackend):
         the next op's quantisation): returns the ForwardMetadata holding attn_logits / attn_lse / num_kv_splits."""
         kv_indptr, kv_indices, num_kv_splits, _ = self._layer_kv(layer)
         md = self.forward_metadata
+        if md.sched is not None:
+            raise RuntimeError("HipAttnBackend: the sorted unit list (kv_split_rule 3) has no stage-1-only form")
         K.decode_attention_fwd(
             q.reshape(-1, layer.tp_q_head_num, layer.qk_head_dim),
             forward_batch.token_to_kv_pool.get_key_buffer(layer.layer_id),
@@ -396,7 +425,8 @@ class HipAttnBackend(AttentionBackend):
             forward_batch.token_to_kv_pool.get_key_buffer(layer.layer_id),
             forward_batch.token_to_kv_pool.get_value_buffer(layer.layer_id),
             kv_indptr, kv_indices, md.attn_logits, md.attn_lse, num_kv_splits, self.max_kv_splits, layer.scaling,
-            self._merge_counters, layer.logit_cap, layer.k_scale_float or 1.0, layer.v_scale_float or 1.0, want_o=want_o)
+            self._merge_counters, layer.logit_cap, layer.k_scale_float or 1.0, layer.v_scale_float or 1.0, want_o=want_o,
+            sched=md.sched)
 
     def support_triton(self):
         return False  # the host helpers use this build's HIP index kernels, never Triton

@@ -509,3 +509,158 @@ def test_backend_cascade_metadata_and_forward(pkg):
     with pytest.raises(ValueError, match="longer than the shared prefix"):
         backend.init_forward_metadata_cascade(fb, int(P["seq"].min()))
 
+
+
+# ---------------------------------------------------------------- round 5: the sorted unit list (kv_split_rule 3)
+def _schedule_reference(seq, target_even, target_ragged, max_splits):
+    """Host restatement of decode_schedule_kernel (csrc/kv_index.hip): (T, kv_indptr, splits per request, units sorted longest first)."""
+    seq = [int(x) for x in seq]
+    indptr = np.concatenate([[0], np.cumsum(seq)]).astype(np.int64)
+    tot = int(indptr[-1])
+    target = target_even if max(seq) * 8 < min(seq) * 10 else target_ragged
+    t = max(64, -(-(-(-tot // target)) // 32) * 32)
+    splits, units = [], []
+    for b, n in enumerate(seq):
+        ns = min(max(-(-n // t), 1), max_splits)
+        splits.append(ns)
+        per = -(-(-(-n // ns)) // 32) * 32          # decode_attention.py:90-94
+        for j in range(ns):
+            units.append((-min(max(n - j * per, 0), per), j, b))   # longest first; equal lengths: split index, then request
+    units.sort()
+    return t, indptr, splits, [(b, j) for _, j, b in units]
+
+
+def _ragged_pool_problem(seq, hq, hkv, d, dtype, seed):
+    g = torch.Generator().manual_seed(seed)
+    bs = len(seq)
+    seq = torch.tensor(seq, dtype=torch.int64)
+    total = int(seq.sum())
+    pool = total + 3
+    perm = (torch.randperm(pool - 1, generator=g) + 1).int()
+    r2t = torch.zeros(bs + 2, max(int(seq.max()), 1), dtype=torch.int32)
+    rpi = torch.randperm(bs + 2, generator=g)[:bs]
+    cur = 0
+    for i in range(bs):
+        r2t[rpi[i], : seq[i]] = perm[cur:cur + int(seq[i])]
+        cur += int(seq[i])
+    q = torch.randn(bs, hq, d, generator=g).to(dtype)
+    k = torch.randn(pool, hkv, d, generator=g).to(dtype)
+    v = torch.randn(pool, hkv, d, generator=g).to(dtype)
+    return dict(q=q, k=k, v=v, r2t=r2t, rpi=rpi, seq=seq, total=total)
+
+
+def _run_scheduled(sgl_kernel, pr, hq, hkv, d, max_splits, rounds_pct=150, use_list=True, logit_cap=0.0):
+    """The unit list's metadata (kv_indptr, split counts) serves both launches: with the list, and the ordinary 3-D grid over the same
+    split counts."""
+    dev = torch.device("cuda:0")
+    bs, seq = len(pr["seq"]), pr["seq"].to(dev)
+    kv_indptr = torch.zeros(bs + 1, dtype=torch.int32, device=dev)
+    nsplit = torch.zeros(bs, dtype=torch.int32, device=dev)
+    units = sgl_kernel.decode_schedule_units(bs, hq, hkv, rounds_pct)
+    assert units > 0
+    sched = torch.full((4 + 4 * units,), -7, dtype=torch.int32, device=dev)
+    sgl_kernel.decode_schedule(kv_indptr, nsplit, sched, seq, hq, hkv, max_splits, rounds_pct)
+    kv_indices = torch.empty(max(pr["total"], 1), dtype=torch.int32, device=dev)
+    sgl_kernel.create_kv_indices(pr["r2t"].to(dev), pr["rpi"].to(dev), seq, kv_indptr, None, kv_indices)
+    logits = torch.full((bs, hq, max_splits, d), float("nan"), dtype=torch.float32, device=dev)
+    lse = torch.full((bs, hq, max_splits), float("nan"), dtype=torch.float32, device=dev)
+    cnt = torch.zeros(bs, dtype=torch.int32, device=dev)
+    o, oq, osc = sgl_kernel.decode_attention_merge_quant(pr["q"].to(dev), pr["k"].to(dev), pr["v"].to(dev), kv_indptr, kv_indices, logits, lse,
+                                                         nsplit, max_splits, d ** -0.5, cnt, logit_cap, want_o=True, want_quant=True,
+                                                         sched=sched if use_list else None)
+    torch.cuda.synchronize()
+    assert int(cnt.abs().sum()) == 0, "the merge tickets must be left at zero"
+    return o.view(bs, hq, d).cpu(), oq.cpu(), osc.cpu(), (kv_indptr.cpu(), nsplit.cpu(), sched.cpu())
+
+
+SCHED_CASES = {
+    "ragged_37": dict(seq=lambda g: torch.randint(1, 600, (37,), generator=g).tolist(), hq=32, hkv=8, d=128, dtype=torch.bfloat16),
+    "uniform_8x1024": dict(seq=lambda g: [1024] * 8, hq=32, hkv=8, d=128, dtype=torch.bfloat16),
+    "one_long": dict(seq=lambda g: [5000], hq=32, hkv=8, d=128, dtype=torch.bfloat16),
+    "long_and_tiny": dict(seq=lambda g: [3, 7000, 1, 1, 250, 2], hq=16, hkv=2, d=128, dtype=torch.float16),
+    "many_tiny": dict(seq=lambda g: torch.randint(1, 6, (200,), generator=g).tolist(), hq=8, hkv=1, d=128, dtype=torch.bfloat16),
+    "group_20_d64": dict(seq=lambda g: torch.randint(20, 900, (19,), generator=g).tolist(), hq=40, hkv=2, d=64, dtype=torch.float16),
+    "shard_128": dict(seq=lambda g: torch.randint(64, 700, (128,), generator=g).tolist(), hq=8, hkv=1, d=128, dtype=torch.bfloat16),
+    "with_empty": dict(seq=lambda g: [0, 130, 0, 0, 64, 300, 0], hq=8, hkv=2, d=128, dtype=torch.bfloat16),
+}
+
+
+@pytest.mark.parametrize("name", list(SCHED_CASES))
+@pytest.mark.parametrize("max_splits,rounds_pct", [(16, 100), (1, 150), (5, 300), (16, 150)])
+def test_decode_schedule_list_matches_host_restatement(name, max_splits, rounds_pct, pkg):
+    from ltp_sglang_amd import sgl_kernel
+
+    c = SCHED_CASES[name]
+    seq = c["seq"](torch.Generator().manual_seed(11))
+    dev = torch.device("cuda:0")
+    bs = len(seq)
+    cap = sgl_kernel.decode_schedule_units(bs, c["hq"], c["hkv"], rounds_pct)
+    assert cap > bs
+    kv_indptr = torch.full((bs + 1,), -1, dtype=torch.int32, device=dev)
+    nsplit = torch.full((bs,), -1, dtype=torch.int32, device=dev)
+    sched = torch.full((4 + 4 * cap,), -7, dtype=torch.int32, device=dev)
+    sgl_kernel.decode_schedule(kv_indptr, nsplit, sched, torch.tensor(seq, dtype=torch.int64, device=dev), c["hq"], c["hkv"], max_splits, rounds_pct)
+    t, indptr, splits, units = _schedule_reference(seq, sgl_kernel.decode_schedule_units(bs, c["hq"], c["hkv"], 100) - bs, cap - bs, max_splits)
+    s = sched.cpu().tolist()
+    assert s[:4] == [t, len(units), int(indptr[-1]), cap] and len(units) <= cap
+    assert kv_indptr.cpu().tolist() == indptr.tolist() and nsplit.cpu().tolist() == splits
+    for i, (b, j) in enumerate(units):
+        assert s[4 + 4 * i: 8 + 4 * i] == [b, j | (splits[b] << 16), int(indptr[b]), seq[b]], (i, s[4 + 4 * i: 8 + 4 * i], b, j)
+    assert all(x == -7 for x in s[4 + 4 * len(units):])   # nothing written past the list
+
+
+@pytest.mark.parametrize("name", list(SCHED_CASES))
+@pytest.mark.parametrize("max_splits,rounds_pct", [(16, 150), (3, 200)])
+def test_decode_scheduled_is_bit_identical_and_matches_oracle(name, max_splits, rounds_pct, pkg):
+    """The launch over the sorted unit list against the ordinary grid over the same split counts: the same (request, split) units with
+    the same boundaries and arithmetic in another dispatch order, so every output byte is equal; and against the float64 oracle."""
+    from ltp_sglang_amd import sgl_kernel
+
+    c = SCHED_CASES[name]
+    seq = c["seq"](torch.Generator().manual_seed(11))
+    pr = _ragged_pool_problem(seq, c["hq"], c["hkv"], c["d"], c["dtype"], seed=len(seq))
+    o_s, oq_s, osc_s, _ = _run_scheduled(sgl_kernel, pr, c["hq"], c["hkv"], c["d"], max_splits, rounds_pct, True)
+    o_u, oq_u, osc_u, _ = _run_scheduled(sgl_kernel, pr, c["hq"], c["hkv"], c["d"], max_splits, rounds_pct, False)
+    live = [b for b, n in enumerate(seq) if n > 0]
+    assert torch.equal(o_s[live].view(torch.int16), o_u[live].view(torch.int16))
+    assert torch.equal(oq_s[live].view(torch.uint8), oq_u[live].view(torch.uint8)) and torch.equal(osc_s[live], osc_u[live])
+    assert torch.isfinite(o_s[live].float()).all()
+    tol = TOL_F64[c["dtype"]]
+    rng = np.random.default_rng(3)
+    sample = sorted(set([live[0], live[-1], live[int(np.argmax([seq[b] for b in live]))]] + rng.choice(live, size=min(3, len(live)), replace=False).tolist()))
+    for b in sample:
+        ref = oa.decode_attention_f64(pr["q"][b:b + 1], pr["k"], pr["v"], pr["r2t"], pr["rpi"][b:b + 1], pr["seq"][b:b + 1], c["d"] ** -0.5)
+        assert (o_s[b].double() - ref[0]).abs().max().item() <= tol, (name, b, seq[b])
+
+
+def test_decode_scheduled_logit_cap_and_fp8_kv(pkg):
+    from ltp_sglang_amd import sgl_kernel
+
+    seq = torch.randint(1, 500, (23,), generator=torch.Generator().manual_seed(2)).tolist()
+    pr = _ragged_pool_problem(seq, 32, 8, 128, torch.bfloat16, seed=4)
+    o_s, *_ = _run_scheduled(sgl_kernel, pr, 32, 8, 128, 16, 100, True, logit_cap=30.0)
+    o_u, *_ = _run_scheduled(sgl_kernel, pr, 32, 8, 128, 16, 100, False, logit_cap=30.0)
+    assert torch.equal(o_s.view(torch.int16), o_u.view(torch.int16))
+    pr8 = dict(pr)
+    pr8["k"] = (pr["k"].float() * 0.5).to(torch.float8_e4m3fn)
+    pr8["v"] = (pr["v"].float() * 0.5).to(torch.float8_e4m3fn)
+    o_s, *_ = _run_scheduled(sgl_kernel, pr8, 32, 8, 128, 16, 100, True)
+    o_u, *_ = _run_scheduled(sgl_kernel, pr8, 32, 8, 128, 16, 100, False)
+    assert torch.isfinite(o_s.float()).all() and torch.equal(o_s.view(torch.int16), o_u.view(torch.int16))
+
+
+def test_decode_scheduled_argument_checks(pkg):
+    from ltp_sglang_amd import sgl_kernel
+
+    dev = torch.device("cuda:0")
+    seq = torch.tensor([5, 9], dtype=torch.int64, device=dev)
+    kv_indptr = torch.zeros(3, dtype=torch.int32, device=dev)
+    ns = torch.zeros(2, dtype=torch.int32, device=dev)
+    units = sgl_kernel.decode_schedule_units(2, 8, 2)
+    with pytest.raises(RuntimeError, match="max_kv_splits"):
+        sgl_kernel.decode_schedule(kv_indptr, ns, torch.zeros(4 + 4 * units, dtype=torch.int32, device=dev), seq, 8, 2, 0)
+    with pytest.raises(RuntimeError, match="units"):
+        sgl_kernel.decode_schedule(kv_indptr, ns, torch.zeros(4 + 4 * (units - 1), dtype=torch.int32, device=dev), seq, 8, 2, 16)
+    assert sgl_kernel.decode_schedule_units(0, 8, 2) == 0
+    assert sgl_kernel.decode_schedule_units(4000, 8, 1) == 0        # more than 4096 units: served by decode_metadata
+    assert sgl_kernel.decode_schedule_units(8, 8, 3) == 0
