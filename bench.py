@@ -59,7 +59,7 @@ def parse_args():
     ap.add_argument("--skinny-hook", type=int, default=0, help="measurement hook: value passed to sgl_mi355_skinny_gemm_force_generic "
                     "(2 = 8-row tiles one tile ahead, the round-3 form; 3 = all tiles of a workgroup up front, the default; 4 / 5 = slab-mode "
                     "launches with one / two tiles in flight per wave)")
-    ap.add_argument("--kv-split-rule", type=int, default=2, help="0 = the reference's heuristic, 1 = max splits everywhere, 2 = the MI355X balance rule, 3 = rule 2's units as a list sorted longest first, on a grid without never-live workgroups")
+    ap.add_argument("--kv-split-rule", type=int, default=3, help="0 = the reference's heuristic, 1 = max splits everywhere, 2 = the MI355X balance rule, 3 = rule 2's units as a list sorted longest first, on a grid without never-live workgroups")
     ap.add_argument("--kv-sched-rounds-pct", type=int, default=150, help="rule 3: units sized for this many percent of one round of resident workgroups")
     ap.add_argument("--max-kv-splits", type=int, default=16, help="triton_attention_num_kv_splits (16 = the reference's HIP default)")
     ap.add_argument("--all-reduce", default="auto", choices=["auto", "rccl", "p2p"],

@@ -74,10 +74,10 @@ class HipAttnBackend(AttentionBackend):
         if not skip_prefill:
             self.mask_indptr = torch.zeros((max_bs + 1,), dtype=torch.int64, device=self.device)   # triton_backend.py:97-99
         self.max_kv_splits = getattr(args, "triton_attention_num_kv_splits", None) or default_max_kv_splits()
-        # 0 = reference heuristic, 1 = static, 2 = MI355X balance rule (default; split counts are not parity-critical), 3 = rule 2's
-        # splits as a unit list sorted longest first (ragged batches; where it does not apply -- window layers, cascade, head dims
-        # outside {64, 128}, more than 4096 units -- rule 2)
-        self.static_kv_splits = 1 if getattr(args, "static_kv_splits", False) else int(getattr(args, "kv_split_rule", 2))
+        # 0 = reference heuristic, 1 = static, 2 = MI355X balance rule (split counts are not parity-critical), 3 (default) = rule 2's
+        # splits as a unit list sorted longest first, ragged batches cut into smaller units (where it does not apply -- window
+        # layers, cascade, head dims outside {64, 128}, more than 4096 units -- rule 2)
+        self.static_kv_splits = 1 if getattr(args, "static_kv_splits", False) else int(getattr(args, "kv_split_rule", 3))
         self.kv_split_rule = self.static_kv_splits
         if self.static_kv_splits == 3:
             self.static_kv_splits = 2

@@ -613,7 +613,7 @@ class SyntheticModelRunner:
     def __init__(self, cfg: LlamaShape, quantization: Optional[str], max_running_requests: int, context_len: int,
                  max_total_tokens: int, device: str = "cuda:0", dtype=torch.bfloat16, seed: int = 0,
                  kv_cache_dtype: Optional[torch.dtype] = None, init_weights: bool = True, max_kv_splits: int = 16,
-                 kv_split_rule: int = 2, kv_sched_rounds_pct: int = 150):
+                 kv_split_rule: int = 3, kv_sched_rounds_pct: int = 150):
         self.device = device
         self.gpu_id = torch.device(device).index or 0
         self.dtype = dtype

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Every BASELINE.json configuration from ONE command each (bench.py --config N), collected into one file:
 #   gpurun -- 'bash tools/run_configs.sh r5'      -> gpurun_out/<tag>_configs.jsonl (one JSON line per configuration; config 5 also with
-#   the reference's split heuristic, --kv-split-rule 0)
+#   round 4's balance rule on the 3-D grid, --kv-split-rule 2, and the reference's split heuristic, --kv-split-rule 0)
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$R"
 TAG=${1:-r5}
@@ -13,6 +13,7 @@ run --config 2
 run --config 3
 run --config 4
 run --config 5
+run --config 5 --kv-split-rule 2
 run --config 5 --kv-split-rule 0
 python3 - $OUT <<'PY'
 import json, sys
