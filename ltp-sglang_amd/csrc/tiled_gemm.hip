@@ -693,6 +693,176 @@ __global__ __launch_bounds__(NWV * 64, 1) void fp8_gemm256_kernel(const GemmPara
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// PING-PONG form of the 256x256 fp8 kernel (round 5; the guide's "256^2 8-phase" structure on the block-scaled 16x16x128 loop).
+// Same tile, wave layout (2 x 4 waves of 128 x 64 outputs), LDS image, staging instructions, k order per output (bit-identical
+// results) and epilogues as fp8_gemm256_kernel; what differs is the schedule.  A K slice is four PHASES (one 32-row group of the
+// wave's X rows each: 8 MFMAs = 256 cycles of the matrix pipe), every phase is
+//     LOAD: fragment reads of the phase (+ the slice's W fragments in phase 0) | this wave's share of the staging | B1 | lgkmcnt(0)
+//     | 8 MFMAs at priority 1 | B2
+// and waves 4-7 run ONE BARRIER behind waves 0-3: while one wave of a SIMD is in its MFMA block the other is in its LOAD part, so
+// the two never compete for the pipe and neither's LDS round trip or barrier wait leaves it idle (round 4's counters: all eight
+// waves in one phase, 27-31 % of wave cycles parked at the slice's single barrier, 48-50 % stalled at issue behind the partner).
+// Buffers: two slices of [W 32 KiB | X 32 KiB], restaged REGION BY REGION as soon as a region's last reader is through -- W of slice
+// s + 2 in phase 2 of slice s, wave c's 32 X rows (read by its group in phase c) in the phase after -- so every DMA has 1.5-1.75
+// slices to land, as in the one-barrier kernel.  vmcnt: counted, once per slice (phase 3), never 0 in the loop.
+template <typename OutT, bool SILU = false>
+__global__ __launch_bounds__(512, 1) void fp8_gemm256pp_kernel(const GemmParams p) {
+  constexpr int NWV = 8, WN = 256, WCOLS = 4, JN = 4, MR = 128, NI = 8, IG = 2;
+  constexpr int RPW = 32, WRPW = 32;          // staging rows per wave and operand
+  constexpr int WOPB = WN * BKB, BUFB = WOPB + OPB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][W | X]
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int bid = blockIdx.x;
+  const int q = nwg / 8, r8 = nwg % 8, xcd = bid % 8;
+  const int wgid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + bid / 8;
+  const int GM = p.group_m;
+  const int per_group = GM * p.tiles_n;
+  const int grp_ = wgid / per_group, in_grp = wgid - grp_ * per_group;
+  const int gsz = min(p.tiles_m - grp_ * GM, GM);
+  const int tm = grp_ * GM + in_grp % gsz, tn = in_grp / gsz;
+  const int m0 = tm * T2, n0 = tn * WN;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = (w / WCOLS) * MR, wn = (w % WCOLS) * (16 * JN);
+  const int c = w & 3;           // this wave's 32 X rows are the ones its group reads in phase c
+  const bool late = w >= 4;      // waves 4-7: one barrier behind
+  if (p.stagger_q > 0 && (int)blockIdx.x < p.stagger_cus) {   // phase stagger of the CUs' first tiles (see fp8_gemm256_kernel)
+    const int mask = (p.stagger_q & 64) ? 31 : 15;
+    const int steps = ((blockIdx.x >> 3) & mask) * (p.stagger_q & 63);
+    for (int t = 0; t < steps; ++t) __builtin_amdgcn_s_sleep(8);
+  }
+  const int a = lane & 15, g = lane >> 4;
+  const auto wrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (unsigned)((int64_t)p.N * p.w_stride), 0x00020000);
+  const auto xrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (unsigned)((int64_t)p.M * p.x_stride), 0x00020000);
+  unsigned wvo[2], xvo[2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par) {
+    const int rl = lane >> 3;
+    const int chunk = (lane & 7) ^ (((lane >> 4) + 4 * par) & 7);
+    wvo[par] = (unsigned)((int64_t)(n0 + WRPW * w + rl) * p.w_stride) + chunk * 16;
+    xvo[par] = (unsigned)((int64_t)(m0 + RPW * w + rl) * p.x_stride) + chunk * 16;
+  }
+  const int nk = p.kbytes / BKB;
+  auto stage_w = [&](int kt, int buf) {
+    const int off = kt * BKB;
+    auto* wb = (__attribute__((address_space(3))) char*)(smem + buf * BUFB + (WRPW * w) * BKB);
+#pragma unroll
+    for (int t = 0; t < WRPW / 8; ++t) __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, wb + t * 8 * BKB, 16, wvo[t & 1], (int)(t * 8 * p.w_stride) + off, 0, 0);
+  };
+  auto stage_x = [&](int kt, int buf) {
+    const int off = kt * BKB;
+    auto* xb = (__attribute__((address_space(3))) char*)(smem + buf * BUFB + WOPB + (RPW * w) * BKB);
+#pragma unroll
+    for (int t = 0; t < RPW / 8; ++t) __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, xb + t * 8 * BKB, 16, xvo[t & 1], (int)(t * 8 * p.x_stride) + off, 0, 0);
+  };
+
+  f32x4_t acc[JN][NI];
+#pragma unroll
+  for (int j = 0; j < JN; ++j)
+#pragma unroll
+    for (int i = 0; i < NI; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  u32x4_t wf[JN][2], xf[IG][2];
+  auto load_w = [&](int buf) {
+    const char* wa = smem + buf * BUFB;
+#pragma unroll
+    for (int j = 0; j < JN; ++j)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) wf[j][h] = *(const u32x4_t*)(wa + lds_off(wn + 16 * j + a, 4 * h + g));
+  };
+  auto load_x = [&](int buf, int grp) {
+    const char* xa = smem + buf * BUFB + WOPB;
+#pragma unroll
+    for (int i = 0; i < IG; ++i)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) xf[i][h] = *(const u32x4_t*)(xa + lds_off(wm + 16 * IG * grp + 16 * i + a, 4 * h + g));
+  };
+  // (the MFMA builtin touches no memory and hipcc moves such calls across raw s_barriers -- it gathered the four blocks of a slice behind
+  // the last barrier: the phase's X fragments are made opaque in front of the block and its accumulators behind it, which ties the
+  // block to the volatile statements, i.e. to the two barriers, around it)
+  auto mma = [&](int grp) {
+#pragma unroll
+    for (int i = 0; i < IG; ++i)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) asm volatile("" : "+v"(xf[i][h]));
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < IG; ++i)
+#pragma unroll
+      for (int j = 0; j < JN; ++j) mfma_mx(wf[j][0], wf[j][1], xf[i][0], xf[i][1], acc[j][IG * grp + i]);
+    __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+    for (int i = 0; i < IG; ++i)
+#pragma unroll
+      for (int j = 0; j < JN; ++j) asm volatile("" : "+v"(acc[j][IG * grp + i]));
+  };
+
+  stage_w(0, 0);
+  stage_x(0, 0);
+  if constexpr (SILU) {   // the silu table -> LDS once per workgroup, behind the first slice's DMA
+    for (int i = tid; i < kSiluLut / 8; i += NWV * 64) *(u32x4_t*)(smem + kSiluLdsOff + 16 * i) = *(const u32x4_t*)(p.silu_lut + 8 * i);
+  }
+  stage_w(1, 1);
+  stage_x(1, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (late) __builtin_amdgcn_s_barrier();   // waves 4-7 fall one barrier behind; waves 0-3 take the matching one after the loop
+
+  // one phase.  P: 0..3; the staging of the phase goes between the fragment reads and the first barrier (the MFMA block of the other
+  // group is running: the DMA issue costs it nothing)
+  auto phase = [&](int s, int buf, auto p_) {
+    constexpr int P = decltype(p_)::value;
+    if constexpr (P == 0) load_w(buf);
+    load_x(buf, P);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (P == 3) {
+      // slice s + 1 must have landed before anyone reads it in the next phase; still allowed in flight: this wave's W (and, for the
+      // waves whose X rows free early, X) of slice s + 2
+      if (c < 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    }
+    if constexpr (P == 2) stage_w(min(s + 2, nk - 1), buf);              // W of this buffer: every wave read it in phase 0
+    if (c == (P + 3) % 4) {                                              // this wave's X rows were read in phase c = P - 1
+      if constexpr (P == 0) { if (s > 0) stage_x(min(s + 1, nk - 1), buf ^ 1); }   // (rows of slice s - 1, read in its phase 3)
+      else stage_x(min(s + 2, nk - 1), buf);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);   // (MFMAs touch no memory: without the pins hipcc gathers the blocks of several phases behind one barrier)
+    mma(P);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+  for (int s = 0; s < nk; ++s) {
+    const int buf = s & 1;
+    phase(s, buf, I0{});
+    phase(s, buf, I1{});
+    phase(s, buf, I2{});
+    phase(s, buf, I3{});
+  }
+  if (!late) __builtin_amdgcn_s_barrier();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may be in flight when the workgroup ends
+
+  if constexpr (SILU) {
+    __syncthreads();
+    epilogue_silu_lds<OutT>(p, acc, m0, wm, n0, wn, smem, tid, lane);
+    return;
+  }
+  if (p.N % 8 == 0 && p.y_stride % 8 == 0 && ((uintptr_t)p.y & 15) == 0) {
+    __syncthreads();
+    epilogue_scaled_lds<OutT, NI, JN>(p, acc, m0 + wm, n0 + wn, smem + w * (MR * kEpiRowB), lane);
+    return;
+  }
+  epilogue_scaled<OutT, NI, JN>(p, acc, m0 + wm + a, n0 + wn + 4 * g);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // PERSISTENT form of the 256x256 kernel for launches of many tiles per CU (prefill): one workgroup per CU walks its XCD's tile list
 // (tile j, j + W, j + 2 W, ... for the W workgroups of an XCD: the order the dispatcher produces for equal tile times, so the
 // grouped L2 reuse is the same), and the NEXT tile's first K slice is staged while the current tile's last slice is multiplied:
@@ -1049,6 +1219,11 @@ int g_tiled_group_m = 8;   // r3 sweep (tools/debug/gm_sweep.py, M = 8192 / 16 3
 int g_tiled_stagger = 1;  // x 1024 cycles per step, 16 steps: CUs spread over ~6.5 us
 int g_tiled_force = 0;  // test hook: 1 = always the 128x128 kernel, 2 = the 256x256 kernel whenever its shape rules allow
 
+// the ping-pong schedule (fp8_gemm256pp_kernel) for one-tile-per-workgroup fp8 256 x 256 launches: 1 (default) = where K >= 8 KiB --
+// measured (tools/debug/pingpong_ab.py, profiles/round5_ab_gemm_pingpong.json): K = 8192 -2.6...-4.5 %, K = 14336 -3.5...-5.4 %, K = 28672
+// -6...-8.5 % against the one-barrier schedule at M = 2048 ... 65 536; at K = 4096 it ties the persistent form (-2 % against one tile per
+// workgroup), which keeps those launches.  0 = never, 2 = wherever the kernel applies (force_tile 5000 / 5001 / 5002)
+int g_tiled_pingpong = 1;
 template <typename OutT, int NWV, bool DMA = true, int ES = TG_FP8, bool SILU = false, int WN = 256>
 int launch256(GemmParams& p, hipStream_t st) {
   constexpr int smem = (WN == 128 ? 3 : 2) * (WN * BKB + OPB) + (SILU ? kSiluLut * 2 : 0);  // 128 KiB (+ 18.5 KiB: the silu table); 3 x 48 KiB for 256 x 128 tiles
@@ -1062,6 +1237,18 @@ int launch256(GemmParams& p, hipStream_t st) {
   p.group_m = g_tiled_group_m;
   p.stagger_cus = tg_cus();
   p.stagger_q = (p.tiles_m * p.tiles_n >= 2 * p.stagger_cus) ? g_tiled_stagger : 0;  // needs a second round to pay off
+  if constexpr (NWV == 8 && DMA && ES == TG_FP8 && WN == 256) {
+    if (p.kbytes >= 4 * BKB && (g_tiled_pingpong == 2 || (g_tiled_pingpong == 1 && p.kbytes >= 8192))) {
+      static bool pp_attr_set = false;
+      if (!pp_attr_set) {
+        (void)hipFuncSetAttribute((const void*)fp8_gemm256pp_kernel<OutT, SILU>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        pp_attr_set = true;
+      }
+      hipLaunchKernelGGL((fp8_gemm256pp_kernel<OutT, SILU>), dim3(p.tiles_m * p.tiles_n), dim3(512), smem, st, p);
+      SGL_HIP_LAUNCH_CHECK();
+      return SGL_MI355_OK;
+    }
+  }
   hipLaunchKernelGGL((fp8_gemm256_kernel<OutT, NWV, DMA, ES, SILU, WN>), dim3(p.tiles_m * p.tiles_n), dim3(NWV * 64), smem, st, p);
   SGL_HIP_LAUNCH_CHECK();
   return SGL_MI355_OK;
@@ -1412,6 +1599,10 @@ int sgl_mi355_internal_tiled_gemm_silu_mul(const void* x, int64_t x_stride_b, co
 extern "C" int sgl_mi355_fp8_gemm_force_tile(int mode) {
   if (mode >= 3000 && mode < 4000) {  // measurement hook: 3001 = persistent 256x256 kernel where a launch has at least two tiles per CU (default), 3000 = never
     g_tiled_persistent = mode - 3000;
+    return SGL_MI355_OK;
+  }
+  if (mode >= 5000) {  // measurement hook: 5001 = ping-pong schedule for one-tile-per-workgroup fp8 256 x 256 launches with K >= 8 KiB (default), 5002 = all of them, 5000 = none
+    g_tiled_pingpong = mode - 5000;
     return SGL_MI355_OK;
   }
   if (mode >= 4000) {  // measurement hook: 4001 = dynamic tile schedule where counters are available (default), 4000 = static schedule

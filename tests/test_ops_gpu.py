@@ -667,6 +667,49 @@ def test_fp8_scaled_mm_persistent_256_kernel_bits_equal_one_tile_per_workgroup(m
     assert torch.equal(outs[3000], outs[3001])
 
 
+@pytest.mark.parametrize("m,n,k", [(2048, 4096, 512), (1030, 4104, 640), (4096, 2048, 8192), (777, 1000, 9216), (2048, 4096, 14336)])
+def test_fp8_scaled_mm_ping_pong_schedule_bits_equal_one_barrier_schedule(m, n, k, sk):
+    """The ping-pong schedule of the 256x256 fp8 kernel (csrc/tiled_gemm.hip fp8_gemm256pp_kernel: four phases per K slice, two barriers
+    per phase, waves 4-7 one barrier behind waves 0-3, buffers restaged region by region with counted vmcnt -- default for K >= 8 KiB)
+    against the one-barrier-per-slice kernel on the same tile: same k order per output and the same epilogue, so the same bits, with K
+    of 4 / 5 / 64 / 72 / 112 slices, ragged M and N, both output types and the SiluAndMul epilogue; and the oracle's tolerance.  Run
+    five times over: a race between a restaged region and its readers would show as a rare wrong tile."""
+    from ltp_sglang_amd import _cabi
+    ft = _cabi.lib.sgl_mi355_fp8_gemm_force_tile
+    for out in ("bf16", "f16"):
+        c = _cases.build_gemm_case(dict(m=m, n=n, k=k, bias=True, out=out), seed=m + n + k)
+        a, wt, sa, sb, bias = (c[x].to(DEV) for x in ("a", "w", "sa", "sb", "bias"))
+        outs = {}
+        for name, modes in (("one_barrier", (2, 3000, 5000)), ("ping_pong", (2, 3000, 5002))):
+            for md in modes:
+                _cabi.check(ft(md))
+            try:
+                outs[name] = [sk.fp8_scaled_mm(a, wt.t(), sa, sb, c["out_dtype"], bias) for _ in range(5 if name == "ping_pong" else 1)]
+            finally:
+                ft(0); ft(3001); ft(5001)
+        for o in outs["ping_pong"]:
+            assert torch.equal(outs["one_barrier"][0], o)
+        if out == "bf16":
+            ref = oq.scaled_mm(c["a"], c["w"].t(), c["sa"], c["sb"], c["out_dtype"], c["bias"])
+            torch.testing.assert_close(outs["ping_pong"][0].cpu().float(), ref.float(), rtol=1.6e-2, atol=0.3 * max(1.0, (k / 1024) ** 0.5))
+    if n % 256 == 0 and m % 256 == 0:   # the SiluAndMul epilogue (gate_up): both schedules, one tile per workgroup
+        g = torch.Generator().manual_seed(5)
+        w = (torch.randn(n, k, generator=g) * 0.6).clamp(-3, 3).to(torch.float8_e4m3fn).to(DEV)
+        wi = sk.interleave_gate_up_rows(w.view(torch.uint8), 16).view(torch.float8_e4m3fn)
+        sw = sk.interleave_gate_up_rows(torch.rand(n, generator=g).to(DEV) * 0.02, 16)
+        x = (torch.randn(m, k, generator=g)).to(torch.float8_e4m3fn).to(DEV)
+        sx = torch.rand(m, generator=g).to(DEV) * 0.1
+        outs = {}
+        for name, modes in (("one_barrier", (3000, 5000)), ("ping_pong", (3000, 5002))):
+            for md in modes:
+                _cabi.check(ft(md))
+            try:
+                outs[name] = sk.fp8_gemm_silu_mul(x, sx, wi, sw, torch.bfloat16, 16)
+            finally:
+                ft(3001); ft(5001)
+        assert torch.equal(outs["one_barrier"], outs["ping_pong"])
+
+
 @pytest.mark.parametrize("m,n,k", [(8192, 4096, 512), (4100, 8200, 384), (4352, 7936, 9216)])
 def test_persistent_256_kernel_dynamic_tile_schedule_same_bits(m, n, k, sk):
     """Round 4: the persistent kernel draws its tiles after the first from per-XCD ticket counters (one of the 64 eight-word slots in the last 512
