@@ -262,7 +262,8 @@ int sgl_mi355_skinny_gemm_force_generic(int on);
   * streaming 128x128 tile (default for M <= 256), 7 = the 256x128 tile (eight waves of 64x64 outputs; default where 256x256 tiles are
   * fewer than the CUs and half-size tiles fill them); 100 + g = scheduling group height g of the 256x256 kernel; 3001 / 3000 =
   * persistent form of the 256x256 kernel where a launch has at least two tiles per CU (default) / one tile per workgroup always;
-  * 5001 / 5002 / 5000 = ping-pong schedule of the one-tile-per-workgroup fp8 256x256 kernel for K >= 8 KiB (default) / always / never. */
+  * 5001 / 5000 = ping-pong schedule of the fp8 256x256 kernel (default) / round 4's one-barrier kernels (persistent where that won); 5002 / 5003 =
+  * the ping-pong schedule with four / two phases per K slice. */
 int sgl_mi355_fp8_gemm_force_tile(int mode);
 /* Tiled MFMA GEMM for M > 64 with the same contract as sgl_mi355_skinny_gemm's fp8 case:
  * fp8_scaled_mm, sgl-kernel/csrc/gemm/fp8_gemm_kernel.cu:1071-1146 (CUTLASS tile dispatch :303-440,739-796). */

@@ -705,7 +705,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void fp8_gemm256_kernel(const GemmPara
 // Buffers: two slices of [W 32 KiB | X 32 KiB], restaged REGION BY REGION as soon as a region's last reader is through -- W of slice
 // s + 2 in phase 2 of slice s, wave c's 32 X rows (read by its group in phase c) in the phase after -- so every DMA has 1.5-1.75
 // slices to land, as in the one-barrier kernel.  vmcnt: counted, once per slice (phase 3), never 0 in the loop.
-template <typename OutT, bool SILU = false>
+template <typename OutT, bool SILU = false, int PH = 4>   // PH: phases per K slice (4 blocks of 8 MFMAs, or 2 of 16)
 __global__ __launch_bounds__(512, 1) void fp8_gemm256pp_kernel(const GemmParams p) {
   constexpr int NWV = 8, WN = 256, WCOLS = 4, JN = 4, MR = 128, NI = 8, IG = 2;
   constexpr int RPW = 32, WRPW = 32;          // staging rows per wave and operand
@@ -762,7 +762,8 @@ __global__ __launch_bounds__(512, 1) void fp8_gemm256pp_kernel(const GemmParams 
   for (int j = 0; j < JN; ++j)
 #pragma unroll
     for (int i = 0; i < NI; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  u32x4_t wf[JN][2], xf[IG][2];
+  constexpr int XG = 4 / PH;   // 32-row X groups per phase
+  u32x4_t wf[JN][2], xf[XG * IG][2];
   auto load_w = [&](int buf) {
     const char* wa = smem + buf * BUFB;
 #pragma unroll
@@ -770,31 +771,31 @@ __global__ __launch_bounds__(512, 1) void fp8_gemm256pp_kernel(const GemmParams 
 #pragma unroll
       for (int h = 0; h < 2; ++h) wf[j][h] = *(const u32x4_t*)(wa + lds_off(wn + 16 * j + a, 4 * h + g));
   };
-  auto load_x = [&](int buf, int grp) {
+  auto load_x = [&](int buf, int grp, int slot = 0) {
     const char* xa = smem + buf * BUFB + WOPB;
 #pragma unroll
     for (int i = 0; i < IG; ++i)
 #pragma unroll
-      for (int h = 0; h < 2; ++h) xf[i][h] = *(const u32x4_t*)(xa + lds_off(wm + 16 * IG * grp + 16 * i + a, 4 * h + g));
+      for (int h = 0; h < 2; ++h) xf[slot * IG + i][h] = *(const u32x4_t*)(xa + lds_off(wm + 16 * IG * grp + 16 * i + a, 4 * h + g));
   };
   // (the MFMA builtin touches no memory and hipcc moves such calls across raw s_barriers -- it gathered the four blocks of a slice behind
   // the last barrier: the phase's X fragments are made opaque in front of the block and its accumulators behind it, which ties the
   // block to the volatile statements, i.e. to the two barriers, around it)
-  auto mma = [&](int grp) {
+  auto mma = [&](int grp0) {   // the phase's XG groups: grp0 .. grp0 + XG - 1
 #pragma unroll
-    for (int i = 0; i < IG; ++i)
+    for (int i = 0; i < XG * IG; ++i)
 #pragma unroll
       for (int h = 0; h < 2; ++h) asm volatile("" : "+v"(xf[i][h]));
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int i = 0; i < IG; ++i)
+    for (int i = 0; i < XG * IG; ++i)
 #pragma unroll
-      for (int j = 0; j < JN; ++j) mfma_mx(wf[j][0], wf[j][1], xf[i][0], xf[i][1], acc[j][IG * grp + i]);
+      for (int j = 0; j < JN; ++j) mfma_mx(wf[j][0], wf[j][1], xf[i][0], xf[i][1], acc[j][IG * grp0 + i]);
     __builtin_amdgcn_s_setprio(0);
 #pragma unroll
-    for (int i = 0; i < IG; ++i)
+    for (int i = 0; i < XG * IG; ++i)
 #pragma unroll
-      for (int j = 0; j < JN; ++j) asm volatile("" : "+v"(acc[j][IG * grp + i]));
+      for (int j = 0; j < JN; ++j) asm volatile("" : "+v"(acc[j][IG * grp0 + i]));
   };
 
   stage_w(0, 0);
@@ -808,6 +809,11 @@ __global__ __launch_bounds__(512, 1) void fp8_gemm256pp_kernel(const GemmParams 
   __syncthreads();
   if (late) __builtin_amdgcn_s_barrier();   // waves 4-7 fall one barrier behind; waves 0-3 take the matching one after the loop
 
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+  if constexpr (PH == 4) {
   // one phase.  P: 0..3; the staging of the phase goes between the fragment reads and the first barrier (the MFMA block of the other
   // group is running: the DMA issue costs it nothing)
   auto phase = [&](int s, int buf, auto p_) {
@@ -835,16 +841,51 @@ __global__ __launch_bounds__(512, 1) void fp8_gemm256pp_kernel(const GemmParams 
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   };
-  using I0 = std::integral_constant<int, 0>;
-  using I1 = std::integral_constant<int, 1>;
-  using I2 = std::integral_constant<int, 2>;
-  using I3 = std::integral_constant<int, 3>;
   for (int s = 0; s < nk; ++s) {
     const int buf = s & 1;
     phase(s, buf, I0{});
     phase(s, buf, I1{});
     phase(s, buf, I2{});
     phase(s, buf, I3{});
+  }
+  } else {
+  // two phases per slice: blocks of 16 MFMAs, half as many barriers.  Q0 reads W and X groups 0, 1 (the rows of waves c = 0, 1), Q1
+  // groups 2, 3.  Restaging: wave c < 2 puts its X rows of slice s + 2 in Q1 of slice s, wave c >= 2 in Q0 of slice s + 1; W of slice
+  // s + 2 goes behind Q1's first barrier (by then both groups' W reads of slice s have retired).  Every DMA has one slice to land.
+  auto phase2 = [&](int s, int buf, auto q_) {
+    constexpr int Q = decltype(q_)::value;
+    if constexpr (Q == 0) load_w(buf);
+    load_x(buf, 2 * Q, 0);
+    load_x(buf, 2 * Q + 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (Q == 1) {
+      // W and the X rows of groups 0, 1 of slice s + 1 are read two barriers from here: this wave's share must have landed.  Waves
+      // c >= 2 may still have their X rows of slice s + 1 (issued in Q0 of this slice, read in Q1 of the next) in flight.
+      if (c < 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      if (c < 2) stage_x(min(s + 2, nk - 1), buf);
+    } else {
+      // (waves c >= 2) the X rows of slice s issued a slice ago are read in Q1: landed by now; W of slice s + 1 may be in flight
+      if (c >= 2) {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (s > 0) stage_x(min(s + 1, nk - 1), buf ^ 1);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    if constexpr (Q == 1) stage_w(min(s + 2, nk - 1), buf);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    mma(2 * Q);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  for (int s = 0; s < nk; ++s) {
+    const int buf = s & 1;
+    phase2(s, buf, I0{});
+    phase2(s, buf, I1{});
+  }
   }
   if (!late) __builtin_amdgcn_s_barrier();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may be in flight when the workgroup ends
@@ -1219,10 +1260,11 @@ int g_tiled_group_m = 8;   // r3 sweep (tools/debug/gm_sweep.py, M = 8192 / 16 3
 int g_tiled_stagger = 1;  // x 1024 cycles per step, 16 steps: CUs spread over ~6.5 us
 int g_tiled_force = 0;  // test hook: 1 = always the 128x128 kernel, 2 = the 256x256 kernel whenever its shape rules allow
 
-// the ping-pong schedule (fp8_gemm256pp_kernel) for one-tile-per-workgroup fp8 256 x 256 launches: 1 (default) = where K >= 8 KiB --
-// measured (tools/debug/pingpong_ab.py, profiles/round5_ab_gemm_pingpong.json): K = 8192 -2.6...-4.5 %, K = 14336 -3.5...-5.4 %, K = 28672
-// -6...-8.5 % against the one-barrier schedule at M = 2048 ... 65 536; at K = 4096 it ties the persistent form (-2 % against one tile per
-// workgroup), which keeps those launches.  0 = never, 2 = wherever the kernel applies (force_tile 5000 / 5001 / 5002)
+// the ping-pong schedule (fp8_gemm256pp_kernel) for fp8 256 x 256 launches, one tile per workgroup: 1 (default) = every such launch with
+// two phases per K slice -- measured (tools/debug/pingpong_ab.py, profiles/round5_ab_gemm_pingpong.json, M = 65 536, against round 4's
+// default = the one-barrier schedule, persistent where that won): K = 14336 -9.6 %, K = 4096 x N 6144 / 4096 / 28672 -3.1 / -3.1 / -3.3 %,
+// the SiluAndMul form -3.7 %; with four phases per slice (mode 2) -5.4 % at K = 14336 and a tie at K = 4096.  0 = round 4's choice.
+// (force_tile 5000 / 5001 / 5002 / 5003: off / default / four phases / two phases)
 int g_tiled_pingpong = 1;
 template <typename OutT, int NWV, bool DMA = true, int ES = TG_FP8, bool SILU = false, int WN = 256>
 int launch256(GemmParams& p, hipStream_t st) {
@@ -1238,13 +1280,22 @@ int launch256(GemmParams& p, hipStream_t st) {
   p.stagger_cus = tg_cus();
   p.stagger_q = (p.tiles_m * p.tiles_n >= 2 * p.stagger_cus) ? g_tiled_stagger : 0;  // needs a second round to pay off
   if constexpr (NWV == 8 && DMA && ES == TG_FP8 && WN == 256) {
-    if (p.kbytes >= 4 * BKB && (g_tiled_pingpong == 2 || (g_tiled_pingpong == 1 && p.kbytes >= 8192))) {
+    if (p.kbytes >= 4 * BKB && g_tiled_pingpong >= 1) {
       static bool pp_attr_set = false;
       if (!pp_attr_set) {
         (void)hipFuncSetAttribute((const void*)fp8_gemm256pp_kernel<OutT, SILU>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         pp_attr_set = true;
       }
-      hipLaunchKernelGGL((fp8_gemm256pp_kernel<OutT, SILU>), dim3(p.tiles_m * p.tiles_n), dim3(512), smem, st, p);
+      if (g_tiled_pingpong != 2) {   // two phases per slice (default)
+        static bool pp2_attr_set = false;
+        if (!pp2_attr_set) {
+          (void)hipFuncSetAttribute((const void*)fp8_gemm256pp_kernel<OutT, SILU, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+          pp2_attr_set = true;
+        }
+        hipLaunchKernelGGL((fp8_gemm256pp_kernel<OutT, SILU, 2>), dim3(p.tiles_m * p.tiles_n), dim3(512), smem, st, p);
+      } else {
+        hipLaunchKernelGGL((fp8_gemm256pp_kernel<OutT, SILU>), dim3(p.tiles_m * p.tiles_n), dim3(512), smem, st, p);
+      }
       SGL_HIP_LAUNCH_CHECK();
       return SGL_MI355_OK;
     }
@@ -1261,6 +1312,9 @@ int launch256p(GemmParams& p, hipStream_t st, int* sched = nullptr) {
   const int cus = tg_cus() / 8 * 8;
   const int64_t tiles = (int64_t)((p.M + T2 - 1) / T2) * ((p.N + T2 - 1) / T2);
   if (!g_tiled_dynamic) sched = nullptr;
+  if constexpr (ES == TG_FP8) {   // round 5: the ping-pong schedule (one tile per workgroup) beats the persistent one-barrier form at every shape measured
+    if (g_tiled_pingpong >= 1 && p.kbytes >= 4 * BKB) return launch256<OutT, 8, true, ES, SILU>(p, st);
+  }
   if constexpr (SILU) {
     // the SiluAndMul form measured a TIE between the static persistent schedule and one tile per workgroup (round 3); it takes the
     // persistent kernel only with the dynamic schedule, i.e. when the caller gave per-launch counters
@@ -1601,7 +1655,7 @@ extern "C" int sgl_mi355_fp8_gemm_force_tile(int mode) {
     g_tiled_persistent = mode - 3000;
     return SGL_MI355_OK;
   }
-  if (mode >= 5000) {  // measurement hook: 5001 = ping-pong schedule for one-tile-per-workgroup fp8 256 x 256 launches with K >= 8 KiB (default), 5002 = all of them, 5000 = none
+  if (mode >= 5000) {  // measurement hook: 5001 = ping-pong schedule for fp8 256 x 256 launches (default: two phases per slice), 5002 = four phases, 5003 = two, 5000 = round 4's kernels
     g_tiled_pingpong = mode - 5000;
     return SGL_MI355_OK;
   }

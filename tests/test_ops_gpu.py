@@ -632,6 +632,18 @@ def test_fp8_scaled_mm_256x128_tile_vs_oracle_and_256x256_bits(m, n, k, picked, 
     torch.testing.assert_close(outs[7].cpu().float(), ref.float(), rtol=1.6e-2, atol=0.3)
 
 
+@pytest.fixture
+def one_barrier_kernels(pkg):
+    """Round 4's fp8 256x256 kernels (one barrier per K slice; persistent where a launch has two tiles per CU) instead of round 5's
+    ping-pong schedule, for the tests that pin the persistent form's properties: sgl_mi355_fp8_gemm_force_tile(5000)."""
+    from ltp_sglang_amd import _cabi
+    _cabi.check(_cabi.lib.sgl_mi355_fp8_gemm_force_tile(5000))
+    yield
+    _cabi.lib.sgl_mi355_fp8_gemm_force_tile(5001)
+
+
+
+@pytest.mark.usefixtures("one_barrier_kernels")
 @pytest.mark.parametrize("m,n,k", [(8192, 4096, 384), (8190, 4104, 512), (8192, 4096, 640), (4100, 8192, 1024)])
 def test_fp8_scaled_mm_persistent_256_kernel_bits_equal_one_tile_per_workgroup(m, n, k, sk):
     """Launches of at least two 256x256 tiles per CU run the persistent form (csrc/tiled_gemm.hip fp8_gemm256p_kernel: one workgroup
@@ -669,8 +681,8 @@ def test_fp8_scaled_mm_persistent_256_kernel_bits_equal_one_tile_per_workgroup(m
 
 @pytest.mark.parametrize("m,n,k", [(2048, 4096, 512), (1030, 4104, 640), (4096, 2048, 8192), (777, 1000, 9216), (2048, 4096, 14336)])
 def test_fp8_scaled_mm_ping_pong_schedule_bits_equal_one_barrier_schedule(m, n, k, sk):
-    """The ping-pong schedule of the 256x256 fp8 kernel (csrc/tiled_gemm.hip fp8_gemm256pp_kernel: four phases per K slice, two barriers
-    per phase, waves 4-7 one barrier behind waves 0-3, buffers restaged region by region with counted vmcnt -- default for K >= 8 KiB)
+    """The ping-pong schedule of the 256x256 fp8 kernel (csrc/tiled_gemm.hip fp8_gemm256pp_kernel: two (default) or four phases per K
+    slice, two barriers per phase, waves 4-7 one barrier behind waves 0-3, buffers restaged region by region with counted vmcnt)
     against the one-barrier-per-slice kernel on the same tile: same k order per output and the same epilogue, so the same bits, with K
     of 4 / 5 / 64 / 72 / 112 slices, ragged M and N, both output types and the SiluAndMul epilogue; and the oracle's tolerance.  Run
     five times over: a race between a restaged region and its readers would show as a rare wrong tile."""
@@ -680,14 +692,14 @@ def test_fp8_scaled_mm_ping_pong_schedule_bits_equal_one_barrier_schedule(m, n, 
         c = _cases.build_gemm_case(dict(m=m, n=n, k=k, bias=True, out=out), seed=m + n + k)
         a, wt, sa, sb, bias = (c[x].to(DEV) for x in ("a", "w", "sa", "sb", "bias"))
         outs = {}
-        for name, modes in (("one_barrier", (2, 3000, 5000)), ("ping_pong", (2, 3000, 5002))):
+        for name, modes in (("one_barrier", (2, 3000, 5000)), ("ping_pong_4", (2, 3000, 5002)), ("ping_pong", (2, 3000, 5003))):
             for md in modes:
                 _cabi.check(ft(md))
             try:
-                outs[name] = [sk.fp8_scaled_mm(a, wt.t(), sa, sb, c["out_dtype"], bias) for _ in range(5 if name == "ping_pong" else 1)]
+                outs[name] = [sk.fp8_scaled_mm(a, wt.t(), sa, sb, c["out_dtype"], bias) for _ in range(1 if name == "one_barrier" else 5)]
             finally:
                 ft(0); ft(3001); ft(5001)
-        for o in outs["ping_pong"]:
+        for o in outs["ping_pong"] + outs["ping_pong_4"]:
             assert torch.equal(outs["one_barrier"][0], o)
         if out == "bf16":
             ref = oq.scaled_mm(c["a"], c["w"].t(), c["sa"], c["sb"], c["out_dtype"], c["bias"])
@@ -700,16 +712,17 @@ def test_fp8_scaled_mm_ping_pong_schedule_bits_equal_one_barrier_schedule(m, n, 
         x = (torch.randn(m, k, generator=g)).to(torch.float8_e4m3fn).to(DEV)
         sx = torch.rand(m, generator=g).to(DEV) * 0.1
         outs = {}
-        for name, modes in (("one_barrier", (3000, 5000)), ("ping_pong", (3000, 5002))):
+        for name, modes in (("one_barrier", (3000, 5000)), ("ping_pong_4", (3000, 5002)), ("ping_pong", (3000, 5003))):
             for md in modes:
                 _cabi.check(ft(md))
             try:
                 outs[name] = sk.fp8_gemm_silu_mul(x, sx, wi, sw, torch.bfloat16, 16)
             finally:
                 ft(3001); ft(5001)
-        assert torch.equal(outs["one_barrier"], outs["ping_pong"])
+        assert torch.equal(outs["one_barrier"], outs["ping_pong"]) and torch.equal(outs["one_barrier"], outs["ping_pong_4"])
 
 
+@pytest.mark.usefixtures("one_barrier_kernels")
 @pytest.mark.parametrize("m,n,k", [(8192, 4096, 512), (4100, 8200, 384), (4352, 7936, 9216)])
 def test_persistent_256_kernel_dynamic_tile_schedule_same_bits(m, n, k, sk):
     """Round 4: the persistent kernel draws its tiles after the first from per-XCD ticket counters (one of the 64 eight-word slots in the last 512
@@ -748,6 +761,7 @@ def test_persistent_256_kernel_dynamic_tile_schedule_same_bits(m, n, k, sk):
     torch.testing.assert_close(outs[4002][0].cpu().float(), ref.float(), rtol=1.6e-2, atol=0.3)
 
 
+@pytest.mark.usefixtures("one_barrier_kernels")
 def test_persistent_gemm_ticket_slots_on_two_streams(sk):
     """The ticket words of the dynamic tile schedule are one of 64 slots taken round robin (workspace tail for fp8_scaled_mm /
     dense_linear, the wrapper's own ring for fp8_gemm_silu_mul): persistent GEMMs launched alternately on TWO streams, with nothing
@@ -775,6 +789,7 @@ def test_persistent_gemm_ticket_slots_on_two_streams(sk):
     assert all(torch.equal(o, ref1) for o in outs1) and all(torch.equal(o, ref2) for o in outs2)
 
 
+@pytest.mark.usefixtures("one_barrier_kernels")
 @pytest.mark.parametrize("m,n,k", [(8192, 8192, 512), (4100, 8704, 384)])
 def test_gemm_silu_mul_ws_dynamic_schedule_same_bits(m, n, k, sk):
     """sgl_mi355_gemm_silu_mul_ws (round 4): gate_up + SiluAndMul on the persistent kernel with the dynamic tile schedule when the
