@@ -705,7 +705,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void fp8_gemm256_kernel(const GemmPara
 // Buffers: two slices of [W 32 KiB | X 32 KiB], restaged REGION BY REGION as soon as a region's last reader is through -- W of slice
 // s + 2 in phase 2 of slice s, wave c's 32 X rows (read by its group in phase c) in the phase after -- so every DMA has 1.5-1.75
 // slices to land, as in the one-barrier kernel.  vmcnt: counted, once per slice (phase 3), never 0 in the loop.
-template <typename OutT, bool SILU = false, int PH = 4>   // PH: phases per K slice (4 blocks of 8 MFMAs, or 2 of 16)
+template <typename OutT, bool SILU = false, int PH = 2>   // PH: phases per K slice (2 blocks of 16 MFMAs -- the default -- or 4 of 8)
 __global__ __launch_bounds__(512, 1) void fp8_gemm256pp_kernel(const GemmParams p) {
   constexpr int NWV = 8, WN = 256, WCOLS = 4, JN = 4, MR = 128, NI = 8, IG = 2;
   constexpr int RPW = 32, WRPW = 32;          // staging rows per wave and operand
@@ -876,6 +876,8 @@ __global__ __launch_bounds__(512, 1) void fp8_gemm256pp_kernel(const GemmParams 
     if constexpr (Q == 1) stage_w(min(s + 2, nk - 1), buf);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+    // (measured and dropped: the closing barrier in FRONT of the block's last 4 / 8 MFMAs, so that the hand-over of the pipe overlaps
+    // them -- every hazard-relevant operation lies before the block, so it is legal: +3.6 / +9.5 % slower.  The exclusivity is the point.)
     mma(2 * Q);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -1281,21 +1283,18 @@ int launch256(GemmParams& p, hipStream_t st) {
   p.stagger_q = (p.tiles_m * p.tiles_n >= 2 * p.stagger_cus) ? g_tiled_stagger : 0;  // needs a second round to pay off
   if constexpr (NWV == 8 && DMA && ES == TG_FP8 && WN == 256) {
     if (p.kbytes >= 4 * BKB && g_tiled_pingpong >= 1) {
-      static bool pp_attr_set = false;
-      if (!pp_attr_set) {
-        (void)hipFuncSetAttribute((const void*)fp8_gemm256pp_kernel<OutT, SILU>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        pp_attr_set = true;
-      }
-      if (g_tiled_pingpong != 2) {   // two phases per slice (default)
-        static bool pp2_attr_set = false;
-        if (!pp2_attr_set) {
-          (void)hipFuncSetAttribute((const void*)fp8_gemm256pp_kernel<OutT, SILU, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-          pp2_attr_set = true;
-        }
-        hipLaunchKernelGGL((fp8_gemm256pp_kernel<OutT, SILU, 2>), dim3(p.tiles_m * p.tiles_n), dim3(512), smem, st, p);
-      } else {
-        hipLaunchKernelGGL((fp8_gemm256pp_kernel<OutT, SILU>), dim3(p.tiles_m * p.tiles_n), dim3(512), smem, st, p);
-      }
+#define SGL_PP_LAUNCH(PHV)                                                                                                             \
+  do {                                                                                                                                \
+    static bool set_ = false;                                                                                                         \
+    if (!set_) {                                                                                                                      \
+      (void)hipFuncSetAttribute((const void*)fp8_gemm256pp_kernel<OutT, SILU, PHV>, hipFuncAttributeMaxDynamicSharedMemorySize, smem); \
+      set_ = true;                                                                                                                    \
+    }                                                                                                                                 \
+    hipLaunchKernelGGL((fp8_gemm256pp_kernel<OutT, SILU, PHV>), dim3(p.tiles_m * p.tiles_n), dim3(512), smem, st, p);                  \
+  } while (0)
+      if (g_tiled_pingpong == 2) SGL_PP_LAUNCH(4);   // measurement hook: four phases per slice
+      else SGL_PP_LAUNCH(2);
+#undef SGL_PP_LAUNCH
       SGL_HIP_LAUNCH_CHECK();
       return SGL_MI355_OK;
     }
@@ -1312,8 +1311,12 @@ int launch256p(GemmParams& p, hipStream_t st, int* sched = nullptr) {
   const int cus = tg_cus() / 8 * 8;
   const int64_t tiles = (int64_t)((p.M + T2 - 1) / T2) * ((p.N + T2 - 1) / T2);
   if (!g_tiled_dynamic) sched = nullptr;
-  if constexpr (ES == TG_FP8) {   // round 5: the ping-pong schedule (one tile per workgroup) beats the persistent one-barrier form at every shape measured
-    if (g_tiled_pingpong >= 1 && p.kbytes >= 4 * BKB) return launch256<OutT, 8, true, ES, SILU>(p, st);
+  if constexpr (ES == TG_FP8) {   // round 5: the ping-pong schedule, one tile per workgroup, beats the one-barrier forms at every shape measured.
+    // (A persistent form of it -- the slice stream running on across tiles, the epilogue through the last slice's buffer -- was built,
+    // bit-identical, and measured -1.8 ... +2.6 % against this at M = 65 536: profiles/round5_ab_gemm_pingpong_persistent.log.  Removed.)
+    if (g_tiled_pingpong >= 1 && p.kbytes >= 4 * BKB) {
+      return launch256<OutT, 8, true, ES, SILU>(p, st);
+    }
   }
   if constexpr (SILU) {
     // the SiluAndMul form measured a TIE between the static persistent schedule and one tile per workgroup (round 3); it takes the
