@@ -705,7 +705,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void fp8_gemm256_kernel(const GemmPara
 // Buffers: two slices of [W 32 KiB | X 32 KiB], restaged REGION BY REGION as soon as a region's last reader is through -- W of slice
 // s + 2 in phase 2 of slice s, wave c's 32 X rows (read by its group in phase c) in the phase after -- so every DMA has 1.5-1.75
 // slices to land, as in the one-barrier kernel.  vmcnt: counted, once per slice (phase 3), never 0 in the loop.
-template <typename OutT, bool SILU = false, int PH = 2>   // PH: phases per K slice (2 blocks of 16 MFMAs -- the default -- or 4 of 8)
+template <typename OutT, bool SILU = false, int PH = 2, int ES = TG_FP8>   // PH: phases per K slice (2 blocks of 16 MFMAs -- the default -- or 4 of 8); ES as fp8_gemm256_kernel
 __global__ __launch_bounds__(512, 1) void fp8_gemm256pp_kernel(const GemmParams p) {
   constexpr int NWV = 8, WN = 256, WCOLS = 4, JN = 4, MR = 128, NI = 8, IG = 2;
   constexpr int RPW = 32, WRPW = 32;          // staging rows per wave and operand
@@ -790,7 +790,14 @@ __global__ __launch_bounds__(512, 1) void fp8_gemm256pp_kernel(const GemmParams 
 #pragma unroll
     for (int i = 0; i < XG * IG; ++i)
 #pragma unroll
-      for (int j = 0; j < JN; ++j) mfma_mx(wf[j][0], wf[j][1], xf[i][0], xf[i][1], acc[j][IG * grp0 + i]);
+      for (int j = 0; j < JN; ++j) {
+        if constexpr (ES == TG_FP8) {
+          mfma_mx(wf[j][0], wf[j][1], xf[i][0], xf[i][1], acc[j][IG * grp0 + i]);
+        } else {   // 16-bit operands: two 16x16x32 k-steps per slice, in the one-barrier kernel's order
+          mfma_chunk<ES>(wf[j][0], xf[i][0], acc[j][IG * grp0 + i]);
+          mfma_chunk<ES>(wf[j][1], xf[i][1], acc[j][IG * grp0 + i]);
+        }
+      }
     __builtin_amdgcn_s_setprio(0);
 #pragma unroll
     for (int i = 0; i < XG * IG; ++i)
@@ -1281,16 +1288,16 @@ int launch256(GemmParams& p, hipStream_t st) {
   p.group_m = g_tiled_group_m;
   p.stagger_cus = tg_cus();
   p.stagger_q = (p.tiles_m * p.tiles_n >= 2 * p.stagger_cus) ? g_tiled_stagger : 0;  // needs a second round to pay off
-  if constexpr (NWV == 8 && DMA && ES == TG_FP8 && WN == 256) {
+  if constexpr (NWV == 8 && DMA && WN == 256) {
     if (p.kbytes >= 4 * BKB && g_tiled_pingpong >= 1) {
 #define SGL_PP_LAUNCH(PHV)                                                                                                             \
   do {                                                                                                                                \
     static bool set_ = false;                                                                                                         \
     if (!set_) {                                                                                                                      \
-      (void)hipFuncSetAttribute((const void*)fp8_gemm256pp_kernel<OutT, SILU, PHV>, hipFuncAttributeMaxDynamicSharedMemorySize, smem); \
+      (void)hipFuncSetAttribute((const void*)fp8_gemm256pp_kernel<OutT, SILU, PHV, ES>, hipFuncAttributeMaxDynamicSharedMemorySize, smem); \
       set_ = true;                                                                                                                    \
     }                                                                                                                                 \
-    hipLaunchKernelGGL((fp8_gemm256pp_kernel<OutT, SILU, PHV>), dim3(p.tiles_m * p.tiles_n), dim3(512), smem, st, p);                  \
+    hipLaunchKernelGGL((fp8_gemm256pp_kernel<OutT, SILU, PHV, ES>), dim3(p.tiles_m * p.tiles_n), dim3(512), smem, st, p);                  \
   } while (0)
       if (g_tiled_pingpong == 2) SGL_PP_LAUNCH(4);   // measurement hook: four phases per slice
       else SGL_PP_LAUNCH(2);
@@ -1311,7 +1318,7 @@ int launch256p(GemmParams& p, hipStream_t st, int* sched = nullptr) {
   const int cus = tg_cus() / 8 * 8;
   const int64_t tiles = (int64_t)((p.M + T2 - 1) / T2) * ((p.N + T2 - 1) / T2);
   if (!g_tiled_dynamic) sched = nullptr;
-  if constexpr (ES == TG_FP8) {   // round 5: the ping-pong schedule, one tile per workgroup, beats the one-barrier forms at every shape measured.
+  {   // round 5: the ping-pong schedule, one tile per workgroup, beats the one-barrier forms at every shape measured (fp8 and 16-bit operands).
     // (A persistent form of it -- the slice stream running on across tiles, the epilogue through the last slice's buffer -- was built,
     // bit-identical, and measured -1.8 ... +2.6 % against this at M = 65 536: profiles/round5_ab_gemm_pingpong_persistent.log.  Removed.)
     if (g_tiled_pingpong >= 1 && p.kbytes >= 4 * BKB) {

@@ -720,6 +720,21 @@ def test_fp8_scaled_mm_ping_pong_schedule_bits_equal_one_barrier_schedule(m, n, 
             finally:
                 ft(3001); ft(5001)
         assert torch.equal(outs["one_barrier"], outs["ping_pong"]) and torch.equal(outs["one_barrier"], outs["ping_pong_4"])
+    # 16-bit operands through the same kernel (two 16x16x32 k-steps per slice)
+    g = torch.Generator().manual_seed(23)
+    for dt in (torch.bfloat16, torch.float16):
+        x = torch.randn(m, k // 2, generator=g).to(dt).to(DEV)
+        w = (torch.randn(n, k // 2, generator=g) * 0.05).to(dt).to(DEV)
+        outs = {}
+        for name, modes in (("one_barrier", (3000, 5000)), ("ping_pong_4", (3000, 5002)), ("ping_pong", (3000, 5003))):
+            for md in modes:
+                _cabi.check(ft(md))
+            try:
+                outs[name] = sk.dense_linear(x, w)
+            finally:
+                ft(3001); ft(5001)
+        assert torch.equal(outs["one_barrier"], outs["ping_pong"]) and torch.equal(outs["one_barrier"], outs["ping_pong_4"])
+        torch.testing.assert_close(outs["ping_pong"].float().cpu(), (x.float() @ w.float().t()).cpu(), rtol=2e-2, atol=2e-2 * (k / 2) ** 0.5 * 0.05)
 
 
 @pytest.mark.usefixtures("one_barrier_kernels")

@@ -53,3 +53,18 @@ for rep in range(3):
 same = "bits equal" if all(torch.equal(outs["round-4 default"], o) for o in outs.values()) else "BITS DIFFER"
 tf = 2.0 * M * n * k / 1e6
 print(f"silu_mul M={M} N={n} K={k}: " + " | ".join(f"{v} {min(res[v]):8.1f} us ({tf / min(res[v]):5.0f} TF)" for v, _ in VARIANTS) + f"  {same}", flush=True)
+# 16-bit operands (the unquantised linears of config 2): dense_linear, the same kernels with two 16x16x32 k-steps per slice
+for n, k in [(6144, 4096), (4096, 4096), (28672, 4096), (4096, 14336)]:
+    for dt in (torch.bfloat16,):
+        xs = torch.randn(M, k, device=DEV).to(dt)
+        wd = (torch.randn(n, k, device=DEV) * 0.05).to(dt)
+        res, outs = {v: [] for v, _ in VARIANTS}, {}
+        for rep in range(2):
+            for v, modes in VARIANTS:
+                if rep == 0:
+                    outs[v] = with_modes(modes, lambda: K.dense_linear(xs, wd))
+                res[v].append(with_modes(modes, lambda: timed([lambda: K.dense_linear(xs, wd)])))
+        same = "bits equal" if all(torch.equal(outs["round-4 default"], o) for o in outs.values()) else "BITS DIFFER"
+        tf = 2.0 * M * n * k / 1e6
+        print(f"dense bf16 M={M} N={n:6d} K={k:6d}: " + " | ".join(f"{v} {min(res[v]):8.1f} us ({tf / min(res[v]):5.0f} TF)" for v, _ in VARIANTS) + f"  {same}", flush=True)
+        del xs, wd, outs
