@@ -14,7 +14,7 @@ import os
 import sys
 from collections import defaultdict
 
-KEYS = ("fp8_gemm256_kernel", "fp8_gemm256p_kernel", "tiled_gemm_kernel", "extend_attn_kernel", "extend_attn_dma_kernel", "extend_attn_phased_kernel", "decode_attn_stage1", "skinny_gemm_v2_kernel",
+KEYS = ("fp8_gemm256pp_kernel", "fp8_gemm256_kernel", "fp8_gemm256p_kernel", "tiled_gemm_kernel", "extend_attn_kernel", "extend_attn_dma_kernel", "extend_attn_phased_kernel", "decode_attn_stage1", "skinny_gemm_v2_kernel",
         "awq_gemm_kernel")
 
 

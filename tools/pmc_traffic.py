@@ -44,7 +44,7 @@ def load(dirname, counter):
 def short(name):
     if name.startswith("skinny_gemm_v2_kernel<"):
         return name
-    for key in ("decode_attn_stage1", "decode_attn_stage2", "decode_merge_quant", "extend_attn_kernel", "extend_attn_dma_kernel", "extend_attn_phased_kernel", "fp8_gemm256_kernel", "fp8_gemm256p_kernel", "fp8_gemm128s_kernel", "tiled_gemm", "per_token_quant", "rope_set_kv",
+    for key in ("decode_attn_stage1", "decode_attn_stage2", "decode_merge_quant", "extend_attn_kernel", "extend_attn_dma_kernel", "extend_attn_phased_kernel", "fp8_gemm256pp_kernel", "fp8_gemm256_kernel", "fp8_gemm256p_kernel", "fp8_gemm128s_kernel", "tiled_gemm", "per_token_quant", "rope_set_kv",
                 "add_rmsnorm_quant", "silu_mul_quant"):
         if key in name:
             return key
