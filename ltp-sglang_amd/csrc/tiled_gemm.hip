@@ -705,7 +705,8 @@ __global__ __launch_bounds__(NWV * 64, 1) void fp8_gemm256_kernel(const GemmPara
 // Buffers: two slices of [W 32 KiB | X 32 KiB], restaged REGION BY REGION as soon as a region's last reader is through -- W of slice
 // s + 2 in phase 2 of slice s, wave c's 32 X rows (read by its group in phase c) in the phase after -- so every DMA has 1.5-1.75
 // slices to land, as in the one-barrier kernel.  vmcnt: counted, once per slice (phase 3), never 0 in the loop.
-template <typename OutT, bool SILU = false, int PH = 2, int ES = TG_FP8>   // PH: phases per K slice (2 blocks of 16 MFMAs -- the default -- or 4 of 8); ES as fp8_gemm256_kernel
+template <typename OutT, bool SILU = false, int PH = 2, int ES = TG_FP8, int WLATE = 0>   // PH: phases per K slice (2 blocks of 16 MFMAs -- the default -- or 4 of 8); ES as
+                                                                                          // fp8_gemm256_kernel; WLATE: X fragments of the second block issued in front of the W staging
 __global__ __launch_bounds__(512, 1) void fp8_gemm256pp_kernel(const GemmParams p) {
   constexpr int NWV = 8, WN = 256, WCOLS = 4, JN = 4, MR = 128, NI = 8, IG = 2;
   constexpr int RPW = 32, WRPW = 32;          // staging rows per wave and operand
@@ -781,28 +782,34 @@ __global__ __launch_bounds__(512, 1) void fp8_gemm256pp_kernel(const GemmParams 
   // (the MFMA builtin touches no memory and hipcc moves such calls across raw s_barriers -- it gathered the four blocks of a slice behind
   // the last barrier: the phase's X fragments are made opaque in front of the block and its accumulators behind it, which ties the
   // block to the volatile statements, i.e. to the two barriers, around it)
-  auto mma = [&](int grp0) {   // the phase's XG groups: grp0 .. grp0 + XG - 1
+  auto mma = [&](int grp0, int i0 = 0, int i1 = 4) {   // the phase's XG groups grp0 .. grp0 + XG - 1: X fragments i0 .. i1 - 1 of them (at most XG IG <= 4)
 #pragma unroll
     for (int i = 0; i < XG * IG; ++i)
+      if (i >= i0 && i < i1) {
 #pragma unroll
-      for (int h = 0; h < 2; ++h) asm volatile("" : "+v"(xf[i][h]));
+        for (int h = 0; h < 2; ++h) asm volatile("" : "+v"(xf[i][h]));
+      }
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int i = 0; i < XG * IG; ++i)
+      if (i >= i0 && i < i1) {
 #pragma unroll
-      for (int j = 0; j < JN; ++j) {
-        if constexpr (ES == TG_FP8) {
-          mfma_mx(wf[j][0], wf[j][1], xf[i][0], xf[i][1], acc[j][IG * grp0 + i]);
-        } else {   // 16-bit operands: two 16x16x32 k-steps per slice, in the one-barrier kernel's order
-          mfma_chunk<ES>(wf[j][0], xf[i][0], acc[j][IG * grp0 + i]);
-          mfma_chunk<ES>(wf[j][1], xf[i][1], acc[j][IG * grp0 + i]);
+        for (int j = 0; j < JN; ++j) {
+          if constexpr (ES == TG_FP8) {
+            mfma_mx(wf[j][0], wf[j][1], xf[i][0], xf[i][1], acc[j][IG * grp0 + i]);
+          } else {   // 16-bit operands: two 16x16x32 k-steps per slice, in the one-barrier kernel's order
+            mfma_chunk<ES>(wf[j][0], xf[i][0], acc[j][IG * grp0 + i]);
+            mfma_chunk<ES>(wf[j][1], xf[i][1], acc[j][IG * grp0 + i]);
+          }
         }
       }
     __builtin_amdgcn_s_setprio(0);
 #pragma unroll
     for (int i = 0; i < XG * IG; ++i)
+      if (i >= i0 && i < i1) {
 #pragma unroll
-      for (int j = 0; j < JN; ++j) asm volatile("" : "+v"(acc[j][IG * grp0 + i]));
+        for (int j = 0; j < JN; ++j) asm volatile("" : "+v"(acc[j][IG * grp0 + i]));
+      }
   };
 
   stage_w(0, 0);
@@ -880,12 +887,22 @@ __global__ __launch_bounds__(512, 1) void fp8_gemm256pp_kernel(const GemmParams 
     }
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
-    if constexpr (Q == 1) stage_w(min(s + 2, nk - 1), buf);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (Q == 1 && WLATE > 0) {
+      // W of slice s + 2: behind this barrier (both groups' W reads of slice s have retired) and BEHIND the block's first MFMAs -- in
+      // front of them the four DMA issues hold the matrix pipe idle once per slice
+      mma(2 * Q, 0, WLATE);
+      __builtin_amdgcn_sched_barrier(0);
+      stage_w(min(s + 2, nk - 1), buf);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(2 * Q, WLATE, XG * IG);
+    } else {
+      if constexpr (Q == 1) stage_w(min(s + 2, nk - 1), buf);
     // (measured and dropped: the closing barrier in FRONT of the block's last 4 / 8 MFMAs, so that the hand-over of the pipe overlaps
     // them -- every hazard-relevant operation lies before the block, so it is legal: +3.6 / +9.5 % slower.  The exclusivity is the point.)
-    mma(2 * Q);
+      mma(2 * Q);
+    }
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -1273,7 +1290,7 @@ int g_tiled_force = 0;  // test hook: 1 = always the 128x128 kernel, 2 = the 256
 // two phases per K slice -- measured (tools/debug/pingpong_ab.py, profiles/round5_ab_gemm_pingpong.json, M = 65 536, against round 4's
 // default = the one-barrier schedule, persistent where that won): K = 14336 -9.6 %, K = 4096 x N 6144 / 4096 / 28672 -3.1 / -3.1 / -3.3 %,
 // the SiluAndMul form -3.7 %; with four phases per slice (mode 2) -5.4 % at K = 14336 and a tie at K = 4096.  0 = round 4's choice.
-// (force_tile 5000 / 5001 / 5002 / 5003: off / default / four phases / two phases)
+// (force_tile 5000 / 5001 / 5002 / 5003: off / default / four phases / two phases with the W staging in front of the second block)
 int g_tiled_pingpong = 1;
 template <typename OutT, int NWV, bool DMA = true, int ES = TG_FP8, bool SILU = false, int WN = 256>
 int launch256(GemmParams& p, hipStream_t st) {
@@ -1290,17 +1307,18 @@ int launch256(GemmParams& p, hipStream_t st) {
   p.stagger_q = (p.tiles_m * p.tiles_n >= 2 * p.stagger_cus) ? g_tiled_stagger : 0;  // needs a second round to pay off
   if constexpr (NWV == 8 && DMA && WN == 256) {
     if (p.kbytes >= 4 * BKB && g_tiled_pingpong >= 1) {
-#define SGL_PP_LAUNCH(PHV)                                                                                                             \
+#define SGL_PP_LAUNCH(PHV, WL)                                                                                                         \
   do {                                                                                                                                \
     static bool set_ = false;                                                                                                         \
     if (!set_) {                                                                                                                      \
-      (void)hipFuncSetAttribute((const void*)fp8_gemm256pp_kernel<OutT, SILU, PHV, ES>, hipFuncAttributeMaxDynamicSharedMemorySize, smem); \
+      (void)hipFuncSetAttribute((const void*)fp8_gemm256pp_kernel<OutT, SILU, PHV, ES, WL>, hipFuncAttributeMaxDynamicSharedMemorySize, smem); \
       set_ = true;                                                                                                                    \
     }                                                                                                                                 \
-    hipLaunchKernelGGL((fp8_gemm256pp_kernel<OutT, SILU, PHV, ES>), dim3(p.tiles_m * p.tiles_n), dim3(512), smem, st, p);                  \
+    hipLaunchKernelGGL((fp8_gemm256pp_kernel<OutT, SILU, PHV, ES, WL>), dim3(p.tiles_m * p.tiles_n), dim3(512), smem, st, p);          \
   } while (0)
-      if (g_tiled_pingpong == 2) SGL_PP_LAUNCH(4);   // measurement hook: four phases per slice
-      else SGL_PP_LAUNCH(2);
+      if (g_tiled_pingpong == 2) SGL_PP_LAUNCH(4, 0);        // measurement hooks: four phases per slice;
+      else if (g_tiled_pingpong == 3) SGL_PP_LAUNCH(2, 0);   // two, W staged in front of the second block (-0.3 ... -0.9 % behind its first four MFMAs)
+      else SGL_PP_LAUNCH(2, 1);
 #undef SGL_PP_LAUNCH
       SGL_HIP_LAUNCH_CHECK();
       return SGL_MI355_OK;

@@ -15,7 +15,7 @@ SHAPES = [(4096, 14336), (6144, 4096), (4096, 4096), (28672, 4096)]
 if len(sys.argv) > 2:   # "N:K,N:K,..."
     SHAPES = [tuple(int(v) for v in t.split(":")) for t in sys.argv[2].split(",")]
 ft = _cabi.lib.sgl_mi355_fp8_gemm_force_tile
-VARIANTS = [("round-4 default", (3001, 5000)), ("one tile/wg", (3000, 5000)), ("ping-pong 4-phase", (3000, 5002)), ("ping-pong 2-phase", (3000, 5003))]
+VARIANTS = [("round-4 default", (3001, 5000)), ("one tile/wg", (3000, 5000)), ("ping-pong 4-phase", (3000, 5002)), ("ping-pong 2-phase (default)", (3000, 5001))]
 def with_modes(modes, fn):
     for m in modes: _cabi.check(ft(m))
     try:
