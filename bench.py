@@ -44,6 +44,7 @@ def parse_args():
                     help="auto = the model dtype (the BASELINE configuration); fp8_e4m3 halves the KV stream (reported separately)")
     ap.add_argument("--no-graph-metadata", action="store_true", help="measurement hook: keep the decode metadata launches outside the captured graph")
     ap.add_argument("--decode-attn-mode", type=int, default=-1, help="measurement hook: 0 / 1 = sgl_mi355_decode_attention_set_mode")
+    ap.add_argument("--extend-attn-mode", type=int, default=-1, help="measurement hook: sgl_mi355_extend_attention_set_mode (0 / 2 / 3 = the older kernels, 5 = force the 32x32x16 kernel)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the measured configuration); gloo = rehearsal of the N > 1 path on fewer GPUs")
     ap.add_argument("--no-graph", action="store_true")
@@ -429,6 +430,10 @@ def main():
         from ltp_sglang_amd import _cabi
 
         _cabi.check(_cabi.lib.sgl_mi355_decode_attention_set_mode(args.decode_attn_mode))
+    if args.extend_attn_mode >= 0:
+        from ltp_sglang_amd import _cabi
+
+        _cabi.check(_cabi.lib.sgl_mi355_extend_attention_set_mode(args.extend_attn_mode))
     quant = None if args.quant == "none" else args.quant
     bs, seq = args.batch, args.seq_len
     total_steps = args.steps + args.warmup + 4

@@ -1339,7 +1339,9 @@ int launch256p(GemmParams& p, hipStream_t st, int* sched = nullptr) {
   {   // round 5: the ping-pong schedule, one tile per workgroup, beats the one-barrier forms at every shape measured (fp8 and 16-bit operands).
     // (A persistent form of it -- the slice stream running on across tiles, the epilogue through the last slice's buffer -- was built,
     // bit-identical, and measured -1.8 ... +2.6 % against this at M = 65 536: profiles/round5_ab_gemm_pingpong_persistent.log.  Removed.)
-    if (g_tiled_pingpong >= 1 && p.kbytes >= 4 * BKB) {
+    // Very short K keeps the persistent one-barrier kernel where that applies (TP-8 shard shapes at M = 65 536: K = 512 183 vs 215 us,
+    // K = 1792 426 vs 435 us: there the tile boundary is most of a tile and hiding the prologue is worth more than the schedule).
+    if (p.kbytes >= 4 * BKB && (g_tiled_pingpong >= 2 || (g_tiled_pingpong == 1 && p.kbytes >= 2048))) {
       return launch256<OutT, 8, true, ES, SILU>(p, st);
     }
   }

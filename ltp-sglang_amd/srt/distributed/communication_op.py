@@ -113,8 +113,11 @@ def tensor_model_parallel_all_gather(input_: torch.Tensor, dim: int = -1) -> tor
     if _EMULATED:
         shape = list(input_.shape)
         shape[dim] *= _TP_SIZE
-        out = torch.empty(shape, dtype=input_.dtype, device=input_.device)
-        out.narrow(dim, 0, input_.shape[dim]).copy_(input_)   # the bytes one rank contributes; the peers' slices stay unwritten
+        # the bytes one rank contributes; the peers' slices are ZEROS (a same-size device write, as the gather is): left unwritten
+        # (round 4) they were whatever the allocator handed back, and bench.py's finite-logits check failed on that garbage -- 8B
+        # --emulate-tp 8 -- while every kernel was right
+        out = torch.zeros(shape, dtype=input_.dtype, device=input_.device)
+        out.narrow(dim, 0, input_.shape[dim]).copy_(input_)
         return out
     if _CUSTOM_AR is not None and dim == input_.dim() - 1 and _CUSTOM_AR.should_use_gather(input_):
         return _CUSTOM_AR.all_gather_last_dim(input_)
