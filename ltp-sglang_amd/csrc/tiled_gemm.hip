@@ -875,13 +875,17 @@ __global__ __launch_bounds__(512, 1) void fp8_gemm256pp_kernel(const GemmParams 
     if constexpr (Q == 1) {
       // W and the X rows of groups 0, 1 of slice s + 1 are read two barriers from here: this wave's share must have landed.  Waves
       // c >= 2 may still have their X rows of slice s + 1 (issued in Q0 of this slice, read in Q1 of the next) in flight.
+#ifndef SGL_PP_NOWAIT   // timing-only build (wrong results): how much of the loop is the counted wait
       if (c < 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+#endif
       if (c < 2) stage_x(min(s + 2, nk - 1), buf);
     } else {
       // (waves c >= 2) the X rows of slice s issued a slice ago are read in Q1: landed by now; W of slice s + 1 may be in flight
       if (c >= 2) {
+#ifndef SGL_PP_NOWAIT
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+#endif
         if (s > 0) stage_x(min(s + 1, nk - 1), buf ^ 1);
       }
     }
