@@ -44,6 +44,7 @@ def parse_args():
                     help="auto = the model dtype (the BASELINE configuration); fp8_e4m3 halves the KV stream (reported separately)")
     ap.add_argument("--no-graph-metadata", action="store_true", help="measurement hook: keep the decode metadata launches outside the captured graph")
     ap.add_argument("--decode-attn-mode", type=int, default=-1, help="measurement hook: 0 / 1 = sgl_mi355_decode_attention_set_mode")
+    ap.add_argument("--no-pad-qkv", action="store_true", help="measurement hook: the prefill's qkv output rows at their natural stride")
     ap.add_argument("--extend-attn-mode", type=int, default=-1, help="measurement hook: sgl_mi355_extend_attention_set_mode (0 / 2 / 3 = the older kernels, 5 = force the 32x32x16 kernel)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the measured configuration); gloo = rehearsal of the N > 1 path on fewer GPUs")
@@ -450,6 +451,8 @@ def main():
                                   kv_cache_dtype=torch.float8_e4m3fn if args.kv_cache_dtype == "fp8_e4m3" else None,
                                   max_kv_splits=args.max_kv_splits, kv_split_rule=args.kv_split_rule,
                                   kv_sched_rounds_pct=args.kv_sched_rounds_pct)
+    if args.no_pad_qkv:
+        runner.model.pad_qkv_rows = False
     if args.no_fused_decode:
         runner.model.fused_decode = False
     if args.no_graph_metadata:

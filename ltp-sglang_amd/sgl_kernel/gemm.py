@@ -133,8 +133,11 @@ def awq_gemm_num_kranges(m: int, k: int) -> int:
     return int(lib.sgl_mi355_awq_gemm_num_kranges(int(m), int(k)))
 
 
-def fp8_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype, bias=None):
+def fp8_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype, bias=None, out=None):
     """out[M,N] = (mat_a[M,K] @ mat_b[K,N]) * scales_a[m] * scales_b[n] (+ bias[n]).
+
+    ``out`` (not in the reference's signature): an [M, N] tensor of ``out_dtype`` to write into; its rows may be padded (row stride
+    >= N, a multiple of 8 elements) -- the prefill path hands in a qkv buffer whose row stride is not a multiple of 4 KiB.
 
     Argument checks and messages follow fp8_scaled_mm in
     sgl-kernel/csrc/gemm/fp8_gemm_kernel.cu:1078-1108.
@@ -184,7 +187,11 @@ def fp8_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype, bias=None):
             raise RuntimeError("bias dtype must match output dtype")
     m, k = mat_a.shape
     n = mat_b.size(1)
-    out = torch.empty((m, n), dtype=out_dtype, device=mat_a.device)
+    if out is None:
+        out = torch.empty((m, n), dtype=out_dtype, device=mat_a.device)
+    elif (out.shape != (m, n) or out.dtype != out_dtype or out.device != mat_a.device or out.stride(1) != 1 or out.stride(0) < n
+          or (out.stride(0) * out.element_size()) % 16 != 0 or out.data_ptr() % 16 != 0):
+        raise RuntimeError("out must be an [M, N] tensor of out_dtype with contiguous, 16-byte aligned rows")
     if (out.size(1) * out.element_size()) % 16 != 0:
         raise RuntimeError("out must be multiple of 16 bytes for memory alignment")
     w_stride = mat_b.stride(1)  # W[n, :] = mat_b[:, n]

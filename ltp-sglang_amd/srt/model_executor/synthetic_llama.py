@@ -157,6 +157,7 @@ class LlamaForCausalLM(nn.Module):
         self.cfg, self.dtype = cfg, dtype
         self.fused_decode = True
         self.fused_extend = True
+        self.pad_qkv_rows = True   # forward_extend_fused: qkv output rows padded by 256 bytes (measurement hook: False)
         self.fused_attn_merge = True   # decode: stage-2 merge + quant by the last-arriving workgroup of each request
         self.fused_epilogues = True
         # decode, M <= 32: post-attention norm -> gate_up + SiluAndMul -> quant -> down_proj as ONE persistent launch
@@ -540,6 +541,7 @@ class LlamaForCausalLM(nn.Module):
         backend = forward_batch.attn_backend
         hidden = K.embedding(input_ids, self.embed_tokens)
         residual = None
+        qkv_buf = None   # one padded [T, N + 128] buffer, reused by every layer
         for layer in self.layers:
             attn, mlp = layer.self_attn, layer.mlp
             ln1, ln2 = layer.input_layernorm, layer.post_attention_layernorm
@@ -549,8 +551,14 @@ class LlamaForCausalLM(nn.Module):
             else:
                 _, xq, xs = K.fused_add_rmsnorm_quant_fp8(hidden, residual, ln1.weight.data, ln1.variance_epsilon)
             lid = attn.attn.layer_id
+            # qkv rows padded by 256 bytes: extend attention reads the new tokens' K / V rows out of this tensor, and at the natural
+            # 12 KiB row stride (3 x 4 KiB) those rows fall into few HBM channels (tools/debug/ext_stride.py: 1 543 -> 1 411 us per launch; the 32x32x16 kernel takes
+            # row strides that are multiples of 128 elements)
+            n_qkv = attn.q_size + 2 * attn.kv_size
+            if self.pad_qkv_rows and (qkv_buf is None or qkv_buf.shape[0] != xq.shape[0] or qkv_buf.shape[1] != n_qkv + 128):
+                qkv_buf = torch.empty((xq.shape[0], n_qkv + 128), dtype=self.dtype, device=xq.device)
             qkv = K.fp8_scaled_mm(xq, attn.qkv_proj.weight, xs.view(-1), attn.qkv_proj.weight_scale.view(-1), self.dtype,
-                                  attn.qkv_proj.bias)
+                                  attn.qkv_proj.bias, out=qkv_buf[:, :n_qkv] if self.pad_qkv_rows else None)
             q, k, v = qkv.split([attn.q_size, attn.kv_size, attn.kv_size], dim=-1)
             attn.rope_and_write_kv(positions, q, k, v, forward_batch)
             o = backend.forward_extend(q, k.view(-1, attn.num_kv_heads, attn.head_dim), v.view(-1, attn.num_kv_heads, attn.head_dim),
