@@ -212,7 +212,9 @@ __global__ __launch_bounds__(256) void per_token_group_quant_kernel(const T* __r
 // Decode-sized batches (few tokens, one 256-thread workgroup each): the whole row is requested up front and held in registers
 // -- with the two strided loops of the general kernel every 16-byte piece was its own dependent L2 round trip (7 per thread at
 // hidden = 14336, twice), which is all a kernel with 32 workgroups is made of.  Same arithmetic, bit for bit.
-template <typename T, int MAXV>
+// NT: prefill-sized launches (the row is read once, the codes are read once by a GEMM that streams gigabytes): non-temporal loads and
+// stores, so the stream does not evict what the neighbouring kernels re-read
+template <typename T, int MAXV, bool NT = false>
 __global__ __launch_bounds__(256) void per_token_quant_row_kernel(const T* __restrict__ in, uint8_t* __restrict__ out_q,
                                                                   float* __restrict__ out_s, int hidden, int64_t in_stride) {
   __shared__ float red[4];
@@ -224,7 +226,8 @@ __global__ __launch_bounds__(256) void per_token_quant_row_kernel(const T* __res
 #pragma unroll
   for (int it = 0; it < MAXV; ++it) {
     const int i = tid + it * 256;
-    raw[it] = *(const u32x4_t*)(row + (i < nvec ? i : 0) * 8);
+    if constexpr (NT) raw[it] = __builtin_nontemporal_load((const u32x4_t*)(row + (i < nvec ? i : 0) * 8));
+    else raw[it] = *(const u32x4_t*)(row + (i < nvec ? i : 0) * 8);
   }
   float vals[MAXV][8];
   float amax = 0.f;
@@ -254,7 +257,8 @@ __global__ __launch_bounds__(256) void per_token_quant_row_kernel(const T* __res
       float f[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) f[j] = clamp448(vals[it][j] * inv);
-      *(u32x2_t*)(orow + i * 8) = pack8_fp8(f);
+      if constexpr (NT) __builtin_nontemporal_store(pack8_fp8(f), (u32x2_t*)(orow + i * 8));
+      else *(u32x2_t*)(orow + i * 8) = pack8_fp8(f);
     }
   }
 }
@@ -268,15 +272,22 @@ int launch_per_token(const void* in, void* q, float* s, int64_t tokens, int64_t 
   // twice with one wave (the second pass out of L2); at 65 536 x 14 336 it moved its 2.8 GB in 790 us = 3.6 TB/s
   const bool wide = SGL_QUANT_ROW_WIDE && hidden >= 4096;
   if ((tokens <= 512 || wide) && tokens < (1ll << 31) && hidden <= 256 * 8 * 8 && in_stride % 8 == 0 && ((uintptr_t)in % 16) == 0) {
-    if (hidden <= 256 * 8 * 2)
-      hipLaunchKernelGGL((per_token_quant_row_kernel<T, 2>), dim3((unsigned)tokens), dim3(256), 0, st, (const T*)in, (uint8_t*)q, s,
-                         (int)hidden, in_stride);
-    else if (hidden <= 256 * 8 * 4)
-      hipLaunchKernelGGL((per_token_quant_row_kernel<T, 4>), dim3((unsigned)tokens), dim3(256), 0, st, (const T*)in, (uint8_t*)q, s,
-                         (int)hidden, in_stride);
-    else
-      hipLaunchKernelGGL((per_token_quant_row_kernel<T, 8>), dim3((unsigned)tokens), dim3(256), 0, st, (const T*)in, (uint8_t*)q, s,
-                         (int)hidden, in_stride);
+#ifndef SGL_ROW_NT
+#define SGL_ROW_NT 1
+#endif
+    // (tools/debug/quant_time.py: 65 536 x 14 336 520 -> 447 us, 65 536 x 4096 138 -> 124 us, 16 384 x 14 336 128 -> 109 us)
+    const bool nt = SGL_ROW_NT && tokens * hidden >= (1ll << 27);
+#define SGL_ROWQ(MV)                                                                                                             \
+  do {                                                                                                                           \
+    if (nt) hipLaunchKernelGGL((per_token_quant_row_kernel<T, MV, true>), dim3((unsigned)tokens), dim3(256), 0, st, (const T*)in, \
+                               (uint8_t*)q, s, (int)hidden, in_stride);                                                          \
+    else hipLaunchKernelGGL((per_token_quant_row_kernel<T, MV, false>), dim3((unsigned)tokens), dim3(256), 0, st, (const T*)in,   \
+                            (uint8_t*)q, s, (int)hidden, in_stride);                                                             \
+  } while (0)
+    if (hidden <= 256 * 8 * 2) SGL_ROWQ(2);
+    else if (hidden <= 256 * 8 * 4) SGL_ROWQ(4);
+    else SGL_ROWQ(8);
+#undef SGL_ROWQ
     SGL_HIP_LAUNCH_CHECK();
     return SGL_MI355_OK;
   }

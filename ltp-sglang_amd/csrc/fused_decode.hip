@@ -15,7 +15,8 @@
 
 namespace {
 
-template <typename T, int MAXV, bool SLABS = true>  // SLABS = false drops the split-K registers: 4x the occupancy at prefill-sized M
+template <typename T, int MAXV, bool SLABS = true, bool NT = false>  // SLABS = false drops the split-K registers: 4x the occupancy at prefill-sized M;
+                                                                       // NT: non-temporal row loads / stores (prefill-sized launches)
 __global__ __launch_bounds__(256) void add_rmsnorm_quant_kernel(const T* x, const float* slabs_, int nslabs,
                                                                 const float* slab_sx, const float* slab_sw, T* residual,
                                                                 const T* weight, float eps, T* out_norm, uint8_t* out_q,
@@ -35,7 +36,7 @@ __global__ __launch_bounds__(256) void add_rmsnorm_quant_kernel(const T* x, cons
     const int i = threadIdx.x + it * 256;
     const int ic = i < nvec ? i : 0;  // clamped: lanes past the row read column 0 (harmless) instead of branching
     wreg[it] = ld8(weight + ic * 8);
-    if (residual) rreg[it] = ld8(residual + row * hidden + ic * 8);
+    if (residual) rreg[it] = NT ? ld8_nt(residual + row * hidden + ic * 8) : ld8(residual + row * hidden + ic * 8);
     if (slabs) {
       const float* sp = slabs + row * hidden + ic * 8;
       s0[it][0] = *(const f32x4_t*)sp;
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(256) void add_rmsnorm_quant_kernel(const T* x, cons
         swr[it][1] = *(const f32x4_t*)(slab_sw + ic * 8 + 4);
       }
     } else {
-      xreg[it] = ld8(x + row * hidden + ic * 8);
+      xreg[it] = NT ? ld8_nt(x + row * hidden + ic * 8) : ld8(x + row * hidden + ic * 8);
     }
   }
   float vals[MAXV][8];
@@ -100,7 +101,8 @@ __global__ __launch_bounds__(256) void add_rmsnorm_quant_kernel(const T* x, cons
           f[j] += (float)rreg[it].v[j];
           ro.v[j] = (T)f[j];
         }
-        st8(residual + row * hidden + i * 8, ro);
+        if constexpr (NT) st8_nt(residual + row * hidden + i * 8, ro);
+        else st8(residual + row * hidden + i * 8, ro);
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(256) void add_rmsnorm_quant_kernel(const T* x, cons
       if (out_norm) st8(out_norm + row * hidden + i * 8, o);
     }
   }
-  if (out_q) quant_row<MAXV>(vals, nvec, out_q + row * hidden, out_s + row, red);
+  if (out_q) quant_row<MAXV, NT>(vals, nvec, out_q + row * hidden, out_s + row, red);
 }
 
 template <typename T, int MAXV>
@@ -372,9 +374,20 @@ extern "C" int sgl_mi355_fused_add_rmsnorm_quant_fp8(const void* x, const float*
   SGL_CHECK(dtype == SGL_BF16 || dtype == SGL_F16, "fused_add_rmsnorm_quant_fp8: dtype must be bf16 or f16");
   SGL_CHECK(!slabs || nslabs >= 1, "fused_add_rmsnorm_quant_fp8: nslabs must be >= 1");
   hipStream_t st = (hipStream_t)stream;
-#define SGL_NORM_LAUNCH(MV, SL)                                                                                              \
-  hipLaunchKernelGGL((add_rmsnorm_quant_kernel<T, MV, SL>), dim3(tokens), dim3(256), 0, st, (const T*)x, slabs, nslabs, slab_sx, \
+#ifndef SGL_ROW_NT
+#define SGL_ROW_NT 1
+#endif
+  // prefill-sized launches stream their rows through once: non-temporal row loads / stores.  Measured (tools/debug/norm_time.py): 65 536 x
+  // 4096 322 -> 301 us, 65 536 x 8192 670 -> 605 us; 16 384 x 4096 (0.47 GB of traffic: it fits the 256 MB Infinity Cache half-way) 76 -> 80 us
+  const bool nt = SGL_ROW_NT && (int64_t)tokens * hidden >= (1ll << 28) && slabs == nullptr;
+#define SGL_NORM_LAUNCH_(MV, SL, NTV)                                                                                        \
+  hipLaunchKernelGGL((add_rmsnorm_quant_kernel<T, MV, SL, NTV>), dim3(tokens), dim3(256), 0, st, (const T*)x, slabs, nslabs, slab_sx, \
                      slab_sw, (T*)residual, (const T*)weight, eps, (T*)out_norm, (uint8_t*)out_q, out_s, tokens, hidden)
+#define SGL_NORM_LAUNCH(MV, SL)               \
+  do {                                        \
+    if (nt && !(SL)) SGL_NORM_LAUNCH_(MV, false, true); \
+    else SGL_NORM_LAUNCH_(MV, SL, false);     \
+  } while (0)
   DISPATCH_HALF(dtype, {
     if (slabs != nullptr) {
       if (hidden <= 4096) {
@@ -390,6 +403,7 @@ extern "C" int sgl_mi355_fused_add_rmsnorm_quant_fp8(const void* x, const float*
       SGL_NORM_LAUNCH(4, false);
     }
   })
+#undef SGL_NORM_LAUNCH_
 #undef SGL_NORM_LAUNCH
   SGL_HIP_LAUNCH_CHECK();
   return SGL_MI355_OK;

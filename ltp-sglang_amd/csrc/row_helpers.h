@@ -20,6 +20,15 @@ template <typename T>
 __device__ __forceinline__ void st8(T* p, const V8<T>& x) {
   *(u32x4_t*)p = __builtin_bit_cast(u32x4_t, x);
 }
+// non-temporal forms for prefill-sized row kernels: a row is read once and its results are read once, gigabytes later
+template <typename T>
+__device__ __forceinline__ V8<T> ld8_nt(const T* p) {
+  return __builtin_bit_cast(V8<T>, __builtin_nontemporal_load((const u32x4_t*)p));
+}
+template <typename T>
+__device__ __forceinline__ void st8_nt(T* p, const V8<T>& x) {
+  __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, x), (u32x4_t*)p);
+}
 
 // f32 -> T -> f32 through the bit pattern (see elementwise.hip: the rounding point must really happen)
 template <typename T>
@@ -62,7 +71,7 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 }
 
 // per-token fp8 quantisation of the row held in vals (already rounded to T), exactly per_token_quant_fp8.cu
-template <int MAXV>
+template <int MAXV, bool NT = false>
 __device__ __forceinline__ void quant_row(const float (&vals)[MAXV][8], int nvec, uint8_t* qrow, float* srow, float* red) {
   const bool on = threadIdx.x < 256;
   float amax = 0.f;
@@ -82,7 +91,8 @@ __device__ __forceinline__ void quant_row(const float (&vals)[MAXV][8], int nvec
       float f[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) f[j] = clamp448(vals[it][j] * inv);
-      *(u32x2_t*)(qrow + i * 8) = pack8_fp8(f);
+      if constexpr (NT) __builtin_nontemporal_store(pack8_fp8(f), (u32x2_t*)(qrow + i * 8));
+      else *(u32x2_t*)(qrow + i * 8) = pack8_fp8(f);
     }
   }
 }
