@@ -13,6 +13,10 @@
 #include "row_helpers.h"
 #include "silu_lut.h"
 
+#ifndef SGL_ROW_NT
+#define SGL_ROW_NT 1   // 0: ordinary loads / stores in the prefill-sized row kernels (A/B builds)
+#endif
+
 namespace {
 
 template <typename T, int MAXV, bool SLABS = true, bool NT = false>  // SLABS = false drops the split-K registers: 4x the occupancy at prefill-sized M;
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(256) void silu_mul_quant_kernel(const T* x, uint8_t
 // < 128, and walks `rows_per_wg` rows with one ds_read_u16 per element; anything outside the table (zeros, denormals, tiny or
 // huge values, inf, nan) takes the exact expression.  Bit-identical to silu_mul_quant_kernel by construction.
 
-template <int MAXV>
+template <int MAXV, bool NT = false>   // NT: non-temporal row loads / stores (prefill-sized launches)
 __global__ __launch_bounds__(256) void silu_mul_quant_lut_kernel(const __bf16* x, uint8_t* out_q, float* out_s, int d, int tokens,
                                                                  int rows_per_wg) {
   using T = __bf16;
@@ -175,7 +179,8 @@ __global__ __launch_bounds__(256) void silu_mul_quant_lut_kernel(const __bf16* x
     for (int it = 0; it < MAXV; ++it) {
       const int i = threadIdx.x + it * 256;
       if (i < nvec) {
-        const V8<T> a = ld8(x + row * 2 * d + i * 8), b = ld8(x + row * 2 * d + d + i * 8);
+        const V8<T> a = NT ? ld8_nt(x + row * 2 * d + i * 8) : ld8(x + row * 2 * d + i * 8);
+        const V8<T> b = NT ? ld8_nt(x + row * 2 * d + d + i * 8) : ld8(x + row * 2 * d + d + i * 8);
         // eight lookups in flight behind ONE wait; a wave with any element outside the table (rare: zeros, tiny / huge values)
         // evaluates the exact expression for the whole vector -- a wave-uniform branch, not a per-element exec mask (with the test
         // per element every ds_read was waited for on its own)
@@ -215,7 +220,7 @@ __global__ __launch_bounds__(256) void silu_mul_quant_lut_kernel(const __bf16* x
         for (int j = 0; j < 8; ++j) vals[it][j] = __uint_as_float((j & 1) ? (pw[j >> 1] & 0xFFFF0000u) : (pw[j >> 1] << 16));
       }
     }
-    quant_row<MAXV>(vals, nvec, out_q + row * d, out_s + row, red);
+    quant_row<MAXV, NT>(vals, nvec, out_q + row * d, out_s + row, red);
   }
 }
 
@@ -374,9 +379,6 @@ extern "C" int sgl_mi355_fused_add_rmsnorm_quant_fp8(const void* x, const float*
   SGL_CHECK(dtype == SGL_BF16 || dtype == SGL_F16, "fused_add_rmsnorm_quant_fp8: dtype must be bf16 or f16");
   SGL_CHECK(!slabs || nslabs >= 1, "fused_add_rmsnorm_quant_fp8: nslabs must be >= 1");
   hipStream_t st = (hipStream_t)stream;
-#ifndef SGL_ROW_NT
-#define SGL_ROW_NT 1
-#endif
   // prefill-sized launches stream their rows through once: non-temporal row loads / stores.  Measured (tools/debug/norm_time.py): 65 536 x
   // 4096 322 -> 301 us, 65 536 x 8192 670 -> 605 us; 16 384 x 4096 (0.47 GB of traffic: it fits the 256 MB Infinity Cache half-way) 76 -> 80 us
   const bool nt = SGL_ROW_NT && (int64_t)tokens * hidden >= (1ll << 28) && slabs == nullptr;
@@ -427,10 +429,14 @@ extern "C" int sgl_mi355_silu_and_mul_quant_fp8(const void* x, void* out_q, floa
     int rpw = tokens / 2048;
     rpw = rpw < 4 ? 4 : (rpw > 32 ? 32 : rpw);
     const unsigned grid = (unsigned)((tokens + rpw - 1) / rpw);
-    if (d <= 16384)
-      hipLaunchKernelGGL((silu_mul_quant_lut_kernel<8>), dim3(grid), dim3(256), 0, st, (const __bf16*)x, (uint8_t*)out_q, out_s, d, tokens, rpw);
-    else
-      hipLaunchKernelGGL((silu_mul_quant_lut_kernel<16>), dim3(grid), dim3(256), 0, st, (const __bf16*)x, (uint8_t*)out_q, out_s, d, tokens, rpw);
+    const bool nt = SGL_ROW_NT && (int64_t)tokens * d >= (1ll << 27);   // (2 d inputs per token: the add + RMSNorm + quant kernel's threshold in bytes)
+    if (d <= 16384) {
+      if (nt) hipLaunchKernelGGL((silu_mul_quant_lut_kernel<8, true>), dim3(grid), dim3(256), 0, st, (const __bf16*)x, (uint8_t*)out_q, out_s, d, tokens, rpw);
+      else hipLaunchKernelGGL((silu_mul_quant_lut_kernel<8>), dim3(grid), dim3(256), 0, st, (const __bf16*)x, (uint8_t*)out_q, out_s, d, tokens, rpw);
+    } else {
+      if (nt) hipLaunchKernelGGL((silu_mul_quant_lut_kernel<16, true>), dim3(grid), dim3(256), 0, st, (const __bf16*)x, (uint8_t*)out_q, out_s, d, tokens, rpw);
+      else hipLaunchKernelGGL((silu_mul_quant_lut_kernel<16>), dim3(grid), dim3(256), 0, st, (const __bf16*)x, (uint8_t*)out_q, out_s, d, tokens, rpw);
+    }
     SGL_HIP_LAUNCH_CHECK();
     return SGL_MI355_OK;
   }
