@@ -705,6 +705,10 @@ __global__ __launch_bounds__(NWV * 64, 1) void fp8_gemm256_kernel(const GemmPara
 // Buffers: two slices of [W 32 KiB | X 32 KiB], restaged REGION BY REGION as soon as a region's last reader is through -- W of slice
 // s + 2 in phase 2 of slice s, wave c's 32 X rows (read by its group in phase c) in the phase after -- so every DMA has 1.5-1.75
 // slices to land, as in the one-barrier kernel.  vmcnt: counted, once per slice (phase 3), never 0 in the loop.
+// What bounds the loop now (timing-only builds, -DSGL_PP_NOWAIT / NOREAD / NOSTAGE; K = 14 336, M = 65 536): without the counted waits
+// 2 711 vs 2 701 us, without the fragment reads 2 767 vs 2 796, WITHOUT THE IN-LOOP STAGING 2 223 vs 2 796 -- the delivery of 64 KiB per
+// slice and CU out of the L2 (and what it costs in power) is a fifth of the loop; the same bytes through registers (plain loads issued a
+// slice ahead, ds_write_b128 at the DMA form's issue points; built, bit-identical) are 15-25 % SLOWER than LDS-DMA, as the guide says.
 template <typename OutT, bool SILU = false, int PH = 2, int ES = TG_FP8, int WLATE = 0>   // PH: phases per K slice (2 blocks of 16 MFMAs -- the default -- or 4 of 8); ES as
                                                                                           // fp8_gemm256_kernel; WLATE: X fragments of the second block issued in front of the W staging
 __global__ __launch_bounds__(512, 1) void fp8_gemm256pp_kernel(const GemmParams p) {
@@ -746,12 +750,18 @@ __global__ __launch_bounds__(512, 1) void fp8_gemm256pp_kernel(const GemmParams 
   }
   const int nk = p.kbytes / BKB;
   auto stage_w = [&](int kt, int buf) {
+#ifdef SGL_PP_NOSTAGE   // timing-only build (wrong results): no staging inside the loop
+    if (kt > 1) return;
+#endif
     const int off = kt * BKB;
     auto* wb = (__attribute__((address_space(3))) char*)(smem + buf * BUFB + (WRPW * w) * BKB);
 #pragma unroll
     for (int t = 0; t < WRPW / 8; ++t) __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, wb + t * 8 * BKB, 16, wvo[t & 1], (int)(t * 8 * p.w_stride) + off, 0, 0);
   };
   auto stage_x = [&](int kt, int buf) {
+#ifdef SGL_PP_NOSTAGE
+    if (kt > 1) return;
+#endif
     const int off = kt * BKB;
     auto* xb = (__attribute__((address_space(3))) char*)(smem + buf * BUFB + WOPB + (RPW * w) * BKB);
 #pragma unroll
@@ -766,6 +776,9 @@ __global__ __launch_bounds__(512, 1) void fp8_gemm256pp_kernel(const GemmParams 
   constexpr int XG = 4 / PH;   // 32-row X groups per phase
   u32x4_t wf[JN][2], xf[XG * IG][2];
   auto load_w = [&](int buf) {
+#ifdef SGL_PP_NOREAD   // timing-only build (wrong results): fragments are read once
+    if (buf) return;
+#endif
     const char* wa = smem + buf * BUFB;
 #pragma unroll
     for (int j = 0; j < JN; ++j)
@@ -773,6 +786,9 @@ __global__ __launch_bounds__(512, 1) void fp8_gemm256pp_kernel(const GemmParams 
       for (int h = 0; h < 2; ++h) wf[j][h] = *(const u32x4_t*)(wa + lds_off(wn + 16 * j + a, 4 * h + g));
   };
   auto load_x = [&](int buf, int grp, int slot = 0) {
+#ifdef SGL_PP_NOREAD
+    if (buf) return;
+#endif
     const char* xa = smem + buf * BUFB + WOPB;
 #pragma unroll
     for (int i = 0; i < IG; ++i)
@@ -895,7 +911,8 @@ __global__ __launch_bounds__(512, 1) void fp8_gemm256pp_kernel(const GemmParams 
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (Q == 1 && WLATE > 0) {
       // W of slice s + 2: behind this barrier (both groups' W reads of slice s have retired) and BEHIND the block's first MFMAs -- in
-      // front of them the four DMA issues hold the matrix pipe idle once per slice
+      // front of them the four DMA issues hold the matrix pipe idle once per slice (one DMA behind each quarter of the block instead: no
+      // further difference)
       mma(2 * Q, 0, WLATE);
       __builtin_amdgcn_sched_barrier(0);
       stage_w(min(s + 2, nk - 1), buf);
