@@ -582,6 +582,7 @@ SCHED_CASES = {
     "group_20_d64": dict(seq=lambda g: torch.randint(20, 900, (19,), generator=g).tolist(), hq=40, hkv=2, d=64, dtype=torch.float16),
     "shard_128": dict(seq=lambda g: torch.randint(64, 700, (128,), generator=g).tolist(), hq=8, hkv=1, d=128, dtype=torch.bfloat16),
     "with_empty": dict(seq=lambda g: [0, 130, 0, 0, 64, 300, 0], hq=8, hkv=2, d=128, dtype=torch.bfloat16),
+    "batch_1500": dict(seq=lambda g: torch.randint(1, 40, (1500,), generator=g).tolist(), hq=8, hkv=1, d=128, dtype=torch.bfloat16),   # two scan chunks
 }
 
 
