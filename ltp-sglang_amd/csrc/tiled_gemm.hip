@@ -1536,7 +1536,7 @@ inline TileChoice choose_tile(int M, int N, int kbytes, int64_t x_stride_b, int6
   const int splits = splits128s(M, N, kbytes, have_workspace, workspace_floats, &kt_per);
   const double r = (double)t128 * splits / cus, rounds = r <= 1.0 ? 1.0 : 0.5 * (ceil(r) + r);
   const double cost128 = rounds * 24.0 * k4 / splits + (splits > 1 ? 7.0 : 0.0);
-  const double cost256 = ceil((double)t256 / cus) * 49.0 * k4;
+  const double cost256 = ceil((double)t256 / cus) * 46.0 * k4;   // (49 until round 5: the ping-pong schedule; M = 2048, N = 6144: one round in 46.4 us)
   const double costnar = ceil((double)tnar / cus) * 31.0 * k4;
   if (cost128 < cost256 && cost128 <= costnar) return kTile128s;
   return costnar < cost256 ? kTile256x128 : kTile256;
@@ -1557,7 +1557,7 @@ inline TileChoice choose_tile16(int M, int N, int kbytes, int64_t x_stride_b, in
   if (M <= 256 || r < 0.5) return kTileOld;
   if (t128 > 8 * (int64_t)cus) return kTile256;
   const double cost_old = (20.0 + 47.0 * r) * k8;
-  const double cost256 = ceil((double)t256 / cus) * 88.0 * k8;
+  const double cost256 = ceil((double)t256 / cus) * 84.0 * k8;   // (88 until round 5: the ping-pong schedule, -4 ... -9 % on 16-bit operands)
   const double costnar = ceil((double)tnar / cus) * 55.0 * k8;
   if (cost_old < cost256 && cost_old <= costnar) return kTileOld;
   return costnar < cost256 ? kTile256x128 : kTile256;
